@@ -1,0 +1,131 @@
+/*
+ * ck_oracle.h -- CPU ORACLE for the CamKifu per-frame vision hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product (camkifu_amd/) never does.
+ *
+ * It restates, in plain scalar C, what the reference computes on its hot path
+ * (reference = /root/reference, ArnaudPel/CamKifu).  The reference itself is pure Python;
+ * all arithmetic lives in OpenCV 3.1.0 (src/ckmain.py:53) and Keras-1/Theano
+ * (src/camkifu/stone/nn_manager.py:277-298), neither of which is vendored or installable
+ * here.  So each routine below follows the *call site* in the reference and the published
+ * algorithm of the library routine behind it.
+ *
+ * PARITY STATUS (see DESIGN.md "Oracle"):
+ *   - label codec, patch/grid geometry, hull ordering: pinned by the reference's own
+ *     known-answer tests / doctests (tests/golden/reference_known_answers.json).
+ *   - K1..K9 image stages and K11 CNN numerics: "parity unpinned" -- the reference holds
+ *     no golden image, edge map, line list or weights; these routines are pinned only by
+ *     independent brute-force restatements (numpy / pure python) in tests/.
+ */
+#ifndef CK_ORACLE_H
+#define CK_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* K1  cv2.medianBlur(frame, ksize)            board/bf_auto.py:72
+ * Exact per-channel ksize x ksize median, 8-bit, replicate border. */
+void ora_median(const uint8_t* src, int h, int w, int cn, int ksize, uint8_t* dst);
+
+/* K2  cv2.Canny(median, low, high) on a cn-channel 8-bit image   board/bf_auto.py:73
+ * aperture 3, L1 gradient.  map_out (optional, h*w): 0 = candidate that survived NMS,
+ * 1 = suppressed, 2 = strong seed (m > high) -- before hysteresis, with every strong
+ * NMS survivor marked 2 (OpenCV only pushes a subset; the closure is identical).
+ * mag_out / dx_out / dy_out (optional): per-pixel selected-channel values. */
+void ora_canny(const uint8_t* src, int h, int w, int cn, int low, int high,
+               uint8_t* edges, uint8_t* map_out, int32_t* mag_out,
+               int16_t* dx_out, int16_t* dy_out);
+
+/* K3  cv2.findContours(canny, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)   board/bf_auto.py:75
+ * Sequential Suzuki-Abe border following on a copy of the image whose 1-px frame is
+ * cleared (OpenCV 3.1 does this in place).  Contours are returned in DISCOVERY order
+ * (raster order of their start pixel); cv2 returns the reverse of this.
+ *   starts[k*2+{0,1}] = x,y of start pixel; npix/pix = every traced pixel (with repeats);
+ *   nvert/vert = CHAIN_APPROX_SIMPLE vertices.
+ * Returns the number of contours, or -1 if a capacity was exceeded. */
+int ora_find_external_suzuki(const uint8_t* edges, int h, int w,
+                             int max_contours, int* starts,
+                             int* pix_off, int* vert_off,   /* max_contours+1 each */
+                             int max_pix, int* pix_xy, int max_vert, int* vert_xy);
+
+/* Set-based restatement used by the GPU design: frame-cleared image; S0 = 4-connected
+ * background reached from the frame; top-level 8-components = those with a pixel
+ * 4-adjacent to S0; outer border = such pixels.  labels_out (h*w int32): component id
+ * (0..n-1 in raster order of first pixel) for outer-border pixels of top-level
+ * components, -1 elsewhere.  Returns number of top-level components. */
+int ora_find_external_sets(const uint8_t* edges, int h, int w, int32_t* labels_out,
+                           int max_contours, int* starts);
+
+/* K4  cv2.minAreaRect(contour)    core/imgutil.py:423-428
+ * Convex hull (cv::convexHull clockwise=true ordering) + rotating calipers in float32.
+ * pts: n x 2 int32.  out_wh[0..1] = box size (width,height) as float32. */
+void ora_min_area_rect(const int32_t* pts, int n, float* out_wh);
+
+/* imgutil.sort_contours_box + sorted_boxes[-3:]   core/imgutil.py:291-315, bf_auto.py:78-84
+ * areas given in cv2 enumeration order (reverse discovery).  Emulates bisect.insort on
+ * BoundingBox.__lt__.  out_pos: up to 3 positions (ascending area order, i.e. the order
+ * of sorted_boxes[-3:]); returns how many; *biggest = largest area. */
+int ora_top3(const double* areas, int n, int* out_pos, double* biggest);
+
+/* K3..K6 chained as BoardFinderAuto._detect + find_lines do     board/bf_auto.py:75-84,105-141
+ * edges -> ghost (h*w, 0/255) and Hough lines.  lines: cap x 2 float (rho,theta), sorted as
+ * OpenCV sorts them.  Returns number of lines (may exceed cap: only cap are written), or -1
+ * if there is no contour, or -2 if the area gate (frame_area/3 < biggest) fails.
+ * *biggest_area receives sorted_boxes[-1].area when >= -2 ... (always when n contours > 0). */
+int ora_board_lines(const uint8_t* edges, int h, int w, int hough_thresh,
+                    uint8_t* ghost, float* lines, int cap, double* biggest_area,
+                    int* n_contours);
+
+/* K6  cv2.HoughLines(ghost, 1, pi/180, threshold)   board/bf_auto.py:132-133 */
+int ora_hough_lines(const uint8_t* img, int h, int w, int threshold,
+                    float* lines, int cap, int32_t* accum_out /* optional (182*(numrho+2)) */);
+
+/* K8  cv2.warpPerspective(frame, M, (dsize,dsize))  stone/stonesfinder.py:140
+ * INTER_LINEAR, BORDER_CONSTANT(0); M maps src->dst (inverted internally like cv2).
+ * Minv_out (optional 9 doubles) receives the inverse used. */
+void ora_warp_perspective(const uint8_t* src, int h, int w, int cn, const double* M,
+                          int dsize_w, int dsize_h, uint8_t* dst, double* Minv_out);
+
+/* K7  cv2.getPerspectiveTransform(src4, dst4)   board/boardfinder.py:43-45
+ * src/dst: 4x2 float32.  M: 9 doubles.  (OpenCV solves the 8x8 system by SVD; this uses
+ * Gaussian elimination with partial pivoting -- same solution to ~1e-12.) Returns 0 ok. */
+int ora_get_perspective_transform(const float* src, const float* dst, double* M);
+
+/* K9  cv2.createBackgroundSubtractorMOG2(detectShadows=False).apply(img, learningRate)
+ *     stone/stonesfinder.py:113-115, 171-176 */
+typedef struct ora_mog2 ora_mog2;
+ora_mog2* ora_mog2_create(int h, int w, int cn);
+void ora_mog2_destroy(ora_mog2*);
+void ora_mog2_apply(ora_mog2*, const uint8_t* img, double learning_rate, uint8_t* fgmask);
+
+/* K10-K12  NNManager._get_x / create_net / NNCache.predict_*   stone/nn_manager.py:216-298,
+ *          stone/nn_cache.py:16-52
+ * Weights in Keras-1 'tf' layout: conv kernels [kh][kw][cin][cout] applied as a TRUE
+ * convolution (Theano flips), dense [in][out]. */
+typedef struct {
+    const float *c1w, *c1b;   /* 5,5,3,32   / 32  */
+    const float *c2w, *c2b;   /* 5,5,32,32  / 32  */
+    const float *c3w, *c3b;   /* 3,3,32,90  / 90  */
+    const float *c4w, *c4b;   /* 3,3,90,90  / 90  */
+    const float *d1w, *d1b;   /* 3240,160   / 160 */
+    const float *d2w, *d2b;   /* 160,81     / 81  */
+} ora_cnn_weights;
+
+/* goban: 380x380x3 u8.  y_out: 100 x 81 softmax (region order i*10+j).
+ * logits_out optional 100x81.  */
+void ora_cnn_predict_regions(const ora_cnn_weights* W, const uint8_t* goban,
+                             float* y_out, float* logits_out);
+/* patches: n x 40 x 40 x 3 u8 -> y n x 81 */
+void ora_cnn_forward(const ora_cnn_weights* W, const uint8_t* patches, int n,
+                     float* y_out, float* logits_out);
+/* NNCache.predict_all_stones: labels 19x19 u8 {0=E,1=B,2=W}, conf 19x19 double */
+void ora_decode_all(const float* y /*100x81*/, uint8_t* labels, double* conf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
