@@ -1,0 +1,423 @@
+// ck_api.hip -- C-ABI entry points of libck_hip.so (see include/camkifu_amd.h).
+// Host-side glue only: argument checks, staging between host and HBM, and the order in
+// which the stage kernels are launched on the context's stream.
+#include <stdarg.h>
+
+#include "ck_common.h"
+
+thread_local std::string g_ck_create_error;
+
+int ck_fail(ck_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_ck_create_error = buf;
+    return code;
+}
+
+int ck_ensure(ck_ctx* ctx, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return CK_OK;
+    if (b.p) { CK_HIP(ctx, hipStreamSynchronize(ctx->stream)); CK_HIP(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    CK_HIP(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return CK_OK;
+}
+
+int ck_ensure_pinned(ck_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->host_pinned_cap) return CK_OK;
+    if (ctx->host_pinned) { CK_HIP(ctx, hipHostFree(ctx->host_pinned)); ctx->host_pinned = nullptr; ctx->host_pinned_cap = 0; }
+    CK_HIP(ctx, hipHostMalloc(&ctx->host_pinned, bytes, hipHostMallocDefault));
+    ctx->host_pinned_cap = bytes;
+    return CK_OK;
+}
+
+int ck_to_device(ck_ctx* ctx, const void* src, size_t bytes, int space, DevBuf& stage, const void** dev)
+{
+    if (space == CK_DEVICE) { *dev = src; return CK_OK; }
+    if (space != CK_HOST) return ck_fail(ctx, CK_ERR_ARG, "bad memory space %d", space);
+    CK_TRY(ck_ensure(ctx, stage, bytes));
+    CK_HIP(ctx, hipMemcpyAsync(stage.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev = stage.p;
+    return CK_OK;
+}
+
+int ck_from_device(ck_ctx* ctx, void* dst, const void* dev, size_t bytes, int space)
+{
+    if (!dst || dst == dev) return CK_OK;
+    if (space == CK_DEVICE) {
+        CK_HIP(ctx, hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        CK_HIP(ctx, hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return CK_OK;
+}
+
+// ---- timing ---------------------------------------------------------------------------
+TimeScope::TimeScope(ck_ctx* c, const char* name) : ctx(c)
+{
+    if (!ctx->timing) return;
+    PendingEvent pe;
+    auto get = [&](hipEvent_t* e) {
+        if (!ctx->event_pool.empty()) { *e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+        else (void)hipEventCreate(e);
+    };
+    get(&pe.a); get(&pe.b);
+    pe.name = name;
+    (void)hipEventRecord(pe.a, ctx->stream);
+    ctx->pending.push_back(pe);
+    idx = (int)ctx->pending.size() - 1;
+}
+TimeScope::~TimeScope()
+{
+    if (idx >= 0) (void)hipEventRecord(ctx->pending[idx].b, ctx->stream);
+}
+
+int ck_timing_collect(ck_ctx* ctx)
+{
+    for (auto& pe : ctx->pending) {
+        float ms = 0;
+        if (hipEventSynchronize(pe.b) == hipSuccess && hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+            auto& s = ctx->slots[pe.name];
+            s.ms += ms; s.launches += 1;
+        }
+        ctx->event_pool.push_back(pe.a);
+        ctx->event_pool.push_back(pe.b);
+    }
+    ctx->pending.clear();
+    return CK_OK;
+}
+
+extern "C" {
+
+int ck_version(void) { return 100; }
+
+int ck_ctx_create(int device, ck_ctx** out)
+{
+    if (!out) return ck_fail(nullptr, CK_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return ck_fail(nullptr, CK_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count) return ck_fail(nullptr, CK_ERR_ARG, "device %d out of range [0,%d)", device, count);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return ck_fail(nullptr, CK_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    ck_ctx* ctx = new ck_ctx();
+    ctx->device = device;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return ck_fail(nullptr, CK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    *out = ctx;
+    return CK_OK;
+}
+
+void ck_ctx_destroy(ck_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* bufs[] = { &ctx->in_stage, &ctx->in_stage2, &ctx->planes, &ctx->edges, &ctx->map, &ctx->labels,
+                       &ctx->labels2, &ctx->ghost, &ctx->misc, &ctx->comp, &ctx->pts, &ctx->accum, &ctx->peaks,
+                       &ctx->goban, &ctx->act0, &ctx->act1, &ctx->act2, &ctx->ybuf, &ctx->lblbuf, &ctx->confbuf,
+                       &ctx->out_stage, &ctx->mats,
+                       &ctx->cnn.c1w, &ctx->cnn.c1b, &ctx->cnn.c2w, &ctx->cnn.c2b, &ctx->cnn.c3w, &ctx->cnn.c3b,
+                       &ctx->cnn.c4w, &ctx->cnn.c4b, &ctx->cnn.d1w, &ctx->cnn.d1b, &ctx->cnn.d2w, &ctx->cnn.d2b,
+                       &ctx->cnn.c2w_bf, &ctx->cnn.c3w_bf, &ctx->cnn.c4w_bf, &ctx->cnn.d1w_bf };
+    for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    for (auto& m : ctx->mog2) {
+        DevBuf* mb[] = { &m.weight, &m.variance, &m.mean, &m.nmodes };
+        for (DevBuf* b : mb) if (b->p) (void)hipFree(b->p);
+    }
+    for (auto& pe : ctx->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* ck_last_error(const ck_ctx* ctx) { return ctx ? ctx->err.c_str() : g_ck_create_error.c_str(); }
+int ck_backend(const ck_ctx*) { return CK_BACKEND_HIP; }
+void* ck_stream(ck_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int ck_timing_enable(ck_ctx* ctx, int on) { if (!ctx) return CK_ERR_ARG; ctx->timing = on != 0; return CK_OK; }
+int ck_timing_reset(ck_ctx* ctx)
+{
+    if (!ctx) return CK_ERR_ARG;
+    ck_timing_collect(ctx);
+    ctx->slots.clear();
+    return CK_OK;
+}
+int ck_timing_get(ck_ctx* ctx, const char* name, double* total_ms, int* launches)
+{
+    if (!ctx || !name) return CK_ERR_ARG;
+    ck_timing_collect(ctx);
+    auto it = ctx->slots.find(name);
+    if (total_ms) *total_ms = it == ctx->slots.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == ctx->slots.end() ? 0 : it->second.launches;
+    return CK_OK;
+}
+
+static int check_img(ck_ctx* ctx, const void* p, int n, int h, int w)
+{
+    if (!ctx) return CK_ERR_ARG;
+    if (!p) return ck_fail(ctx, CK_ERR_ARG, "image pointer is NULL");
+    if (n <= 0 || h <= 0 || w <= 0) return ck_fail(ctx, CK_ERR_ARG, "bad shape n=%d h=%d w=%d", n, h, w);
+    if ((long long)h * w > (1LL << 28)) return ck_fail(ctx, CK_ERR_ARG, "image too large");
+    CK_HIP(ctx, hipSetDevice(ctx->device));
+    return CK_OK;
+}
+
+static int finish(ck_ctx* ctx)
+{
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CK_HIP(ctx, hipGetLastError());
+    return CK_OK;
+}
+
+int ck_median15(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space, uint8_t* out, int out_space)
+{
+    CK_TRY(check_img(ctx, bgr, n, h, w));
+    if (!out) return ck_fail(ctx, CK_ERR_ARG, "out is NULL");
+    const size_t bytes = (size_t)n * h * w * 3;
+    const int pitch = ck_pitch(w);
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, bgr, bytes, in_space, ctx->in_stage, &d_in));
+    CK_TRY(ck_ensure(ctx, ctx->planes, (size_t)n * 3 * h * pitch));
+    CK_TRY(k_median15_planar(ctx, (const uint8_t*)d_in, n, h, w, (uint8_t*)ctx->planes.p, pitch));
+    uint8_t* d_out = out;
+    if (out_space == CK_HOST) { CK_TRY(ck_ensure(ctx, ctx->out_stage, bytes)); d_out = (uint8_t*)ctx->out_stage.p; }
+    CK_TRY(k_planar_to_interleaved(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, d_out));
+    if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, out, d_out, bytes, CK_HOST));
+    return finish(ctx);
+}
+
+int ck_canny(ck_ctx* ctx, const uint8_t* img3, int n, int h, int w, int in_space,
+             int low, int high, uint8_t* edges, uint8_t* map_out, int out_space)
+{
+    CK_TRY(check_img(ctx, img3, n, h, w));
+    if (!edges) return ck_fail(ctx, CK_ERR_ARG, "edges is NULL");
+    const size_t npx = (size_t)n * h * w;
+    const int pitch = ck_pitch(w);
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, img3, npx * 3, in_space, ctx->in_stage, &d_in));
+    CK_TRY(ck_ensure(ctx, ctx->planes, (size_t)n * 3 * h * pitch));
+    CK_TRY(k_interleaved_to_planar(ctx, (const uint8_t*)d_in, n, h, w, pitch, (uint8_t*)ctx->planes.p));
+    CK_TRY(ck_ensure(ctx, ctx->map, npx));
+    CK_TRY(ck_ensure(ctx, ctx->labels, npx * 4));
+    uint8_t* d_edges = edges;
+    uint8_t* d_mapout = map_out;
+    if (out_space == CK_HOST) {
+        CK_TRY(ck_ensure(ctx, ctx->edges, npx)); d_edges = (uint8_t*)ctx->edges.p;
+        if (map_out) { CK_TRY(ck_ensure(ctx, ctx->out_stage, npx)); d_mapout = (uint8_t*)ctx->out_stage.p; }
+    }
+    CK_TRY(k_canny_planar(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, low, high,
+                          (uint8_t*)ctx->map.p, (int32_t*)ctx->labels.p, d_edges, d_mapout));
+    if (out_space == CK_HOST) {
+        CK_TRY(ck_from_device(ctx, edges, d_edges, npx, CK_HOST));
+        if (map_out) CK_TRY(ck_from_device(ctx, map_out, d_mapout, npx, CK_HOST));
+    }
+    return finish(ctx);
+}
+
+static int board_edges_dev(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, uint8_t* d_edges)
+{
+    const size_t npx = (size_t)n * h * w;
+    const int pitch = ck_pitch(w);
+    CK_TRY(ck_ensure(ctx, ctx->planes, (size_t)n * 3 * h * pitch));
+    CK_TRY(ck_ensure(ctx, ctx->map, npx));
+    CK_TRY(ck_ensure(ctx, ctx->labels, npx * 4));
+    CK_TRY(k_median15_planar(ctx, d_bgr, n, h, w, (uint8_t*)ctx->planes.p, pitch));
+    CK_TRY(k_canny_planar(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, 25, 75,
+                          (uint8_t*)ctx->map.p, (int32_t*)ctx->labels.p, d_edges, nullptr));
+    return CK_OK;
+}
+
+int ck_board_edges(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space, uint8_t* edges, int out_space)
+{
+    CK_TRY(check_img(ctx, bgr, n, h, w));
+    if (!edges) return ck_fail(ctx, CK_ERR_ARG, "edges is NULL");
+    const size_t npx = (size_t)n * h * w;
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, bgr, npx * 3, in_space, ctx->in_stage, &d_in));
+    uint8_t* d_edges = edges;
+    if (out_space == CK_HOST) { CK_TRY(ck_ensure(ctx, ctx->edges, npx)); d_edges = (uint8_t*)ctx->edges.p; }
+    CK_TRY(board_edges_dev(ctx, (const uint8_t*)d_in, n, h, w, d_edges));
+    if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, edges, d_edges, npx, CK_HOST));
+    return finish(ctx);
+}
+
+int ck_board_lines(ck_ctx* ctx, const uint8_t* edges, int n, int h, int w, int in_space,
+                   int hough_thresh, float* lines, int cap, ck_board_result* res,
+                   uint8_t* ghost_out, int ghost_space)
+{
+    CK_TRY(check_img(ctx, edges, n, h, w));
+    if (!lines || !res || cap <= 0) return ck_fail(ctx, CK_ERR_ARG, "lines/res NULL or cap <= 0");
+    if (h < 3 || w < 3) return ck_fail(ctx, CK_ERR_ARG, "image smaller than 3x3");
+    const size_t npx = (size_t)n * h * w;
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, edges, npx, in_space, ctx->in_stage2, &d_in));
+    if (hough_thresh < 0) hough_thresh = (int)((h < w ? h : w) / 5.0);
+    uint8_t* d_ghost = nullptr;
+    if (ghost_out) {
+        if (ghost_space == CK_DEVICE) d_ghost = ghost_out;
+        else { CK_TRY(ck_ensure(ctx, ctx->out_stage, npx)); d_ghost = (uint8_t*)ctx->out_stage.p; }
+    }
+    CK_TRY(k_board_lines(ctx, (const uint8_t*)d_in, n, h, w, hough_thresh, lines, cap, res, d_ghost));
+    if (ghost_out && ghost_space == CK_HOST) CK_TRY(ck_from_device(ctx, ghost_out, d_ghost, npx, CK_HOST));
+    return finish(ctx);
+}
+
+int ck_board_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
+                    int hough_thresh, float* lines, int cap, ck_board_result* res)
+{
+    CK_TRY(check_img(ctx, bgr, n, h, w));
+    if (!lines || !res || cap <= 0) return ck_fail(ctx, CK_ERR_ARG, "lines/res NULL or cap <= 0");
+    if (h < 3 || w < 3) return ck_fail(ctx, CK_ERR_ARG, "image smaller than 3x3");
+    const size_t npx = (size_t)n * h * w;
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, bgr, npx * 3, in_space, ctx->in_stage, &d_in));
+    CK_TRY(ck_ensure(ctx, ctx->edges, npx));
+    CK_TRY(board_edges_dev(ctx, (const uint8_t*)d_in, n, h, w, (uint8_t*)ctx->edges.p));
+    if (hough_thresh < 0) hough_thresh = (int)((h < w ? h : w) / 5.0);
+    CK_TRY(k_board_lines(ctx, (const uint8_t*)ctx->edges.p, n, h, w, hough_thresh, lines, cap, res, nullptr));
+    return finish(ctx);
+}
+
+static int upload_minv(ck_ctx* ctx, const double* M, int m_count, int n, const double** d_minv)
+{
+    if (!M) return ck_fail(ctx, CK_ERR_ARG, "M is NULL");
+    if (m_count != 1 && m_count != n) return ck_fail(ctx, CK_ERR_ARG, "m_count must be 1 or n");
+    std::vector<double> inv((size_t)m_count * 9);
+    for (int i = 0; i < m_count; i++) ck_invert3x3(M + 9 * i, inv.data() + 9 * i);
+    CK_TRY(ck_ensure(ctx, ctx->mats, inv.size() * sizeof(double)));
+    // pageable source: the copy is staged by the runtime before the call returns
+    CK_HIP(ctx, hipMemcpyAsync(ctx->mats.p, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *d_minv = (const double*)ctx->mats.p;
+    return CK_OK;
+}
+
+int ck_warp_perspective(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
+                        const double* M, int m_count, int dsize, uint8_t* out, int out_space)
+{
+    CK_TRY(check_img(ctx, bgr, n, h, w));
+    if (!out || dsize <= 0) return ck_fail(ctx, CK_ERR_ARG, "out NULL or dsize <= 0");
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, bgr, (size_t)n * h * w * 3, in_space, ctx->in_stage, &d_in));
+    const double* d_minv;
+    CK_TRY(upload_minv(ctx, M, m_count, n, &d_minv));
+    const size_t obytes = (size_t)n * dsize * dsize * 3;
+    uint8_t* d_out = out;
+    if (out_space == CK_HOST) { CK_TRY(ck_ensure(ctx, ctx->goban, obytes)); d_out = (uint8_t*)ctx->goban.p; }
+    CK_TRY(k_warp(ctx, (const uint8_t*)d_in, n, h, w, d_minv, m_count, dsize, d_out));
+    if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, out, d_out, obytes, CK_HOST));
+    return finish(ctx);
+}
+
+int ck_cnn_set_weights(ck_ctx* ctx, const float* const weights[12], int space)
+{
+    if (!ctx || !weights) return CK_ERR_ARG;
+    for (int i = 0; i < 12; i++) if (!weights[i]) return ck_fail(ctx, CK_ERR_ARG, "weights[%d] is NULL", i);
+    CK_HIP(ctx, hipSetDevice(ctx->device));
+    CK_TRY(k_cnn_pack_weights(ctx, weights, space));
+    return finish(ctx);
+}
+
+int ck_cnn_set_mode(ck_ctx* ctx, int mode)
+{
+    if (!ctx) return CK_ERR_ARG;
+    if (mode != CK_CNN_FP32 && mode != CK_CNN_BF16) return ck_fail(ctx, CK_ERR_ARG, "unknown cnn mode %d", mode);
+    ctx->cnn_mode = mode;
+    return CK_OK;
+}
+
+static int cnn_predict_dev(ck_ctx* ctx, const uint8_t* d_goban, int n, float* y, uint8_t* labels, double* conf, int out_space)
+{
+    if (!ctx->cnn.set) return ck_fail(ctx, CK_ERR_STATE, "ck_cnn_set_weights has not been called");
+    CK_TRY(ck_ensure(ctx, ctx->ybuf, (size_t)n * 8100 * sizeof(float)));
+    CK_TRY(ck_ensure(ctx, ctx->lblbuf, (size_t)n * 361));
+    CK_TRY(ck_ensure(ctx, ctx->confbuf, (size_t)n * 361 * sizeof(double)));
+    CK_TRY(k_cnn_predict(ctx, d_goban, n, (float*)ctx->ybuf.p, (uint8_t*)ctx->lblbuf.p, (double*)ctx->confbuf.p));
+    if (y) CK_TRY(ck_from_device(ctx, y, ctx->ybuf.p, (size_t)n * 8100 * sizeof(float), out_space));
+    if (labels) CK_TRY(ck_from_device(ctx, labels, ctx->lblbuf.p, (size_t)n * 361, out_space));
+    if (conf) CK_TRY(ck_from_device(ctx, conf, ctx->confbuf.p, (size_t)n * 361 * sizeof(double), out_space));
+    return CK_OK;
+}
+
+int ck_cnn_predict(ck_ctx* ctx, const uint8_t* goban, int n, int in_space,
+                   float* y, uint8_t* labels, double* conf, int out_space)
+{
+    if (!ctx) return CK_ERR_ARG;
+    if (!goban || n <= 0) return ck_fail(ctx, CK_ERR_ARG, "goban NULL or n <= 0");
+    CK_HIP(ctx, hipSetDevice(ctx->device));
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, goban, (size_t)n * 380 * 380 * 3, in_space, ctx->in_stage, &d_in));
+    CK_TRY(cnn_predict_dev(ctx, (const uint8_t*)d_in, n, y, labels, conf, out_space));
+    return finish(ctx);
+}
+
+int ck_stones_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
+                     const double* M, int m_count, uint8_t* labels, double* conf, int out_space)
+{
+    CK_TRY(check_img(ctx, bgr, n, h, w));
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, bgr, (size_t)n * h * w * 3, in_space, ctx->in_stage, &d_in));
+    const double* d_minv;
+    CK_TRY(upload_minv(ctx, M, m_count, n, &d_minv));
+    CK_TRY(ck_ensure(ctx, ctx->goban, (size_t)n * 380 * 380 * 3));
+    CK_TRY(k_warp(ctx, (const uint8_t*)d_in, n, h, w, d_minv, m_count, 380, (uint8_t*)ctx->goban.p));
+    CK_TRY(cnn_predict_dev(ctx, (const uint8_t*)ctx->goban.p, n, nullptr, labels, conf, out_space));
+    return finish(ctx);
+}
+
+int ck_mog2_create(ck_ctx* ctx, int h, int w, int* handle)
+{
+    if (!ctx || !handle || h <= 0 || w <= 0) return CK_ERR_ARG;
+    CK_HIP(ctx, hipSetDevice(ctx->device));
+    int idx = -1;
+    for (size_t i = 0; i < ctx->mog2.size(); i++) if (!ctx->mog2[i].alive) { idx = (int)i; break; }
+    if (idx < 0) { ctx->mog2.emplace_back(); idx = (int)ctx->mog2.size() - 1; }
+    Mog2State& st = ctx->mog2[idx];
+    st.h = h; st.w = w; st.nframes = 0; st.alive = true;
+    const size_t npx = (size_t)h * w;
+    CK_TRY(ck_ensure(ctx, st.weight, npx * 5 * sizeof(float)));
+    CK_TRY(ck_ensure(ctx, st.variance, npx * 5 * sizeof(float)));
+    CK_TRY(ck_ensure(ctx, st.mean, npx * 15 * sizeof(float)));
+    CK_TRY(ck_ensure(ctx, st.nmodes, npx));
+    CK_HIP(ctx, hipMemsetAsync(st.nmodes.p, 0, npx, ctx->stream));
+    *handle = idx;
+    return finish(ctx);
+}
+
+int ck_mog2_apply(ck_ctx* ctx, int handle, const uint8_t* img3, int in_space,
+                  double learning_rate, uint8_t* fgmask, int out_space)
+{
+    if (!ctx) return CK_ERR_ARG;
+    if (handle < 0 || handle >= (int)ctx->mog2.size() || !ctx->mog2[handle].alive)
+        return ck_fail(ctx, CK_ERR_ARG, "bad mog2 handle %d", handle);
+    if (!img3 || !fgmask) return ck_fail(ctx, CK_ERR_ARG, "NULL image or mask");
+    CK_HIP(ctx, hipSetDevice(ctx->device));
+    Mog2State& st = ctx->mog2[handle];
+    const size_t npx = (size_t)st.h * st.w;
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, img3, npx * 3, in_space, ctx->in_stage, &d_in));
+    uint8_t* d_fg = fgmask;
+    if (out_space == CK_HOST) { CK_TRY(ck_ensure(ctx, ctx->out_stage, npx)); d_fg = (uint8_t*)ctx->out_stage.p; }
+    CK_TRY(k_mog2_apply(ctx, st, (const uint8_t*)d_in, learning_rate, d_fg));
+    if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, fgmask, d_fg, npx, CK_HOST));
+    return finish(ctx);
+}
+
+int ck_mog2_destroy(ck_ctx* ctx, int handle)
+{
+    if (!ctx || handle < 0 || handle >= (int)ctx->mog2.size()) return CK_ERR_ARG;
+    ctx->mog2[handle].alive = false;
+    return CK_OK;
+}
+
+}  // extern "C"

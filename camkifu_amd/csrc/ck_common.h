@@ -1,0 +1,131 @@
+// ck_common.h -- internal declarations shared by the HIP translation units of libck_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/camkifu_amd.h"
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct TimingSlot {
+    double ms = 0;
+    int launches = 0;
+};
+
+struct PendingEvent {
+    hipEvent_t a, b;
+    std::string name;
+};
+
+struct Mog2State {
+    int h = 0, w = 0, nframes = 0;
+    DevBuf weight, variance, mean, nmodes;
+    bool alive = false;
+};
+
+struct CnnWeights {
+    bool set = false;
+    // repacked fp32 (correlation layout, [kh][kw][cin][cout] with the flip applied)
+    DevBuf c1w, c1b, c2w, c2b, c3w, c3b, c4w, c4b, d1w, d1b, d2w, d2b;
+    // bf16 packs for the MFMA path
+    DevBuf c2w_bf, c3w_bf, c4w_bf, d1w_bf;
+};
+
+struct ck_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool timing = false;
+    std::map<std::string, TimingSlot> slots;
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+
+    // scratch (grown on demand, never shrunk)
+    DevBuf in_stage;     // staged host input
+    DevBuf in_stage2;
+    DevBuf planes;       // median output, planar n*3*h*pitch
+    DevBuf edges;        // n*h*w
+    DevBuf map;          // n*h*w NMS map
+    DevBuf labels;       // n*h*w int32 union-find parents
+    DevBuf labels2;
+    DevBuf ghost;        // n*h*w
+    DevBuf misc;         // small per-frame counters
+    DevBuf comp;         // per-frame component tables
+    DevBuf pts;          // compacted border points
+    DevBuf accum;        // hough accumulators
+    DevBuf peaks;
+    DevBuf goban;        // n*380*380*3
+    DevBuf act0, act1, act2;   // cnn activations
+    DevBuf ybuf, lblbuf, confbuf;
+    DevBuf out_stage;
+    DevBuf mats;
+    void* host_pinned = nullptr;
+    size_t host_pinned_cap = 0;
+
+    CnnWeights cnn;
+    int cnn_mode = CK_CNN_FP32;
+    std::vector<Mog2State> mog2;
+};
+
+extern thread_local std::string g_ck_create_error;
+
+int ck_fail(ck_ctx* ctx, int code, const char* fmt, ...);
+int ck_ensure(ck_ctx* ctx, DevBuf& b, size_t bytes);
+int ck_ensure_pinned(ck_ctx* ctx, size_t bytes);
+
+#define CK_HIP(ctx, call)                                                                 \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess)                                                            \
+            return ck_fail((ctx), CK_ERR_HIP, "%s failed: %s (%s:%d)", #call,             \
+                           hipGetErrorString(e__), __FILE__, __LINE__);                   \
+    } while (0)
+
+#define CK_TRY(call)                     \
+    do {                                 \
+        int rc__ = (call);               \
+        if (rc__ != CK_OK) return rc__;  \
+    } while (0)
+
+// timing brackets: record HIP events on the ctx stream around a group of launches
+struct TimeScope {
+    ck_ctx* ctx;
+    int idx = -1;
+    TimeScope(ck_ctx* c, const char* name);
+    ~TimeScope();
+};
+int ck_timing_collect(ck_ctx* ctx);
+
+// bring a possibly-host input to the device (returns device pointer in *dev)
+int ck_to_device(ck_ctx* ctx, const void* src, size_t bytes, int space, DevBuf& stage, const void** dev);
+// deliver a device result to a possibly-host output
+int ck_from_device(ck_ctx* ctx, void* dst, const void* dev, size_t bytes, int space);
+
+static inline int ck_pitch(int w) { return (w + 63) & ~63; }
+
+// ---- kernels (one launcher per stage; all asynchronous on ctx->stream) -----------------
+int k_median15_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, uint8_t* d_planes, int pitch);
+int k_planar_to_interleaved(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, uint8_t* d_out);
+int k_interleaved_to_planar(ck_ctx* ctx, const uint8_t* d_in, int n, int h, int w, int pitch, uint8_t* d_planes);
+// canny: planar 3-channel input -> map (0/1/2) -> edges (0/255); labels = scratch n*h*w int32
+int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, int low, int high,
+                   uint8_t* d_map, int32_t* d_labels, uint8_t* d_edges, uint8_t* d_map_out);
+int k_warp(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, const double* d_minv, int m_count,
+           int dsize, uint8_t* d_out);
+int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int hough_thresh,
+                  float* lines, int cap, ck_board_result* res, uint8_t* d_ghost_out);
+int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int n, float* d_y, uint8_t* d_labels, double* d_conf);
+int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space);
+int k_mog2_apply(ck_ctx* ctx, Mog2State& st, const uint8_t* d_img, double lr, uint8_t* d_fg);
+
+// host geometry (ck_host_geom.cpp)
+void ck_invert3x3(const double* s, double* d);
+void ck_min_area_rect(const int32_t* pts, int n, float* out_wh);

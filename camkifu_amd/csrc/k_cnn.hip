@@ -1,0 +1,419 @@
+// k_cnn.hip -- K10..K12: the stone classifier of SfNeural.
+//   K10 patch extraction  NNManager._get_x            (reference: src/camkifu/stone/nn_manager.py:216-218, 256-275)
+//   K11 the Keras net     NNManager.create_net        (nn_manager.py:277-298)
+//   K12 decode            NNCache.predict_all_stones  (src/camkifu/stone/nn_cache.py:25-41, nn_manager.py:246-254)
+//
+// The four convolutions and the first dense layer are dense contractions and run on the
+// matrix cores as implicit GEMMs (M = output pixels, N = output channels, K = kh*kw*cin):
+//   fp32 mode: v_mfma_f32_32x32x2_f32 -- exact f32, and because one MFMA is a k-ordered fmaf
+//              chain, accumulating K in (kh, kw, cin) order reproduces the scalar CPU chain.
+// A (activations) is staged in LDS with the per-pixel channel stride padded to an odd number
+// of dwords (conflict-free ds_read_b32 for 32 consecutive pixels); B (weights) streams from
+// L2 and is reused by R register-blocked M tiles per wave.
+// Everything else (pooling, 160->81 dense, softmax, base-3 decode) is byte/float VALU work.
+#include <math.h>
+
+#include "ck_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// region index -> first pixel row/col of its 40x40 patch (nn_manager.py:92-126, 256-275)
+__device__ __forceinline__ int region_origin(int i) { return i == 9 ? 340 : 40 * i; }
+
+// ------------------------------------------------------------------------------------------
+// Implicit-GEMM valid convolution + bias + relu (+ optional fused 2x2 max-pool when OW == 32).
+//   in : U8IN ? goban images [frame][380][380][3] u8 (patch gathered on the fly)
+//              : activations [patch][H][W][CIN] f32
+//   wc : [KS*2][COUTP] f32, correlation layout (flip already applied), zero padded
+//   out: [patch][OH*OW or pooled][COUT] f32
+// Work split: blockIdx.x = patch, blockIdx.y = group of WAVES_M*R consecutive M tiles;
+// wave (wm, wn) owns R M-tiles x one 32-wide N tile.
+template <int H, int W, int CIN, int KH, int KW, int COUT, int R, int WAVES_M, bool U8IN, bool POOL>
+__global__ __launch_bounds__(64 * WAVES_M * cdiv(COUT, 32)) void conv_mfma_f32_kernel(
+    const void* __restrict__ in_, const float* __restrict__ wc, const float* __restrict__ bias,
+    float* __restrict__ out)
+{
+#pragma clang fp contract(off)
+    constexpr int OH = H - KH + 1, OW = W - KW + 1, M = OH * OW;
+    constexpr int NT = cdiv(COUT, 32), COUTP = NT * 32;
+    constexpr int K = KH * KW * CIN, KS = cdiv(K, 2);
+    constexpr int CS = (CIN % 2 == 0) ? CIN + 1 : CIN;            // odd dword stride per pixel
+    constexpr int TILES_WG = WAVES_M * R;
+    constexpr int ROWS = (TILES_WG * 32 + OW - 2) / OW + 1 + KH - 1;   // input rows a WG can touch
+    constexpr int ROWS_C = ROWS < H ? ROWS : H;
+    __shared__ float lds[ROWS_C * W * CS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NT, wn = wave % NT;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int patch = blockIdx.x;
+    const int m_wg0 = blockIdx.y * TILES_WG * 32;
+    const int oy_min = m_wg0 / OW;
+    int row_cnt = H - oy_min;
+    if (row_cnt > ROWS_C) row_cnt = ROWS_C;
+
+    // ---- stage the input rows this workgroup needs ---------------------------------------
+    constexpr int NTHREADS = 64 * WAVES_M * NT;
+    if (U8IN) {
+        const uint8_t* g = (const uint8_t*)in_;
+        const int frame = patch / 100, reg = patch % 100;
+        const int py0 = region_origin(reg / 10), px0 = region_origin(reg % 10);
+        const uint8_t* src = g + ((size_t)frame * 380 + py0) * 380 * 3 + (size_t)px0 * 3;
+        for (int i = tid; i < row_cnt * W * CIN; i += NTHREADS) {
+            const int r = i / (W * CIN), rem = i % (W * CIN);
+            lds[r * W * CS + rem] = (float)src[(size_t)(oy_min + r) * 380 * 3 + rem];   // CS == CIN == 3
+        }
+    } else {
+        const float* g = (const float*)in_ + (size_t)patch * H * W * CIN + (size_t)oy_min * W * CIN;
+        for (int i = tid; i < row_cnt * W * CIN; i += NTHREADS) {
+            const int pxl = i / CIN, c = i % CIN;
+            lds[pxl * CS + c] = g[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- per-lane A base offsets for the R tiles ------------------------------------------
+    int abase[R];
+    const int tile0 = (blockIdx.y * WAVES_M + wm) * R;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int m = (tile0 + r) * 32 + l31;
+        if (m > M - 1) m = M - 1;                    // padded rows recompute the last pixel
+        const int oy = m / OW, ox = m % OW;
+        abase[r] = ((oy - oy_min) * W + ox) * CS;
+    }
+    f32x16 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[r][e] = 0.f;
+
+    const float* wcol = wc + wn * 32 + l31;
+    if (tile0 * 32 < M) {
+        if constexpr (CIN % 2 == 0) {
+            for (int i = 0; i < KH; i++) {
+                for (int j = 0; j < KW; j++) {
+                    const int aoff = (i * W + j) * CS + hi;
+                    const float* wrow = wcol + (size_t)((i * KW + j) * CIN + hi) * COUTP;
+#pragma unroll 8
+                    for (int cc = 0; cc < CIN / 2; cc++) {
+                        const float b = wrow[(size_t)(2 * cc) * COUTP];
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            const float a = lds[abase[r] + aoff + 2 * cc];
+                            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[r], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll 2
+            for (int s = 0; s < KS; s++) {
+                const int k = 2 * s + hi;
+                const int i = k / (KW * CIN), rem = k % (KW * CIN);
+                const int j = rem / CIN, c = rem % CIN;
+                const bool live = k < K;
+                const int aoff = live ? (i * W + j) * CS + c : 0;
+                const float b = wcol[(size_t)k * COUTP];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    float a = lds[abase[r] + aoff];
+                    a = live ? a : 0.f;
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[r], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias, relu, (pool), store ----------------------------------------------
+    const int co = wn * 32 + l31;
+    const float bv = co < COUT ? bias[co] : 0.f;
+    if constexpr (POOL) {
+        static_assert(!POOL || (OW == 32 && R % 2 == 0), "fused pooling needs one tile per output row");
+        constexpr int PW = OW / 2;
+        float* o = out + (size_t)patch * (OH / 2) * PW * COUT;
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            const int oy = tile0 + r;                      // tile index == output row
+            if (oy >= OH) continue;
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const int ox = (e & 3) + 8 * (e >> 2) + 4 * hi;       // even
+                float v0 = acc[r][e] + bv, v1 = acc[r][e + 1] + bv;
+                float v2 = acc[r + 1][e] + bv, v3 = acc[r + 1][e + 1] + bv;
+                v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
+                v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+                float mx = v0 > v1 ? v0 : v1; mx = mx > v2 ? mx : v2; mx = mx > v3 ? mx : v3;
+                if (co < COUT) o[((size_t)(oy / 2) * PW + ox / 2) * COUT + co] = mx;
+            }
+        }
+    } else {
+        float* o = out + (size_t)patch * M * COUT;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int m = (tile0 + r) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                float v = acc[r][e] + bv;
+                v = v > 0.f ? v : 0.f;
+                if (m < M && co < COUT) o[(size_t)m * COUT + co] = v;
+            }
+        }
+    }
+}
+
+// 2x2 max pool, channels-last
+__global__ void pool2_kernel(const float* __restrict__ in, int H, int W, int C, float* __restrict__ out, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int OW = W / 2, OH = H / 2;
+    const int c = (int)(i % C);
+    const int x = (int)((i / C) % OW);
+    const int y = (int)((i / ((size_t)C * OW)) % OH);
+    const size_t p = i / ((size_t)C * OW * OH);
+    const float* b = in + ((p * H + 2 * y) * W + 2 * x) * C + c;
+    float m = b[0];
+    float v = b[C]; m = m > v ? m : v;
+    v = b[(size_t)W * C]; m = m > v ? m : v;
+    v = b[(size_t)W * C + C]; m = m > v ? m : v;
+    out[i] = m;
+}
+
+// dense 3240 -> 160 + relu as an MFMA GEMM over patches: one wave = 32 patches x 32 outputs
+__global__ __launch_bounds__(64) void fc1_mfma_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          int npatch)
+{
+#pragma clang fp contract(off)
+    constexpr int KIN = 3240, NOUT = 160;
+    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    const int p0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    int p = p0 + l31;
+    if (p > npatch - 1) p = npatch - 1;
+    const float* xa = x + (size_t)p * KIN + hi;
+    const float* wb = w + (size_t)hi * NOUT + n0 + l31;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+#pragma unroll 4
+    for (int s = 0; s < KIN / 2; s++) {
+        const float a = xa[2 * s];
+        const float b = wb[(size_t)(2 * s) * NOUT];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    const int co = n0 + l31;
+    const float bv = bias[co];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int pp = p0 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        float v = acc[e] + bv;
+        v = v > 0.f ? v : 0.f;
+        if (pp < npatch) out[(size_t)pp * NOUT + co] = v;
+    }
+}
+
+// dense 160 -> 81, softmax, argmax/base-3 decode and confidence.  One wave per patch.
+__global__ __launch_bounds__(64) void fc2_softmax_decode_kernel(const float* __restrict__ h1, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ y,
+                                                                uint8_t* __restrict__ labels, double* __restrict__ conf,
+                                                                int npatch)
+{
+#pragma clang fp contract(off)
+    __shared__ float lg[96];
+    __shared__ float ex[96];
+    const int patch = blockIdx.x, lane = threadIdx.x;
+    if (patch >= npatch) return;
+    const float* hv = h1 + (size_t)patch * 160;
+    for (int o = lane; o < 81; o += 64) {
+        float acc = 0.f;
+        for (int i = 0; i < 160; i++) acc = fmaf(hv[i], w[(size_t)i * 81 + o], acc);
+        lg[o] = acc + bias[o];
+    }
+    __syncthreads();
+    float mx = lg[0];
+    for (int i = 1; i < 81; i++) mx = lg[i] > mx ? lg[i] : mx;
+    for (int o = lane; o < 81; o += 64) ex[o] = expf(lg[o] - mx);
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = 0; i < 81; i++) sum += ex[i];
+    for (int o = lane; o < 81; o += 64) {
+        const float v = ex[o] / sum;
+        ex[o] = v;
+        y[(size_t)patch * 81 + o] = v;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int label = 0;
+        double s = 0.0;
+        for (int k = 0; k < 81; k++) {
+            if (ex[k] > ex[label]) label = k;       // first maximum, like np.argmax
+            s += (double)ex[k];                      // python sum(): float64, index order
+        }
+        const double cf = (double)ex[label] / s;
+        const int frame = patch / 100, reg = patch % 100;
+        const int i = reg / 10, j = reg % 10;
+        const int rs = i == 9 ? 17 : 2 * i, cs = j == 9 ? 17 : 2 * j;
+        int kk = label;
+        const int d3 = kk / 27; kk %= 27;
+        const int d2 = kk / 9; kk %= 9;
+        const int d1 = kk / 3;
+        const int d0 = kk % 3;
+        const int dg[4] = { d0, d1, d2, d3 };
+        uint8_t* L = labels + (size_t)frame * 361;
+        double* C = conf + (size_t)frame * 361;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int r = rs + d / 2, c = cs + d % 2;
+            L[r * 19 + c] = (uint8_t)dg[d];
+            C[r * 19 + c] = cf;
+        }
+    }
+}
+
+}  // namespace
+
+// Regions are decoded by independent waves, but NNCache.predict_all_stones writes them in
+// (i, j) raster order, so where the last region overlaps its neighbour (rows/cols 17) the
+// LATER region must win.  Regions 9 overlap regions 8 on intersection row/col 17 only; the
+// decode kernel is therefore launched twice: first regions with i<9 and j<9, then the rest
+// in an order-preserving second pass (see k_cnn_predict).
+namespace {
+__global__ __launch_bounds__(64) void decode_fix_kernel(const float* __restrict__ y, uint8_t* __restrict__ labels,
+                                                        double* __restrict__ conf, int nframes)
+{
+    // one thread per frame re-applies regions in raster order for the overlapping band
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    for (int reg = 0; reg < 100; reg++) {
+        const int i = reg / 10, j = reg % 10;
+        if (i < 8 && j < 8) continue;              // cannot touch row/col 17
+        const float* yy = y + ((size_t)f * 100 + reg) * 81;
+        int label = 0;
+        double s = 0.0;
+        for (int k = 0; k < 81; k++) { if (yy[k] > yy[label]) label = k; s += (double)yy[k]; }
+        const double cf = (double)yy[label] / s;
+        const int rs = i == 9 ? 17 : 2 * i, cs = j == 9 ? 17 : 2 * j;
+        int kk = label;
+        const int d3 = kk / 27; kk %= 27;
+        const int d2 = kk / 9; kk %= 9;
+        const int d1 = kk / 3, d0 = kk % 3;
+        const int dg[4] = { d0, d1, d2, d3 };
+        for (int d = 0; d < 4; d++) {
+            const int r = rs + d / 2, c = cs + d % 2;
+            labels[(size_t)f * 361 + r * 19 + c] = (uint8_t)dg[d];
+            conf[(size_t)f * 361 + r * 19 + c] = cf;
+        }
+    }
+}
+}  // namespace
+
+static void flip_pack(const float* k, int KH, int KW, int CIN, int COUT, std::vector<float>& dst)
+{
+    const int NT = (COUT + 31) / 32, COUTP = NT * 32;
+    const int K = KH * KW * CIN, KS2 = ((K + 1) / 2) * 2;
+    dst.assign((size_t)KS2 * COUTP, 0.f);
+    for (int i = 0; i < KH; i++)
+        for (int j = 0; j < KW; j++)
+            for (int c = 0; c < CIN; c++)
+                for (int o = 0; o < COUT; o++)
+                    dst[(size_t)((i * KW + j) * CIN + c) * COUTP + o] =
+                        k[(((size_t)(KH - 1 - i) * KW + (KW - 1 - j)) * CIN + c) * COUT + o];
+}
+
+int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
+{
+    static const size_t counts[12] = { 5 * 5 * 3 * 32, 32, 5 * 5 * 32 * 32, 32, 3 * 3 * 32 * 90, 90,
+                                       3 * 3 * 90 * 90, 90, 3240 * 160, 160, 160 * 81, 81 };
+    std::vector<std::vector<float>> host(12);
+    for (int i = 0; i < 12; i++) {
+        host[i].resize(counts[i]);
+        if (space == CK_DEVICE) CK_HIP(ctx, hipMemcpy(host[i].data(), w[i], counts[i] * 4, hipMemcpyDeviceToHost));
+        else if (space == CK_HOST) memcpy(host[i].data(), w[i], counts[i] * 4);
+        else return ck_fail(ctx, CK_ERR_ARG, "bad memory space %d", space);
+    }
+    auto up = [&](DevBuf& b, const std::vector<float>& v) -> int {
+        CK_TRY(ck_ensure(ctx, b, v.size() * 4));
+        CK_HIP(ctx, hipMemcpy(b.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+        return CK_OK;
+    };
+    std::vector<float> t;
+    flip_pack(host[0].data(), 5, 5, 3, 32, t);  CK_TRY(up(ctx->cnn.c1w, t));
+    flip_pack(host[2].data(), 5, 5, 32, 32, t); CK_TRY(up(ctx->cnn.c2w, t));
+    flip_pack(host[4].data(), 3, 3, 32, 90, t); CK_TRY(up(ctx->cnn.c3w, t));
+    flip_pack(host[6].data(), 3, 3, 90, 90, t); CK_TRY(up(ctx->cnn.c4w, t));
+    CK_TRY(up(ctx->cnn.c1b, host[1])); CK_TRY(up(ctx->cnn.c2b, host[3]));
+    CK_TRY(up(ctx->cnn.c3b, host[5])); CK_TRY(up(ctx->cnn.c4b, host[7]));
+    CK_TRY(up(ctx->cnn.d1w, host[8])); CK_TRY(up(ctx->cnn.d1b, host[9]));
+    CK_TRY(up(ctx->cnn.d2w, host[10])); CK_TRY(up(ctx->cnn.d2b, host[11]));
+    ctx->cnn.set = true;
+    return CK_OK;
+}
+
+int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, uint8_t* d_labels, double* d_conf)
+{
+    // frames are processed in chunks so the activation scratch stays bounded
+    const int CHUNK = 32;
+    const size_t a1_sz = (size_t)CHUNK * 100 * 36 * 36 * 32 * 4;      // conv1 out, later conv3 out
+    const size_t p2_sz = (size_t)CHUNK * 100 * 16 * 16 * 32 * 4;      // conv2+pool out, later conv4 out
+    CK_TRY(ck_ensure(ctx, ctx->act0, a1_sz));
+    CK_TRY(ck_ensure(ctx, ctx->act1, p2_sz));
+    CK_TRY(ck_ensure(ctx, ctx->act2, (size_t)CHUNK * 100 * (3240 + 160) * 4));
+    float* a1 = (float*)ctx->act0.p;
+    float* p2 = (float*)ctx->act1.p;
+    float* p4 = (float*)ctx->act2.p;
+    float* h1 = p4 + (size_t)CHUNK * 100 * 3240;
+    const CnnWeights& W = ctx->cnn;
+    for (int f0 = 0; f0 < nframes; f0 += CHUNK) {
+        const int nf = nframes - f0 < CHUNK ? nframes - f0 : CHUNK;
+        const int np = nf * 100;
+        const uint8_t* gob = d_goban + (size_t)f0 * 380 * 380 * 3;
+        {
+            TimeScope ts(ctx, "cnn_conv1");
+            // 41 M tiles: 4 groups of (4 waves x 3 tiles)
+            hipLaunchKernelGGL((conv_mfma_f32_kernel<40, 40, 3, 5, 5, 32, 3, 4, true, false>), dim3(np, 4), dim3(256), 0,
+                               ctx->stream, (const void*)gob, (const float*)W.c1w.p, (const float*)W.c1b.p, a1);
+        }
+        {
+            TimeScope ts(ctx, "cnn_conv2");
+            // 32 rows: 4 groups of (4 waves x 2 rows), pooled output 16x16x32
+            hipLaunchKernelGGL((conv_mfma_f32_kernel<36, 36, 32, 5, 5, 32, 2, 4, false, true>), dim3(np, 4), dim3(256), 0,
+                               ctx->stream, (const void*)a1, (const float*)W.c2w.p, (const float*)W.c2b.p, p2);
+        }
+        float* a3 = a1;
+        {
+            TimeScope ts(ctx, "cnn_conv3");
+            // 7 M tiles x 3 N tiles: one wave per N tile, 7 tiles register-blocked
+            hipLaunchKernelGGL((conv_mfma_f32_kernel<16, 16, 32, 3, 3, 90, 7, 1, false, false>), dim3(np, 1), dim3(192), 0,
+                               ctx->stream, (const void*)p2, (const float*)W.c3w.p, (const float*)W.c3b.p, a3);
+        }
+        float* a4 = p2;
+        {
+            TimeScope ts(ctx, "cnn_conv4");
+            hipLaunchKernelGGL((conv_mfma_f32_kernel<14, 14, 90, 3, 3, 90, 5, 1, false, false>), dim3(np, 1), dim3(192), 0,
+                               ctx->stream, (const void*)a3, (const float*)W.c4w.p, (const float*)W.c4b.p, a4);
+        }
+        {
+            TimeScope ts(ctx, "cnn_tail");
+            const size_t total = (size_t)np * 6 * 6 * 90;
+            hipLaunchKernelGGL(pool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const float*)a4, 12, 12, 90, p4, total);
+            hipLaunchKernelGGL(fc1_mfma_f32_kernel, dim3((np + 31) / 32, 5), dim3(64), 0, ctx->stream,
+                               (const float*)p4, (const float*)W.d1w.p, (const float*)W.d1b.p, h1, np);
+            hipLaunchKernelGGL(fc2_softmax_decode_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float*)h1,
+                               (const float*)W.d2w.p, (const float*)W.d2b.p, d_y + (size_t)f0 * 8100,
+                               d_labels + (size_t)f0 * 361, d_conf + (size_t)f0 * 361, np);
+            hipLaunchKernelGGL(decode_fix_kernel, dim3((nf + 63) / 64), dim3(64), 0, ctx->stream,
+                               (const float*)(d_y + (size_t)f0 * 8100), d_labels + (size_t)f0 * 361,
+                               d_conf + (size_t)f0 * 361, nf);
+        }
+        CK_HIP(ctx, hipGetLastError());
+    }
+    return CK_OK;
+}

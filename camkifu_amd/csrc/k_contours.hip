@@ -1,0 +1,537 @@
+// k_contours.hip -- K3..K6 of BoardFinderAuto._detect / find_lines
+// (reference: src/camkifu/board/bf_auto.py:75-84, 105-133; core/imgutil.py:291-315, 409-434):
+//   K3 cv2.findContours(canny, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)
+//   K4 minAreaRect of every contour, bisect.insort by area, keep the 3 biggest, area gate
+//   K5 cv2.drawContours(ghost, contours, pos, 255, 1) for those 3
+//   K6 cv2.HoughLines(ghost, 1, pi/180, thresh)
+//
+// GPU formulation.  The serial border following of the CPU library is replaced by its
+// closed form (proved equal on the oracle side, tests/test_oracle_properties.py):
+//   * clear the 1-px image frame;
+//   * S0 = the 4-connected background component that contains the frame;
+//   * RETR_EXTERNAL contours = outer borders of the 8-connected edge components whose
+//     first pixel (raster order) has its west neighbour in S0;
+//   * the outer border of such a component = its pixels with a 4-neighbour in S0, which is
+//     also exactly what drawContours(thickness=1) paints from the compressed vertex list.
+// Both labelings share ONE int32 parent image: edge pixels are union-find nodes
+// (8-connectivity), background pixels point at the first pixel of their horizontal zero-run
+// and only those run heads are nodes (4-connectivity: runs are united where they overlap
+// vertically), so the dense background costs one union per run, not per pixel.
+// The three biggest contours need float rotating calipers; that scalar, branchy search runs
+// on the host for the few components whose bounding box could still make the top three.
+// Hough voting keeps a slab of theta rows in LDS per workgroup (LDS atomics), then writes
+// the rows out coalesced -- the global accumulator is never zero-filled or atomically hit.
+#include <math.h>
+
+#include <algorithm>
+#include <thread>
+
+#include "ck_common.h"
+#include "ck_uf.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int MAXC_LIMIT = 1 << 17;     // top-level components per frame
+constexpr int PEAK_CAP = 1 << 14;       // Hough peaks per frame
+constexpr int NUMANGLE = 180;
+
+struct FrameTab {        // device-side per-frame counters
+    int n_roots;
+    int n_hough_pts;
+    int n_peaks;
+    int overflow;
+};
+
+// ---- A. frame clearing + parent initialisation ------------------------------------------
+// one wave per image row; walks the row in 64-pixel segments carrying the position of the
+// last edge pixel seen so far
+__global__ __launch_bounds__(256) void prep_rows_kernel(const uint8_t* __restrict__ edges, int h, int w,
+                                                        uint8_t* __restrict__ ez, int32_t* __restrict__ L)
+{
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int f = blockIdx.y;
+    if (y >= h) return;
+    const size_t off = ((size_t)f * h + y) * w;
+    const bool row_inner = y > 0 && y < h - 1;
+    int last_edge = -1;                       // wave-uniform
+    for (int x0 = 0; x0 < w; x0 += 64) {
+        const int x = x0 + lane;
+        bool e = false;
+        if (x < w) e = row_inner && x > 0 && x < w - 1 && edges[off + x] != 0;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(e);
+        if (x < w) {
+            ez[off + x] = e ? 1 : 0;
+            int parent;
+            if (e) parent = y * w + x;
+            else {
+                const unsigned long long below = mask & ((1ull << lane) - 1ull);
+                const int le = below ? x0 + 63 - __builtin_clzll(below) : last_edge;
+                parent = y * w + le + 1;          // head of this zero-run
+            }
+            L[off + x] = parent;
+        }
+        if (mask) last_edge = x0 + 63 - __builtin_clzll(mask);
+    }
+}
+
+// ---- B. unions ---------------------------------------------------------------------------
+__global__ void link_kernel(const uint8_t* __restrict__ ez, int h, int w, int32_t* __restrict__ labels)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= w) return;
+    const uint8_t* e = ez + (size_t)f * h * w;
+    int32_t* L = labels + (size_t)f * h * w;
+    const int p = y * w + x;
+    if (e[p]) {
+        if (e[p - 1]) uf_union(L, p, p - 1);          // frame is cleared: x >= 1, y >= 1 here
+        if (e[p - w]) uf_union(L, p, p - w);
+        else {
+            if (e[p - w - 1]) uf_union(L, p, p - w - 1);
+            if (e[p - w + 1]) uf_union(L, p, p - w + 1);
+        }
+    } else if (y > 0 && !e[p - w]) {
+        // first column of a stretch where this row and the row above are both background
+        const bool first = x == 0 || e[p - 1] || e[p - w - 1];
+        if (first) uf_union(L, p, p - w);
+    }
+}
+
+// ---- C. flatten nodes ----------------------------------------------------------------------
+__global__ void flatten_kernel(const uint8_t* __restrict__ ez, int h, int w, int32_t* __restrict__ labels)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= w) return;
+    const size_t off = (size_t)f * h * w;
+    const int p = y * w + x;
+    const bool node = ez[off + p] || x == 0 || ez[off + p - 1];
+    if (!node) return;
+    labels[off + p] = uf_find(labels + off, p);
+}
+
+__device__ __forceinline__ bool in_s0(const int32_t* L, int q, int root0)
+{
+    // q is a background pixel: L[q] is its run head (or already a root); heads are flattened
+    return L[L[q]] == root0;
+}
+
+// ---- D. top-level roots -------------------------------------------------------------------
+__global__ void roots_kernel(const uint8_t* __restrict__ ez, int h, int w, const int32_t* __restrict__ labels,
+                             int32_t* __restrict__ compid, FrameTab* __restrict__ tab, int maxc,
+                             int32_t* __restrict__ roots, int32_t* __restrict__ aabb)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= w) return;
+    const size_t off = (size_t)f * h * w;
+    const int p = y * w + x;
+    if (!ez[off + p]) return;
+    const int32_t* L = labels + off;
+    if (L[p] != p) return;
+    const int root0 = L[0];
+    if (!in_s0(L, p - 1, root0)) return;        // west neighbour of a first pixel is background
+    const int slot = atomicAdd(&tab[f].n_roots, 1);
+    if (slot >= maxc) { tab[f].overflow = 1; compid[off + p] = -1; return; }
+    compid[off + p] = slot;
+    roots[(size_t)f * maxc + slot] = p;
+    int32_t* bb = aabb + ((size_t)f * maxc + slot) * 4;
+    bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1;
+}
+
+// ---- E. outer-border flags + bounding boxes ---------------------------------------------
+__global__ void border_kernel(const uint8_t* __restrict__ ez, int h, int w, const int32_t* __restrict__ labels,
+                              const int32_t* __restrict__ compid, int maxc, uint8_t* __restrict__ bflag,
+                              int32_t* __restrict__ aabb)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= w) return;
+    const size_t off = (size_t)f * h * w;
+    const int p = y * w + x;
+    uint8_t flag = 0;
+    if (ez[off + p]) {
+        const uint8_t* e = ez + off;
+        const int32_t* L = labels + off;
+        const int root0 = L[0];
+        const bool b = (!e[p - 1] && in_s0(L, p - 1, root0)) || (!e[p + 1] && in_s0(L, p + 1, root0)) ||
+                       (!e[p - w] && in_s0(L, p - w, root0)) || (!e[p + w] && in_s0(L, p + w, root0));
+        if (b) {
+            const int slot = compid[off + L[p]];
+            if ((unsigned)slot < (unsigned)maxc) {
+                // a pixel in the middle of a straight run cannot be a hull vertex
+                const bool mid = (e[p - 1] && e[p + 1]) || (e[p - w] && e[p + w]) ||
+                                 (e[p - w - 1] && e[p + w + 1]) || (e[p - w + 1] && e[p + w - 1]);
+                flag = mid ? 1 : 3;
+                int32_t* bb = aabb + ((size_t)f * maxc + slot) * 4;
+                atomicMin(bb + 0, x); atomicMax(bb + 1, x);
+                atomicMin(bb + 2, y); atomicMax(bb + 3, y);
+            }
+        }
+    }
+    bflag[off + p] = flag;
+}
+
+// ---- F. gather hull-candidate points of the components the host asked for ---------------
+__global__ void gather_points_kernel(const uint8_t* __restrict__ bflag, int h, int w, const int32_t* __restrict__ labels,
+                                     const int32_t* __restrict__ compid, int maxc, const uint8_t* __restrict__ want,
+                                     int32_t* __restrict__ counter, int cap, int32_t* __restrict__ pts /* x|y<<16, f<<17|slot */)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= w) return;
+    const size_t off = (size_t)f * h * w;
+    const int p = y * w + x;
+    if (bflag[off + p] != 3) return;
+    const int slot = compid[off + labels[off + p]];
+    if (!want[(size_t)f * maxc + slot]) return;
+    const int i = atomicAdd(counter, 1);
+    if (i >= cap) return;
+    pts[2 * (size_t)i] = x | (y << 16);
+    pts[2 * (size_t)i + 1] = slot;
+    pts[2 * (size_t)cap + i] = f;
+}
+
+// ---- G. ghost image + Hough point list ------------------------------------------------------
+__global__ void ghost_kernel(const uint8_t* __restrict__ bflag, int h, int w, const int32_t* __restrict__ labels,
+                             const int32_t* __restrict__ compid, const int32_t* __restrict__ sel /* f*4: 3 slots + go */,
+                             FrameTab* __restrict__ tab, int pcap, uint32_t* __restrict__ hpts, uint8_t* __restrict__ ghost)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= w) return;
+    const size_t off = (size_t)f * h * w;
+    const int p = y * w + x;
+    bool on = false;
+    if (bflag[off + p] && sel[f * 4 + 3]) {
+        const int slot = compid[off + labels[off + p]];
+        on = slot == sel[f * 4] || slot == sel[f * 4 + 1] || slot == sel[f * 4 + 2];
+    }
+    if (ghost) ghost[off + p] = on ? 255 : 0;
+    if (on) {
+        const int i = atomicAdd(&tab[f].n_hough_pts, 1);
+        if (i < pcap) hpts[(size_t)f * pcap + i] = (uint32_t)x | ((uint32_t)y << 16);
+        else tab[f].overflow = 1;
+    }
+}
+
+// ---- H. Hough voting: one workgroup = RB theta rows of one frame, accumulators in LDS ----
+__global__ __launch_bounds__(256) void hough_vote_kernel(const uint32_t* __restrict__ hpts, const FrameTab* __restrict__ tab,
+                                                         int pcap, const float* __restrict__ trig /* cos[180], sin[180] */,
+                                                         int numrho, int rb, int32_t* __restrict__ accum)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) int32_t slab[];
+    const int f = blockIdx.y;
+    const int n0 = blockIdx.x * rb;
+    const int rows = n0 + rb <= NUMANGLE ? rb : NUMANGLE - n0;
+    const int stride = numrho + 2;
+    for (int i = threadIdx.x; i < rows * stride; i += 256) slab[i] = 0;
+    __syncthreads();
+    int npts = tab[f].n_hough_pts;
+    if (npts > pcap) npts = pcap;
+    const uint32_t* P = hpts + (size_t)f * pcap;
+    const int half = (numrho - 1) / 2;
+    for (int i = threadIdx.x; i < npts; i += 256) {
+        const uint32_t pk = P[i];
+        const float xf = (float)(pk & 0xFFFF), yf = (float)(pk >> 16);
+        for (int k = 0; k < rows; k++) {
+            const float a = xf * trig[n0 + k];
+            const float b = yf * trig[NUMANGLE + n0 + k];
+            const float s = a + b;
+            const int r = (int)rintf(s) + half;
+            atomicAdd(&slab[k * stride + r + 1], 1);
+        }
+    }
+    __syncthreads();
+    int32_t* A = accum + ((size_t)f * (NUMANGLE + 2) + n0 + 1) * stride;
+    for (int i = threadIdx.x; i < rows * stride; i += 256) A[i] = slab[i];
+}
+
+// ---- I. peaks -----------------------------------------------------------------------------
+__global__ void hough_peaks_kernel(const int32_t* __restrict__ accum, int numrho, int threshold,
+                                   FrameTab* __restrict__ tab, int32_t* __restrict__ peaks /* f*PEAK_CAP*2 */)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.y;
+    const int f = blockIdx.z;
+    if (r >= numrho) return;
+    const int stride = numrho + 2;
+    const int32_t* A = accum + (size_t)f * (NUMANGLE + 2) * stride;
+    const int base = (n + 1) * stride + r + 1;
+    const int v = A[base];
+    if (v <= threshold) return;
+    const int up = n > 0 ? A[base - stride] : 0;
+    const int dn = n < NUMANGLE - 1 ? A[base + stride] : 0;
+    if (v > A[base - 1] && v >= A[base + 1] && v > up && v >= dn) {
+        const int i = atomicAdd(&tab[f].n_peaks, 1);
+        if (i < PEAK_CAP) {
+            peaks[((size_t)f * PEAK_CAP + i) * 2] = base;
+            peaks[((size_t)f * PEAK_CAP + i) * 2 + 1] = v;
+        } else tab[f].overflow = 1;
+    }
+}
+
+template <typename F>
+void parallel_for(int n, F fn)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)(hw ? hw : 4);
+    if (nt > 16) nt = 16;
+    if (nt > n) nt = n;
+    if (nt <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++)
+        th.emplace_back([=]() { for (int i = t; i < n; i += nt) fn(i); });
+    for (auto& t : th) t.join();
+}
+
+struct Comp {
+    int root;       // first pixel (raster index) = discovery order key
+    int slot;
+    double ub;      // bounding-box area: upper bound of the minAreaRect area
+    double area;    // exact area once known
+    bool known;
+};
+
+}  // namespace
+
+int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int hough_thresh,
+                  float* lines, int cap, ck_board_result* res, uint8_t* d_ghost_out)
+{
+    const size_t fpx = (size_t)h * w, npx = fpx * n;
+    int maxc = (int)(fpx / 4 + 1);
+    if (maxc > MAXC_LIMIT) maxc = MAXC_LIMIT;
+    const int pcap = (int)(fpx < (1u << 16) ? fpx : (fpx / 8 > (1u << 16) ? fpx / 8 : (1u << 16)));
+    const int numrho = 2 * (w + h) + 1;
+    const int stride = numrho + 2;
+    if (w > 65535 || h > 65535) return ck_fail(ctx, CK_ERR_ARG, "image side > 65535");
+
+    CK_TRY(ck_ensure(ctx, ctx->ghost, npx));                       // ez
+    CK_TRY(ck_ensure(ctx, ctx->map, npx));                         // bflag
+    CK_TRY(ck_ensure(ctx, ctx->labels, npx * 4));
+    CK_TRY(ck_ensure(ctx, ctx->labels2, npx * 4));                 // compid (only read at roots)
+    const size_t tab_bytes = sizeof(FrameTab) * (size_t)n;
+    const size_t sel_bytes = sizeof(int32_t) * 4 * (size_t)n;
+    CK_TRY(ck_ensure(ctx, ctx->misc, tab_bytes + sel_bytes + 4 * NUMANGLE * 2 + 64));
+    CK_TRY(ck_ensure(ctx, ctx->comp, (size_t)n * maxc * (4 + 16 + 1)));
+    uint8_t* ez = (uint8_t*)ctx->ghost.p;
+    uint8_t* bflag = (uint8_t*)ctx->map.p;
+    int32_t* L = (int32_t*)ctx->labels.p;
+    int32_t* compid = (int32_t*)ctx->labels2.p;
+    FrameTab* d_tab = (FrameTab*)ctx->misc.p;
+    int32_t* d_sel = (int32_t*)((char*)ctx->misc.p + tab_bytes);
+    float* d_trig = (float*)((char*)ctx->misc.p + tab_bytes + sel_bytes);
+    int32_t* d_roots = (int32_t*)ctx->comp.p;
+    int32_t* d_aabb = d_roots + (size_t)n * maxc;
+    uint8_t* d_want = (uint8_t*)(d_aabb + (size_t)n * maxc * 4);
+
+    const dim3 pgrid((w + 255) / 256, h, n), pblock(256);
+    {
+        TimeScope ts(ctx, "ccl");
+        CK_HIP(ctx, hipMemsetAsync(d_tab, 0, tab_bytes, ctx->stream));
+        hipLaunchKernelGGL(prep_rows_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L);
+        hipLaunchKernelGGL(link_kernel, pgrid, pblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L);
+        hipLaunchKernelGGL(flatten_kernel, pgrid, pblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L);
+        hipLaunchKernelGGL(roots_kernel, pgrid, pblock, 0, ctx->stream, (const uint8_t*)ez, h, w, (const int32_t*)L,
+                           compid, d_tab, maxc, d_roots, d_aabb);
+        hipLaunchKernelGGL(border_kernel, pgrid, pblock, 0, ctx->stream, (const uint8_t*)ez, h, w, (const int32_t*)L,
+                           (const int32_t*)compid, maxc, bflag, d_aabb);
+        CK_HIP(ctx, hipGetLastError());
+    }
+
+    // ---- host: component tables -------------------------------------------------------------
+    std::vector<FrameTab> tab((size_t)n);
+    CK_HIP(ctx, hipMemcpyAsync(tab.data(), d_tab, tab_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f < n; f++)
+        if (tab[f].overflow) return ck_fail(ctx, CK_ERR_CAPACITY, "frame %d: more than %d external contours", f, maxc);
+    std::vector<std::vector<Comp>> comps((size_t)n);
+    {
+        std::vector<int32_t> hroots, haabb;
+        for (int f = 0; f < n; f++) {
+            const int nc = tab[f].n_roots;
+            res[f].status = nc == 0 ? CK_BOARD_NO_CONTOUR : CK_BOARD_LINES;
+            res[f].n_contours = nc; res[f].n_lines = 0; res[f].reserved = 0; res[f].biggest_area = 0;
+            if (!nc) continue;
+            hroots.resize((size_t)nc); haabb.resize((size_t)nc * 4);
+            CK_HIP(ctx, hipMemcpy(hroots.data(), d_roots + (size_t)f * maxc, (size_t)nc * 4, hipMemcpyDeviceToHost));
+            CK_HIP(ctx, hipMemcpy(haabb.data(), d_aabb + (size_t)f * maxc * 4, (size_t)nc * 16, hipMemcpyDeviceToHost));
+            auto& cv = comps[f];
+            cv.resize((size_t)nc);
+            for (int s = 0; s < nc; s++) {
+                const double dx = (double)haabb[4 * s + 1] - haabb[4 * s], dy = (double)haabb[4 * s + 3] - haabb[4 * s + 2];
+                cv[s] = { hroots[s], s, dx * dy, 0.0, dx * dy == 0.0 };
+            }
+        }
+    }
+
+    // ---- exact areas for the components that can still reach the top three -------------------
+    const int gcap = (int)(npx < (1u << 22) ? npx : (1u << 22));     // points per gather round
+    CK_TRY(ck_ensure(ctx, ctx->pts, (size_t)gcap * 12 + 64));
+    int32_t* d_pts = (int32_t*)ctx->pts.p;
+    int32_t* d_counter = d_pts + (size_t)gcap * 3;
+    std::vector<uint8_t> want((size_t)n * maxc);
+    auto third_best = [](const std::vector<Comp>& cv) {
+        double b[3] = { -1, -1, -1 };
+        for (const Comp& c : cv) if (c.known) {
+            double a = c.area;
+            for (int i = 0; i < 3; i++) if (a > b[i]) std::swap(a, b[i]);
+        }
+        return b[2];          // -1 while fewer than three areas are known
+    };
+    for (int round = 0; round < 3; round++) {
+        bool any = false;
+        std::fill(want.begin(), want.end(), 0);
+        for (int f = 0; f < n; f++) {
+            auto& cv = comps[f];
+            if (cv.empty()) continue;
+            if (round == 0) {
+                std::vector<int> idx;
+                for (int s = 0; s < (int)cv.size(); s++) if (!cv[s].known) idx.push_back(s);
+                const int k = std::min<int>(16, (int)idx.size());
+                std::partial_sort(idx.begin(), idx.begin() + k, idx.end(), [&](int a, int b) { return cv[a].ub > cv[b].ub; });
+                for (int i = 0; i < k; i++) { want[(size_t)f * maxc + idx[i]] = 1; any = true; }
+            } else {
+                const double third = third_best(cv);
+                for (auto& c : cv)
+                    if (!c.known && c.ub * (1.0 + 1e-5) >= third) { want[(size_t)f * maxc + c.slot] = 1; any = true; }
+            }
+        }
+        if (!any) break;
+        if (round == 2) return ck_fail(ctx, CK_ERR_STATE, "contour selection did not converge");
+        {
+            TimeScope ts(ctx, "contour_gather");
+            CK_HIP(ctx, hipMemcpyAsync(d_want, want.data(), want.size(), hipMemcpyHostToDevice, ctx->stream));
+            CK_HIP(ctx, hipMemsetAsync(d_counter, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(gather_points_kernel, pgrid, pblock, 0, ctx->stream, (const uint8_t*)bflag, h, w,
+                               (const int32_t*)L, (const int32_t*)compid, maxc, (const uint8_t*)d_want, d_counter, gcap, d_pts);
+            CK_HIP(ctx, hipGetLastError());
+        }
+        int npts = 0;
+        CK_HIP(ctx, hipMemcpyAsync(&npts, d_counter, 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (npts > gcap) return ck_fail(ctx, CK_ERR_CAPACITY, "too many contour points (%d > %d)", npts, gcap);
+        std::vector<int32_t> hp((size_t)npts * 2), hf((size_t)npts);
+        if (npts) {
+            CK_HIP(ctx, hipMemcpy(hp.data(), d_pts, (size_t)npts * 8, hipMemcpyDeviceToHost));
+            CK_HIP(ctx, hipMemcpy(hf.data(), d_pts + (size_t)gcap * 2, (size_t)npts * 4, hipMemcpyDeviceToHost));
+        }
+        // bucket by (frame, slot)
+        std::vector<std::vector<std::vector<int32_t>>> bucket((size_t)n);
+        for (int f = 0; f < n; f++) bucket[f].resize(comps[f].size());
+        for (int i = 0; i < npts; i++) {
+            auto& b = bucket[hf[i]][hp[2 * (size_t)i + 1]];
+            b.push_back(hp[2 * (size_t)i] & 0xFFFF);
+            b.push_back(hp[2 * (size_t)i] >> 16);
+        }
+        parallel_for(n, [&](int f) {
+            auto& cv = comps[f];
+            for (size_t s = 0; s < cv.size(); s++) {
+                if (!want[(size_t)f * maxc + s]) continue;
+                float wh[2];
+                ck_min_area_rect(bucket[f][s].data(), (int)(bucket[f][s].size() / 2), wh);
+                cv[s].area = (double)wh[0] * (double)wh[1];
+                cv[s].known = true;
+            }
+        });
+    }
+
+    // ---- selection: bisect.insort order = (area ascending, discovery order descending) ------
+    std::vector<int32_t> sel((size_t)n * 4, -1);
+    for (int f = 0; f < n; f++) {
+        auto& cv = comps[f];
+        sel[(size_t)f * 4 + 3] = 0;
+        if (cv.empty()) continue;
+        std::vector<const Comp*> known;
+        for (const Comp& c : cv) if (c.known) known.push_back(&c);
+        std::sort(known.begin(), known.end(), [](const Comp* a, const Comp* b) {
+            if (a->area != b->area) return a->area > b->area;
+            return a->root < b->root;                    // raster-earlier contour ranks higher
+        });
+        res[f].biggest_area = known[0]->area;
+        const double frame_area = (double)h * (double)w;
+        if (!(frame_area / 3 < known[0]->area)) { res[f].status = CK_BOARD_TOO_SMALL; continue; }
+        for (int i = 0; i < 3 && i < (int)known.size(); i++) sel[(size_t)f * 4 + i] = known[i]->slot;
+        sel[(size_t)f * 4 + 3] = 1;
+    }
+
+    // ---- ghost, Hough --------------------------------------------------------------------------
+    std::vector<float> trig(2 * NUMANGLE);
+    {
+        const float theta = (float)(3.1415926535897932384626433832795 / 180);
+        float ang = 0.f;
+        for (int k = 0; k < NUMANGLE; ang += theta, k++) {
+            trig[NUMANGLE + k] = (float)(sin((double)ang) * 1.f);
+            trig[k] = (float)(cos((double)ang) * 1.f);
+        }
+    }
+    CK_TRY(ck_ensure(ctx, ctx->accum, (size_t)n * (NUMANGLE + 2) * stride * 4));
+    CK_TRY(ck_ensure(ctx, ctx->peaks, (size_t)n * PEAK_CAP * 8 + (size_t)n * pcap * 4));
+    int32_t* d_accum = (int32_t*)ctx->accum.p;
+    int32_t* d_peaks = (int32_t*)ctx->peaks.p;
+    uint32_t* d_hpts = (uint32_t*)(d_peaks + (size_t)n * PEAK_CAP * 2);
+    {
+        TimeScope ts(ctx, "ghost");
+        CK_HIP(ctx, hipMemcpyAsync(d_sel, sel.data(), sel_bytes, hipMemcpyHostToDevice, ctx->stream));
+        CK_HIP(ctx, hipMemcpyAsync(d_trig, trig.data(), trig.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(ghost_kernel, pgrid, pblock, 0, ctx->stream, (const uint8_t*)bflag, h, w, (const int32_t*)L,
+                           (const int32_t*)compid, (const int32_t*)d_sel, d_tab, pcap, d_hpts, d_ghost_out);
+        CK_HIP(ctx, hipGetLastError());
+    }
+    {
+        TimeScope ts(ctx, "hough_vote");
+        const size_t row_bytes = (size_t)stride * 4;
+        int rb = (int)((144 * 1024) / row_bytes);
+        if (rb > 6) rb = 6;
+        if (rb < 1) return ck_fail(ctx, CK_ERR_ARG, "image too large for the Hough LDS slab");
+        CK_HIP(ctx, hipFuncSetAttribute((const void*)hough_vote_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(rb * row_bytes)));
+        hipLaunchKernelGGL(hough_vote_kernel, dim3((NUMANGLE + rb - 1) / rb, n), dim3(256), rb * row_bytes, ctx->stream,
+                           (const uint32_t*)d_hpts, (const FrameTab*)d_tab, pcap, (const float*)d_trig, numrho, rb, d_accum);
+        CK_HIP(ctx, hipGetLastError());
+    }
+    {
+        TimeScope ts(ctx, "hough_peaks");
+        hipLaunchKernelGGL(hough_peaks_kernel, dim3((numrho + 255) / 256, NUMANGLE, n), dim3(256), 0, ctx->stream,
+                           (const int32_t*)d_accum, numrho, hough_thresh, d_tab, d_peaks);
+        CK_HIP(ctx, hipGetLastError());
+    }
+    CK_HIP(ctx, hipMemcpyAsync(tab.data(), d_tab, tab_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int32_t> pk;
+    for (int f = 0; f < n; f++) {
+        if (tab[f].overflow) return ck_fail(ctx, CK_ERR_CAPACITY, "frame %d: Hough point/peak capacity exceeded", f);
+        if (res[f].status != CK_BOARD_LINES) continue;
+        const int np = tab[f].n_peaks;
+        res[f].n_lines = np;
+        if (!np) continue;
+        pk.resize((size_t)np * 2);
+        CK_HIP(ctx, hipMemcpy(pk.data(), d_peaks + (size_t)f * PEAK_CAP * 2, (size_t)np * 8, hipMemcpyDeviceToHost));
+        std::vector<int> order((size_t)np);
+        for (int i = 0; i < np; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) {
+            if (pk[2 * a + 1] != pk[2 * b + 1]) return pk[2 * a + 1] > pk[2 * b + 1];
+            return pk[2 * a] < pk[2 * b];
+        });
+        const float theta = (float)(3.1415926535897932384626433832795 / 180);
+        const double scale = 1. / (numrho + 2);
+        for (int i = 0; i < np && i < cap; i++) {
+            const int idx = pk[2 * order[i]];
+            const int nn = (int)floor(idx * scale) - 1;
+            const int rr = idx - (nn + 1) * (numrho + 2) - 1;
+            lines[((size_t)f * cap + i) * 2] = (rr - (numrho - 1) * 0.5f) * 1.f;
+            lines[((size_t)f * cap + i) * 2 + 1] = 0.f + nn * theta;
+        }
+    }
+    return CK_OK;
+}

@@ -1,0 +1,213 @@
+// k_median.hip -- K1: exact 15x15 median of an 8-bit BGR frame, replicate border.
+// Replaces cv2.medianBlur(frame, 15)  (reference: src/camkifu/board/bf_auto.py:72).
+//
+// Algorithm (threshold decomposition + per-tile radix descent, all in registers):
+//   median(p) = min { t : #{window(p) <= t} >= 113 }.
+//   For one threshold t the count is a 15x15 box sum of the indicator (x <= t), which is
+//   separable and shared by every pixel of a tile.  Each pixel resolves its median bit by
+//   bit (MSB first); at bit b a pixel whose decided prefix is q asks threshold
+//   t = q + 2^b - 1.  A wave evaluates the box sum only for the DISTINCT prefixes q present
+//   in its tile (a 256-bit wave-uniform set), so a tile costs (#distinct medians-ish)
+//   box filters instead of 255 -- medians of a 15x15 window vary slowly.
+//
+// Mapping: one wave = one 48x64 output tile of one channel.  64 lanes = 16 (x) x 4 (y);
+// a lane owns 4 adjacent pixels packed in one dword (SWAR, byte lanes) and 16 output rows,
+// so the vertical pass is in-register and the horizontal pass crosses at most 4 lanes of
+// the same 16-lane DPP row.  Lanes 12..15 of each row only supply halo.
+//
+// HBM traffic: each input byte is read ~(64*78)/(48*64) = 1.6x (L2 absorbs the halo),
+// output written once, planar [n][3][h][pitch] so the next stage reads dwords.
+#include "ck_common.h"
+
+namespace {
+
+constexpr int HOUT = 16;              // output rows per lane
+constexpr int HIN = HOUT + 14;        // input rows per lane
+constexpr int TILE_W = 48;            // valid output columns per wave
+constexpr int TILE_H = 4 * HOUT;      // output rows per wave
+
+__device__ __forceinline__ uint32_t lane_right(uint32_t v, int k)
+{
+    // value held by the lane k places to the right inside the 16-lane row
+    return (uint32_t)__shfl_down((int)v, k, 16);
+}
+
+__device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t nbytes)
+{
+    return __builtin_amdgcn_alignbyte(hi, lo, nbytes);
+}
+
+// 15-wide horizontal box sum of packed byte counters: result byte i of lane lx is
+// sum_{k=0..14} V[4*lx + i + k]
+__device__ __forceinline__ uint32_t hsum15(uint32_t w)
+{
+    uint32_t s1 = w + alignbyte(lane_right(w, 1), w, 1);             // pairs
+    uint32_t s2 = s1 + alignbyte(lane_right(s1, 1), s1, 2);          // 4
+    uint32_t s3 = s2 + lane_right(s2, 1);                            // 8
+    uint32_t t14 = alignbyte(lane_right(w, 4), lane_right(w, 3), 2); // element +14
+    return s3 + lane_right(s2, 2) + lane_right(s1, 3) + t14;         // 8 + 4 + 2 + 1
+}
+
+struct Set256 {
+    unsigned long long w[4];
+    __device__ __forceinline__ void clear() { w[0] = w[1] = w[2] = w[3] = 0; }
+    __device__ __forceinline__ void set(int v)
+    {
+        unsigned long long bit = 1ull << (v & 63);
+        switch (v >> 6) {
+        case 0: w[0] |= bit; break;
+        case 1: w[1] |= bit; break;
+        case 2: w[2] |= bit; break;
+        default: w[3] |= bit; break;
+        }
+    }
+};
+
+__global__ __launch_bounds__(64) void median15_kernel(const uint8_t* __restrict__ in, int h, int w,
+                                                      uint8_t* __restrict__ out, int pitch)
+{
+    const int lane = threadIdx.x;
+    const int lx = lane & 15, ly = lane >> 4;
+    const int ox = blockIdx.x * TILE_W, oy = blockIdx.y * TILE_H;
+    const int f = blockIdx.z / 3, c = blockIdx.z % 3;
+    const uint8_t* src = in + (size_t)f * h * w * 3 + c;
+
+    // ---- load the lane's 4 x HIN pixels (replicate border = clamped coordinates) --------
+    uint32_t nx[HIN];
+    int xo[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int x = ox - 7 + 4 * lx + k;
+        x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+        xo[k] = x * 3;
+    }
+    const int ybase = oy + HOUT * ly - 7;
+#pragma unroll
+    for (int r = 0; r < HIN; r++) {
+        int y = ybase + r;
+        y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+        const uint8_t* row = src + (size_t)y * w * 3;
+        uint32_t v = (uint32_t)row[xo[0]] | ((uint32_t)row[xo[1]] << 8) |
+                     ((uint32_t)row[xo[2]] << 16) | ((uint32_t)row[xo[3]] << 24);
+        nx[r] = ~v;
+    }
+
+    uint32_t lo[HOUT];
+#pragma unroll
+    for (int j = 0; j < HOUT; j++) lo[j] = 0;
+    const uint32_t vm80 = (lx < 12) ? 0x80808080u : 0u;   // lanes 12..15 have no full window
+
+    Set256 cur, nxt;
+    cur.clear();
+    cur.set(0);
+    for (int b = 7; b >= 0; b--) {
+        nxt.clear();
+        const int half = 1 << b;
+        for (;;) {
+            int q;
+            if (cur.w[0]) { q = __builtin_ctzll(cur.w[0]); cur.w[0] &= cur.w[0] - 1; }
+            else if (cur.w[1]) { q = 64 + __builtin_ctzll(cur.w[1]); cur.w[1] &= cur.w[1] - 1; }
+            else if (cur.w[2]) { q = 128 + __builtin_ctzll(cur.w[2]); cur.w[2] &= cur.w[2] - 1; }
+            else if (cur.w[3]) { q = 192 + __builtin_ctzll(cur.w[3]); cur.w[3] &= cur.w[3] - 1; }
+            else break;
+            {
+                const uint32_t T = (uint32_t)(q + half) * 0x01010101u;   // t + 1 in every byte
+                const uint32_t Q = (uint32_t)q * 0x01010101u;
+                uint32_t B[HIN];
+#pragma unroll
+                for (int r = 0; r < HIN; r++)
+                    B[r] = (__builtin_amdgcn_lerp(nx[r], T, 0u) >> 7) & 0x01010101u;   // x <= t
+                uint32_t V = 0;
+#pragma unroll
+                for (int r = 0; r < 15; r++) V += B[r];
+                uint32_t any_hi = 0, any_lo = 0;
+#pragma unroll
+                for (int j = 0; j < HOUT; j++) {
+                    if (j > 0) V = V + B[j + 14] - B[j - 1];
+                    const uint32_t S = hsum15(V);
+                    const uint32_t D = 0xF0F0F0F0u - S;            // bit7 set <=> S < 113
+                    const uint32_t x = lo[j] ^ Q;
+                    const uint32_t z = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;   // bit7 set <=> byte != 0
+                    const uint32_t eq7 = ~z & vm80;
+                    const uint32_t upd7 = D & eq7;
+                    lo[j] += upd7 >> (7 - b);
+                    any_hi |= upd7;
+                    any_lo |= eq7 ^ upd7;
+                }
+                if (__builtin_amdgcn_ballot_w64(any_hi != 0)) nxt.set(q + half);
+                if (__builtin_amdgcn_ballot_w64(any_lo != 0)) nxt.set(q);
+            }
+        }
+        cur = nxt;
+    }
+
+    // ---- store: planar, one dword per lane-row ------------------------------------------
+    if (lx < 12) {
+        const int x = ox + 4 * lx;
+        if (x < w) {
+            uint8_t* dst = out + ((size_t)(f * 3 + c) * h) * pitch + x;
+#pragma unroll
+            for (int j = 0; j < HOUT; j++) {
+                const int y = oy + HOUT * ly + j;
+                if (y < h) *reinterpret_cast<uint32_t*>(dst + (size_t)y * pitch) = lo[j];
+            }
+        }
+    }
+}
+
+__global__ void planar_to_interleaved_kernel(const uint8_t* __restrict__ planes, int h, int w, int pitch,
+                                             uint8_t* __restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= w) return;
+    const uint8_t* p = planes + (size_t)f * 3 * h * pitch + (size_t)y * pitch + x;
+    uint8_t* o = out + (((size_t)f * h + y) * w + x) * 3;
+    o[0] = p[0];
+    o[1] = p[(size_t)h * pitch];
+    o[2] = p[(size_t)2 * h * pitch];
+}
+
+__global__ void interleaved_to_planar_kernel(const uint8_t* __restrict__ in, int h, int w, int pitch,
+                                             uint8_t* __restrict__ planes)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= w) return;
+    const uint8_t* i = in + (((size_t)f * h + y) * w + x) * 3;
+    uint8_t* p = planes + (size_t)f * 3 * h * pitch + (size_t)y * pitch + x;
+    p[0] = i[0];
+    p[(size_t)h * pitch] = i[1];
+    p[(size_t)2 * h * pitch] = i[2];
+}
+
+}  // namespace
+
+int k_median15_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, uint8_t* d_planes, int pitch)
+{
+    TimeScope ts(ctx, "median");
+    dim3 grid((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H, n * 3);
+    hipLaunchKernelGGL(median15_kernel, grid, dim3(64), 0, ctx->stream, d_bgr, h, w, d_planes, pitch);
+    CK_HIP(ctx, hipGetLastError());
+    return CK_OK;
+}
+
+int k_planar_to_interleaved(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, uint8_t* d_out)
+{
+    TimeScope ts(ctx, "repack");
+    dim3 grid((w + 255) / 256, h, n);
+    hipLaunchKernelGGL(planar_to_interleaved_kernel, grid, dim3(256), 0, ctx->stream, d_planes, h, w, pitch, d_out);
+    CK_HIP(ctx, hipGetLastError());
+    return CK_OK;
+}
+
+int k_interleaved_to_planar(ck_ctx* ctx, const uint8_t* d_in, int n, int h, int w, int pitch, uint8_t* d_planes)
+{
+    TimeScope ts(ctx, "repack");
+    dim3 grid((w + 255) / 256, h, n);
+    hipLaunchKernelGGL(interleaved_to_planar_kernel, grid, dim3(256), 0, ctx->stream, d_in, h, w, pitch, d_planes);
+    CK_HIP(ctx, hipGetLastError());
+    return CK_OK;
+}

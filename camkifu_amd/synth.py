@@ -1,0 +1,139 @@
+"""Synthetic goban scenes: a wood-coloured 19x19 board with black/white discs
+under a random homography, on a grey background with a gradient and Gaussian noise.
+
+The reference ships no sample clip, so every test and benchmark input comes
+from this seeded generator.  Rendering uses torch so it runs on the CPU (tests) or directly
+in HBM (bench.py).  Colours follow SURVEY.md: wood BGR ~ (65,100,128), black ~25, white ~230.
+"""
+import math
+
+import numpy as np
+import torch
+
+SEED = 20161001
+GSIZE = 19
+E, B, W = 0, 1, 2
+
+
+def random_corners(h, w, rng, jitter=0.08, fill=0.84):
+    """Four board corners (outer wood edge), clockwise from top-left, as float32 (4,2) (x,y).
+    The quad covers well over a third of the frame (area gate, bf_auto.py:82)."""
+    side = fill * min(h, w)
+    cx, cy = w / 2.0, h / 2.0
+    base = np.array([[cx - side / 2, cy - side / 2], [cx + side / 2, cy - side / 2],
+                     [cx + side / 2, cy + side / 2], [cx - side / 2, cy + side / 2]], np.float64)
+    base += rng.uniform(-jitter, jitter, (4, 2)) * side
+    return base.astype(np.float32)
+
+
+def random_stones(rng, density=0.3, keep_first_line_empty=True):
+    g = np.zeros((GSIZE, GSIZE), np.uint8)
+    m = rng.random((GSIZE, GSIZE)) < density
+    g[m] = rng.integers(1, 3, m.sum())
+    if keep_first_line_empty:          # documented limitation of the auto finder (bf_auto.py:14-15)
+        g[0, :] = g[-1, :] = 0
+        g[:, 0] = g[:, -1] = 0
+    return g
+
+
+def homography(src, dst):
+    """3x3 float64 H with H @ (src,1) ~ (dst,1); plain numpy solve (renderer only)."""
+    A, b = [], []
+    for (sx, sy), (dx, dy) in zip(src, dst):
+        A.append([sx, sy, 1, 0, 0, 0, -sx * dx, -sy * dx]); b.append(dx)
+        A.append([0, 0, 0, sx, sy, 1, -sx * dy, -sy * dy]); b.append(dy)
+    x = np.linalg.solve(np.array(A, np.float64), np.array(b, np.float64))
+    return np.append(x, 1.0).reshape(3, 3)
+
+
+def render(h, w, stones, corners, seed=SEED, noise=3.0, device="cpu"):
+    """-> uint8 tensor (h, w, 3) BGR on `device`."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    # image pixel -> board coordinates in cell units; the wood spans [-0.5, 18.5]^2 so that the
+    # canonical 380x380 image puts intersection i at pixel 10 + 20 i (stonesfinder.py:964-981)
+    lo, hi = -0.5, GSIZE - 0.5
+    Hm = homography(np.asarray(corners, np.float64), [(lo, lo), (hi, lo), (hi, hi), (lo, hi)])
+    Ht = torch.tensor(Hm, dtype=torch.float64, device=dev)
+    ys, xs = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float64),
+                            torch.arange(w, device=dev, dtype=torch.float64), indexing="ij")
+    den = Ht[2, 0] * xs + Ht[2, 1] * ys + Ht[2, 2]
+    u = ((Ht[0, 0] * xs + Ht[0, 1] * ys + Ht[0, 2]) / den).float()
+    v = ((Ht[1, 0] * xs + Ht[1, 1] * ys + Ht[1, 2]) / den).float()
+    inside = (u >= lo) & (u <= hi) & (v >= lo) & (v <= hi)
+
+    img = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
+    grad = 90.0 + 14.0 * (xs / w - 0.5).float() + 10.0 * (ys / h - 0.5).float()
+    img[:] = grad[..., None]
+    wood = torch.tensor([65.0, 100.0, 128.0], device=dev)
+    shade = 1.0 + 0.05 * torch.sin(u * 0.9) * torch.cos(v * 0.7)
+    img[inside] = (wood[None, :] * shade[inside][:, None])
+    # grid lines, 1/12 of a cell wide
+    ru, rv = torch.round(u), torch.round(v)
+    on_grid = inside & (u >= -0.04) & (u <= GSIZE - 1 + 0.04) & (v >= -0.04) & (v <= GSIZE - 1 + 0.04)
+    line = on_grid & (((u - ru).abs() < 1.0 / 24) | ((v - rv).abs() < 1.0 / 24))
+    img[line] = 35.0
+    # stones
+    st = torch.as_tensor(np.asarray(stones, np.uint8), device=dev)
+    iu = ru.clamp(0, GSIZE - 1).long()
+    iv = rv.clamp(0, GSIZE - 1).long()
+    d2 = (u - ru) ** 2 + (v - rv) ** 2
+    disc = inside & (d2 < 0.47 ** 2) & (ru >= 0) & (ru <= GSIZE - 1) & (rv >= 0) & (rv <= GSIZE - 1)
+    col = st[iv, iu]              # stones[row=v][col=u]
+    img[disc & (col == B)] = 25.0
+    img[disc & (col == W)] = 230.0
+    if noise > 0:
+        img += torch.randn((h, w, 3), generator=g, device=dev) * noise
+    return img.clamp_(0, 255).round_().to(torch.uint8)
+
+
+def scene(h, w, seed=SEED, density=0.3, device="cpu", noise=3.0):
+    """One seeded scene -> dict(frame uint8 (h,w,3) tensor, corners float32 (4,2), stones uint8 (19,19))."""
+    rng = np.random.default_rng(seed)
+    corners = random_corners(h, w, rng)
+    stones = random_stones(rng, density)
+    frame = render(h, w, stones, corners, seed=seed, noise=noise, device=device)
+    return dict(frame=frame, corners=corners, stones=stones)
+
+
+def video(nframes, h, w, seed=SEED, device="cpu", new_stone_every=5, noise=3.0):
+    """A fixed camera over a game: one new stone every `new_stone_every` frames.
+    -> frames uint8 (n,h,w,3) tensor, corners, list of per-frame stone grids, move list."""
+    rng = np.random.default_rng(seed)
+    corners = random_corners(h, w, rng)
+    stones = np.zeros((GSIZE, GSIZE), np.uint8)
+    frames, grids, moves = [], [], []
+    color = B
+    for f in range(nframes):
+        if f % new_stone_every == 0 and f > 0:
+            while True:
+                r, c = rng.integers(1, GSIZE - 1, 2)
+                if stones[r, c] == E:
+                    break
+            stones[r, c] = color
+            moves.append((color, int(r), int(c)))
+            color = W if color == B else B
+        frames.append(render(h, w, stones, corners, seed=seed + f, noise=noise, device=device))
+        grids.append(stones.copy())
+    return torch.stack(frames), corners, grids, moves
+
+
+def cnn_weights(seed=SEED, as_torch=False, device="cpu"):
+    """He-normal synthetic weights in Keras-1 'tf' layout; conv1 is scaled by 1/128 because the
+    reference feeds raw 0..255 pixels (nn_cache.py:47-51) and random weights have no reason to
+    compensate for it.  Replaced by trained weights when tests/golden/cnn_weights.npz exists."""
+    from .capi import WEIGHT_SHAPES, WEIGHT_ORDER
+    rng = np.random.default_rng(seed)
+    Wt = {}
+    for k in WEIGHT_ORDER:
+        shp = WEIGHT_SHAPES[k]
+        if k.endswith("b"):
+            Wt[k] = (rng.standard_normal(shp) * 0.05).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shp[:-1]))
+            Wt[k] = (rng.standard_normal(shp) * math.sqrt(2.0 / fan_in)).astype(np.float32)
+    Wt["c1w"] *= np.float32(1.0 / 128)
+    if as_torch:
+        return {k: torch.from_numpy(v).to(device) for k, v in Wt.items()}
+    return Wt

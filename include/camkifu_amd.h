@@ -1,0 +1,129 @@
+/*
+ * camkifu_amd.h -- C-ABI of the MI355X-native CamKifu vision hot path (libck_hip.so).
+ *
+ * Drop-in boundary: the reference (ArnaudPel/CamKifu) is pure Python and reaches all of
+ * its arithmetic through cv2 / Keras calls made from BoardFinderAuto._detect and
+ * StonesFinder._doframe / SfNeural._find.  Each entry point below replaces one such call
+ * site (cited as file:line under the reference's src/camkifu/), takes plain pointers and
+ * sizes, and is what a ctypes binding in the reference would bind.
+ *
+ * Conventions
+ *   - every function returns CK_OK (0) or a CK_ERR_* code; nothing throws or aborts across
+ *     the boundary; ck_last_error() gives the message for the last failing call on a ctx.
+ *   - images are uint8, row-major, channels interleaved (BGR) exactly as cv2 hands them,
+ *     no row padding (stride = w * channels); batches are n such images back to back.
+ *   - `*_space` arguments say where a pointer lives: CK_HOST or CK_DEVICE (HBM).  Input
+ *     pointers are borrowed for the duration of the call only.
+ *   - one ck_ctx per finder instance / thread: it owns a HIP stream and scratch buffers
+ *     and is not re-entrant; different contexts may be used concurrently.
+ *   - calls are synchronous: results are complete when the call returns.
+ */
+#ifndef CAMKIFU_AMD_H
+#define CAMKIFU_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { CK_OK = 0, CK_ERR_ARG = 1, CK_ERR_HIP = 2, CK_ERR_CAPACITY = 3, CK_ERR_STATE = 4 };
+enum { CK_HOST = 0, CK_DEVICE = 1 };
+enum { CK_BACKEND_HIP = 1 };
+enum { CK_CNN_FP32 = 0, CK_CNN_BF16 = 1 };
+
+/* per-frame status of the board path, mirrors the early exits of
+ * BoardFinderAuto._detect (board/bf_auto.py:76-82) */
+enum { CK_BOARD_LINES = 0,        /* lines were searched (n_lines may be 0)          */
+       CK_BOARD_NO_CONTOUR = 1,   /* len(contours) == 0                 bf_auto.py:76 */
+       CK_BOARD_TOO_SMALL = 2 };  /* not frame_area/3 < biggest.area     bf_auto.py:82 */
+
+typedef struct ck_ctx ck_ctx;
+
+typedef struct ck_board_result {
+    int32_t status;        /* CK_BOARD_*                                              */
+    int32_t n_contours;    /* len(contours) returned by findContours(RETR_EXTERNAL)   */
+    int32_t n_lines;       /* number of Hough lines found (may exceed the caller cap) */
+    int32_t reserved;
+    double  biggest_area;  /* sorted_boxes[-1].area (minAreaRect w*h)                 */
+} ck_board_result;
+
+/* ---- context ------------------------------------------------------------------------ */
+int  ck_ctx_create(int device, ck_ctx** out);
+void ck_ctx_destroy(ck_ctx* ctx);
+const char* ck_last_error(const ck_ctx* ctx);     /* ctx may be NULL: last create error */
+int  ck_backend(const ck_ctx* ctx);               /* CK_BACKEND_HIP                     */
+int  ck_version(void);
+void* ck_stream(ck_ctx* ctx);                     /* the hipStream_t the ctx launches on */
+/* kernel-time accounting with HIP events on the ctx stream (used by bench.py) */
+int  ck_timing_enable(ck_ctx* ctx, int on);
+int  ck_timing_reset(ck_ctx* ctx);
+/* name: "median", "canny_nms", "ccl", "hough_vote", "warp", "cnn", ...; returns total ms
+ * and number of launches recorded since the last reset */
+int  ck_timing_get(ck_ctx* ctx, const char* name, double* total_ms, int* launches);
+
+/* ---- K1  cv2.medianBlur(frame, 15)                              board/bf_auto.py:72 */
+int ck_median15(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
+                uint8_t* out, int out_space);
+
+/* ---- K2  cv2.Canny(median, low, high)  3-channel, aperture 3, L1  board/bf_auto.py:73
+ * map_out (optional, same space as edges): NMS map before hysteresis
+ * (0 candidate, 1 suppressed, 2 strong). */
+int ck_canny(ck_ctx* ctx, const uint8_t* img3, int n, int h, int w, int in_space,
+             int low, int high, uint8_t* edges, uint8_t* map_out, int out_space);
+
+/* ---- K1+K2 fused pipeline: the "filter pass"                  board/bf_auto.py:72-73 */
+int ck_board_edges(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
+                   uint8_t* edges, int out_space);
+
+/* ---- K3..K6  findContours(RETR_EXTERNAL) -> 3 biggest minAreaRect -> drawContours
+ *      -> HoughLines(1, pi/180, hough_thresh)          board/bf_auto.py:75-84, 105-133
+ * lines: host, n * cap * 2 floats (rho, theta) in OpenCV's order; res: host, n entries.
+ * ghost_out optional (n*h*w).  hough_thresh < 0 means int(min(h,w)/5). */
+int ck_board_lines(ck_ctx* ctx, const uint8_t* edges, int n, int h, int w, int in_space,
+                   int hough_thresh, float* lines, int cap, ck_board_result* res,
+                   uint8_t* ghost_out, int ghost_space);
+
+/* ---- K1..K6 stateless core of BoardFinderAuto._detect        board/bf_auto.py:72-84 */
+int ck_board_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
+                    int hough_thresh, float* lines, int cap, ck_board_result* res);
+
+/* ---- K7  cv2.getPerspectiveTransform(src4, dst4)            board/boardfinder.py:43-45
+ * host only; src/dst 4x2 float32, M 3x3 float64 row-major. */
+int ck_get_perspective_transform(const float* src4, const float* dst4, double* M9);
+
+/* ---- K8  cv2.warpPerspective(frame, M, (dsize,dsize))         stone/stonesfinder.py:140
+ * M: host, m_count x 9 doubles (m_count == 1: shared by all frames, else == n). */
+int ck_warp_perspective(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
+                        const double* M, int m_count, int dsize,
+                        uint8_t* out, int out_space);
+
+/* ---- K9  BackgroundSubtractorMOG2(detectShadows=False).apply stone/stonesfinder.py:113-115,171-176
+ * one model per stream; stateful, frames must be applied in order. */
+int ck_mog2_create(ck_ctx* ctx, int h, int w, int* handle);
+int ck_mog2_apply(ck_ctx* ctx, int handle, const uint8_t* img3, int in_space,
+                  double learning_rate, uint8_t* fgmask, int out_space);
+int ck_mog2_destroy(ck_ctx* ctx, int handle);
+
+/* ---- K10..K12 stone classifier                stone/nn_manager.py:216-298, nn_cache.py:16-52
+ * weights: 12 float32 arrays in Keras-1 'tf' layout, order
+ *   c1w[5,5,3,32] c1b c2w[5,5,32,32] c2b c3w[3,3,32,90] c3b c4w[3,3,90,90] c4b
+ *   d1w[3240,160] d1b d2w[160,81] d2b
+ * (conv kernels are applied as true convolutions, as Keras-1 on Theano does).
+ * `space` may be CK_DEVICE: e.g. data_ptr() of PyTorch-ROCm tensors. */
+int ck_cnn_set_weights(ck_ctx* ctx, const float* const weights[12], int space);
+int ck_cnn_set_mode(ck_ctx* ctx, int mode);      /* CK_CNN_FP32 (default) | CK_CNN_BF16 */
+/* goban: n x 380 x 380 x 3.  Any of y (n*100*81 softmax), labels (n*361, 0=E 1=B 2=W),
+ * conf (n*361 doubles, max(y)/sum(y)) may be NULL. */
+int ck_cnn_predict(ck_ctx* ctx, const uint8_t* goban, int n, int in_space,
+                   float* y, uint8_t* labels, double* conf, int out_space);
+
+/* ---- K8 + K10..K12: frame + M -> 19x19 labels   stonesfinder.py:140 + nn_cache.py:33-41 */
+int ck_stones_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
+                     const double* M, int m_count, uint8_t* labels, double* conf,
+                     int out_space);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,45 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/camkifu_amd.h
+declares (no compute call is made here: that needs a GPU)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "camkifu_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ck_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported():
+    from camkifu_amd import capi
+    capi.build()
+    lib = ctypes.CDLL(capi.SO_PATH)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(capi.EXPORTS) == names
+
+
+def test_no_gpu_means_loud_failure():
+    import pytest
+    import torch
+    from camkifu_amd import capi
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.CkError):
+        capi.Context(0)
+
+
+def test_product_never_imports_oracle():
+    """the product path must not import, link or dlopen anything under oracle/"""
+    pkg = os.path.join(ROOT, "camkifu_amd")
+    bad = re.compile(r"(import\s+oracle|from\s+oracle|libck_oracle|ora_[a-z0-9_]+\s*\(|oracle[/\\.]oracle|ck_oracle\.h)")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not bad.search(txt), os.path.join(dp, f)

@@ -1,0 +1,232 @@
+"""Parity of the HIP path (through the C-ABI, libck_hip.so) against the CPU oracle on the same
+seeded inputs.  Bars: bit-exact for every byte / integer / index result (median, NMS map,
+edges, ghost, contour counts, Hough votes -> (rho,theta) floats, warp, MOG2 masks, labels);
+1e-4 absolute on the CNN's softmax outputs (north_star's float tolerance)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ck():
+    from camkifu_amd import capi
+    ctx = capi.Context(0)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from camkifu_amd import synth
+    return synth
+
+
+def _smooth_rand(rng, h, w):
+    from scipy import ndimage
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    img = ndimage.uniform_filter(img.astype(np.float32), (7, 7, 1)).astype(np.uint8)
+    img[h // 4: h // 2, w // 3: 2 * w // 3] //= 3
+    return img
+
+
+# ---------------------------------------------------------------- K1
+@pytest.mark.parametrize("shape", [(16, 16), (37, 53), (64, 48), (100, 130), (129, 97)])
+def test_median_random_shapes(ck, ora, shape):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    img = rng.integers(0, 256, shape + (3,), dtype=np.uint8)          # worst case: pure noise
+    assert np.array_equal(ck.median15(img), ora.median(img, 15))
+    img = _smooth_rand(rng, *shape)
+    assert np.array_equal(ck.median15(img), ora.median(img, 15))
+
+
+def test_median_extremes_and_batch(ck, ora):
+    rng = np.random.default_rng(11)
+    imgs = np.stack([np.zeros((40, 70, 3), np.uint8), np.full((40, 70, 3), 255, np.uint8),
+                     rng.integers(0, 2, (40, 70, 3), dtype=np.uint8) * 255,
+                     rng.integers(250, 256, (40, 70, 3), dtype=np.uint8)])
+    out = ck.median15(imgs)
+    for k in range(len(imgs)):
+        assert np.array_equal(out[k], ora.median(imgs[k], 15))
+
+
+def test_median_synthetic_vga_and_1080p(ck, ora, synth):
+    for (h, w) in [(480, 640), (1080, 1920)]:
+        fr = synth.scene(h, w, seed=synth.SEED + h)["frame"].numpy()
+        assert np.array_equal(ck.median15(fr), ora.median(fr, 15))
+
+
+# ---------------------------------------------------------------- K2
+@pytest.mark.parametrize("shape", [(16, 16), (40, 56), (97, 131)])
+def test_canny_random(ck, ora, shape):
+    rng = np.random.default_rng(shape[1])
+    img = _smooth_rand(rng, *shape)
+    e, m = ck.canny(img, 25, 75, want_map=True)
+    e2, m2, _, _, _ = ora.canny(img, 25, 75, want_map=True)
+    assert np.array_equal(m, m2)
+    assert np.array_equal(e, e2)
+    assert e.any()
+
+
+def test_board_edges_chain(ck, ora, synth):
+    frames = np.stack([synth.scene(480, 640, seed=s)["frame"].numpy() for s in (1, 2, 3)])
+    e = ck.board_edges(frames)
+    for k in range(3):
+        assert np.array_equal(e[k], ora.canny(ora.median(frames[k], 15), 25, 75))
+    fr = synth.scene(1080, 1920, seed=5)["frame"].numpy()
+    assert np.array_equal(ck.board_edges(fr), ora.canny(ora.median(fr, 15), 25, 75))
+
+
+# ---------------------------------------------------------------- K3..K6
+def _cmp_board(out, ghost, o):
+    """out: one entry of Context.board_lines; o: oracle.board_lines dict."""
+    assert out["n_contours"] == o["n_contours"]
+    if o["status"] == -1:
+        assert out["status"] == 1
+        return
+    assert out["biggest_area"] == o["biggest_area"]
+    if o["status"] == -2:
+        assert out["status"] == 2
+        assert not ghost.any()
+        return
+    assert out["status"] == 0
+    assert np.array_equal(ghost, o["ghost"])
+    assert out["n_lines"] == o["status"]
+    assert np.array_equal(out["lines"], o["lines"])
+
+
+def test_board_lines_synthetic(ck, ora, synth):
+    for (h, w, seed) in [(480, 640, 1), (480, 640, 2), (1080, 1920, 3)]:
+        fr = synth.scene(h, w, seed=seed)["frame"].numpy()
+        edges = ora.canny(ora.median(fr, 15), 25, 75)
+        out, ghost = ck.board_lines(edges, want_ghost=True)
+        o = ora.board_lines(edges)
+        assert o["status"] > 0                      # the scene does yield lines
+        _cmp_board(out[0], ghost, o)
+
+
+@pytest.mark.parametrize("density", [0.02, 0.1, 0.3, 0.5, 0.7])
+def test_board_lines_random_edge_maps(ck, ora, density):
+    rng = np.random.default_rng(int(density * 1000))
+    maps = []
+    for k in range(6):
+        e = (rng.random((60, 90)) < density).astype(np.uint8) * 255
+        if k % 2:                                   # add a big closed outline so the gate passes
+            e[5:55, 8] = e[5:55, 80] = 255
+            e[5, 8:81] = e[54, 8:81] = 255
+        maps.append(e)
+    maps = np.stack(maps)
+    out, ghost = ck.board_lines(maps, hough_thresh=20, want_ghost=True)
+    for k in range(len(maps)):
+        _cmp_board(out[k], ghost[k], ora.board_lines(maps[k], hough_thresh=20))
+
+
+def test_board_lines_edge_cases(ck, ora):
+    z = np.zeros((20, 30), np.uint8)
+    out = ck.board_lines(z)
+    assert out[0]["status"] == 1 and out[0]["n_contours"] == 0
+    one = z.copy()
+    one[10, 10] = 255
+    out = ck.board_lines(one)
+    assert out[0]["status"] == 2 and out[0]["n_contours"] == 1 and out[0]["biggest_area"] == 0.0
+    full = np.full((20, 30), 255, np.uint8)
+    out, ghost = ck.board_lines(full, hough_thresh=5, want_ghost=True)
+    _cmp_board(out[0], ghost[0], ora.board_lines(full, hough_thresh=5))
+
+
+def test_board_detect_full_chain(ck, ora, synth):
+    frames = np.stack([synth.scene(480, 640, seed=s)["frame"].numpy() for s in (7, 8)])
+    out = ck.board_detect(frames)
+    for k in range(2):
+        o = ora.board_lines(ora.canny(ora.median(frames[k], 15), 25, 75))
+        assert out[k]["n_lines"] == o["status"] and np.array_equal(out[k]["lines"], o["lines"])
+
+
+# ---------------------------------------------------------------- K7 / K8
+def test_warp_bit_exact(ck, ora, synth):
+    from camkifu_amd import capi
+    for (h, w, seed) in [(480, 640, 1), (1080, 1920, 2)]:
+        sc = synth.scene(h, w, seed=seed)
+        dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
+        M = capi.get_perspective_transform(sc["corners"], dst)
+        assert np.allclose(M, ora.get_perspective_transform(sc["corners"], dst), rtol=1e-9, atol=1e-12)
+        fr = sc["frame"].numpy()
+        assert np.array_equal(ck.warp_perspective(fr, M), ora.warp_perspective(fr, M))
+    # partly outside the frame: constant border
+    M2 = M.copy()
+    M2[0, 2] -= 150
+    M2[1, 2] += 90
+    assert np.array_equal(ck.warp_perspective(fr, M2), ora.warp_perspective(fr, M2))
+
+
+# ---------------------------------------------------------------- K9
+def test_mog2_sequence(ck, ora):
+    rng = np.random.default_rng(3)
+    base = rng.integers(40, 200, (380, 380, 3)).astype(np.int16)
+    ref = ora.MOG2(380, 380, 3)
+    hd = ck.mog2_create(380, 380)
+    for f in range(60):
+        frame = np.clip(base + rng.integers(-6, 7, base.shape), 0, 255).astype(np.uint8)
+        if f > 52:
+            frame[100:140, 200:260] = 255 - frame[100:140, 200:260]
+        lr = 0.01 if f < 50 else 0.005
+        assert np.array_equal(ck.mog2_apply(hd, frame, lr), ref.apply(frame, lr)), f
+    ck.mog2_destroy(hd)
+
+
+# ---------------------------------------------------------------- K10..K12
+def test_cnn_parity(ck, ora, synth):
+    W = synth.cnn_weights()
+    ck.cnn_set_weights(W)
+    sc = synth.scene(480, 640, seed=4, density=0.4)
+    dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
+    M = ora.get_perspective_transform(sc["corners"], dst)
+    goban = ora.warp_perspective(sc["frame"].numpy(), M)
+    rng = np.random.default_rng(9)
+    gobans = np.stack([goban, rng.integers(0, 256, (380, 380, 3), dtype=np.uint8)])
+    y, labels, conf = ck.cnn_predict(gobans)
+    for k in range(2):
+        y2 = ora.cnn_predict_regions(W, gobans[k])
+        assert np.abs(y[k] - y2).max() <= 1e-4
+        l2, c2 = ora.decode_all(y2)
+        assert np.array_equal(labels[k], l2)
+        assert np.abs(conf[k] - c2).max() <= 1e-4
+        # decode applied to the GPU's own softmax must be exact (integer / index work)
+        l3, c3 = ora.decode_all(y[k])
+        assert np.array_equal(labels[k], l3) and np.array_equal(conf[k], c3)
+
+
+def test_stones_detect_chain(ck, ora, synth):
+    W = synth.cnn_weights()
+    ck.cnn_set_weights(W)
+    sc = synth.scene(1080, 1920, seed=6, density=0.35)
+    dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
+    M = ora.get_perspective_transform(sc["corners"], dst)
+    fr = sc["frame"].numpy()
+    labels, conf = ck.stones_detect(fr, M)
+    goban = ora.warp_perspective(fr, M)
+    l2, c2 = ora.decode_all(ora.cnn_predict_regions(W, goban))
+    assert np.array_equal(labels[0], l2)
+    assert np.abs(conf[0] - c2).max() <= 1e-4
+
+
+def test_device_resident_inputs(ck, ora, synth):
+    """inputs already in HBM (torch tensors): same results as host inputs"""
+    import torch
+    fr = synth.scene(480, 640, seed=12)["frame"]
+    e_host = ck.board_edges(fr.numpy())
+    e_dev = ck.board_edges(fr.cuda())
+    assert e_dev.is_cuda and np.array_equal(e_dev.cpu().numpy(), e_host)
+    out_h = ck.board_detect(fr.numpy())
+    out_d = ck.board_detect(fr.cuda())
+    assert np.array_equal(out_h[0]["lines"], out_d[0]["lines"])
+
+
+def test_errors_are_reported_not_thrown(ck):
+    from camkifu_amd import capi
+    with pytest.raises(capi.CkError):
+        ck.board_lines(np.zeros((2, 2), np.uint8))
+    ck2 = capi.Context(0)
+    with pytest.raises(capi.CkError):
+        ck2.cnn_predict(np.zeros((380, 380, 3), np.uint8))        # weights not set
+    ck2.close()
