@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the per-frame vision hot path on synthetic 1080p video.
+
+One "step" = one pass of the hot path over one batch of frames that is already resident in
+HBM: board detect (K1..K6: median -> Canny -> contours -> Hough lines, lines back on the
+host) and stones detect (K8, K10..K12: warp -> 100 patches -> CNN -> 19x19 labels) for every
+frame of the batch, then (N > 1) an RCCL all-gather of the per-frame 19x19 labels.
+Workload (BASELINE.json configs[2]): 1080p, 256-frame batches on one MI355X; with N GPUs
+every rank processes its own 256-frame shard of the video (weak scaling, no data-path
+collective except the label gather).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
+torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3         # v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TF = 2500.0
+
+# MACs per frame (100 patches), SURVEY.md 8(a)
+MACS = dict(cnn_conv1=311.04e6, cnn_conv2=2621.44e6, cnn_conv3=508.03e6, cnn_conv4=1049.76e6)
+
+
+def cpu_baseline(h, w, frames, corners, weights, nframes):
+    """Time the CPU oracle (our C restatement, OpenMP) on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import oracle as ora
+    dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
+    M = ora.get_perspective_transform(corners, dst)
+    sample = [frames[i].cpu().numpy() for i in range(nframes)]
+    t0 = time.perf_counter()
+    for fr in sample:
+        ora.board_lines(ora.canny(ora.median(fr, 15), 25, 75))
+        ora.decode_all(ora.cnn_predict_regions(weights, ora.warp_perspective(fr, M)))
+    dt = time.perf_counter() - t0
+    return dict(value=round(nframes / dt, 4), unit="frames/s", cores=ora.num_threads(), kind="port",
+                sample="%d frames of the same %dx%d batch, board path + stones path, oracle/*.c with OpenMP"
+                       % (nframes, w, h))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=256, help="frames per batch per GPU")
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--distinct", type=int, default=16, help="distinct rendered scenes per batch")
+    ap.add_argument("--cnn", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from camkifu_amd import capi, synth
+    ctx = capi.Context(local_rank)
+    H, W, F = args.height, args.width, args.frames
+
+    # ---- synthetic video shard of this rank, rendered straight into HBM --------------------
+    rng = np.random.default_rng(synth.SEED + rank)
+    corners = synth.random_corners(H, W, rng)
+    frames = torch.empty((F, H, W, 3), dtype=torch.uint8, device=dev)
+    nd = min(args.distinct, F)
+    for i in range(nd):
+        stones = synth.random_stones(rng, density=0.1 + 0.4 * i / max(1, nd - 1))
+        frames[i] = synth.render(H, W, stones, corners, seed=synth.SEED + 1000 * rank + i, device=dev)
+    for i in range(nd, F):                       # remaining frames: earlier scenes with fresh noise
+        base = frames[i % nd].to(torch.int16)
+        g = torch.Generator(device=dev)
+        g.manual_seed(synth.SEED + 7 * i + rank)
+        noise = torch.randint(-2, 3, base.shape, generator=g, device=dev, dtype=torch.int16)
+        frames[i] = (base + noise).clamp_(0, 255).to(torch.uint8)
+    weights = synth.cnn_weights()
+    ctx.cnn_set_weights({k: torch.from_numpy(v).to(dev) for k, v in weights.items()})
+    ctx.cnn_set_mode(capi.CK_CNN_BF16 if args.cnn == "bf16" else capi.CK_CNN_FP32)
+    dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
+    M = capi.get_perspective_transform(corners, dst)
+    gathered = torch.empty((world * F, 19, 19), dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def step():
+        board = ctx.board_detect(frames)                       # K1..K6, lines on the host
+        labels, conf = ctx.stones_detect(frames, M)            # K8, K10..K12, labels in HBM
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, labels)      # RCCL over xGMI: 361 B / frame
+        return board, labels
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        board, labels = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        stage_names = ["median", "canny_nms", "canny_hyst", "ccl", "contour_gather", "ghost", "hough_vote",
+                       "hough_peaks", "warp", "cnn_conv1", "cnn_conv2", "cnn_conv3", "cnn_conv4", "cnn_tail"]
+        stages = {}
+        for nme in stage_names:
+            ms, cnt = ctx.timing_get(nme)
+            if cnt:
+                stages[nme] = dict(ms_total=round(ms, 3), launches=cnt, us_per_frame=round(1e3 * ms / (args.steps * F), 3))
+        ctx.timing_enable(False)
+        # roofline of the dominant kernel
+        dom = max(stages, key=lambda k: stages[k]["ms_total"]) if stages else None
+        roof = None
+        if dom is not None:
+            per_launch_frames = args.steps * F / stages[dom]["launches"]
+            avg_s = stages[dom]["ms_total"] / stages[dom]["launches"] * 1e-3
+            if dom in MACS:
+                peak = MFMA_BF16_PEAK_TF if args.cnn == "bf16" else MFMA_F32_PEAK_TF
+                ach = 2.0 * MACS[dom] * per_launch_frames / avg_s / 1e12
+                roof = dict(kernel=dom, bound="mfma", achieved=round(ach, 3), peak=peak, unit="TFLOP/s",
+                            frac=round(ach / peak, 5), traffic=None)
+            else:
+                bytes_per_frame = {"median": 2 * 3 * W * H, "canny_nms": 4 * W * H, "warp": 433200 + 3 * W * H,
+                                   "ccl": 6 * W * H, "canny_hyst": 2 * W * H}.get(dom, 4 * W * H)
+                ach = bytes_per_frame * per_launch_frames / avg_s / 1e9
+                roof = dict(kernel=dom, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(ach / HBM_PEAK_GBS, 5), traffic=None)
+        # the filter pass (K1) is always reported as well: north_star quotes HBM roofline on it
+        filt = None
+        if "median" in stages:
+            avg_s = stages["median"]["ms_total"] / stages["median"]["launches"] * 1e-3
+            ach = 2 * 3 * W * H * (args.steps * F / stages["median"]["launches"]) / avg_s / 1e9
+            filt = dict(kernel="median", bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(ach / HBM_PEAK_GBS, 5))
+        out = {
+            "metric": "frames/sec on 1920x1080 video + 19x19 stone-grid match % vs reference SGF",
+            "value": round(world * F * args.steps / dt, 2),
+            "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8" if args.cnn == "fp32" else "u8+bf16", "data": "synthetic",
+            "config": {"workload": "%dx%d synthetic video, %d-frame batch per GPU, board detect (K1-K6) + "
+                                   "stones detect (K8,K10-K12), cnn %s" % (W, H, F, args.cnn),
+                       "frames_per_gpu": F, "height": H, "width": W, "parallelism": "frames sharded x%d" % world},
+            "roofline": roof,
+            "filter_pass": filt,
+            "stages": stages,
+            "lines_found_frame0": int(board[0]["n_lines"]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(H, W, frames, corners, weights, args.cpu_frames)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

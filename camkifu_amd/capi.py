@@ -58,6 +58,14 @@ def lib():
         if not os.path.exists(SO_PATH):
             raise CkError("libck_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                           "camkifu_amd has no CPU fallback")
+        # PyTorch-ROCm wheels bundle their own HIP runtime; two HIP runtimes in one process
+        # cannot both own the GPU.  Importing torch first makes the loader resolve
+        # libck_hip.so's libamdhip64.so.7 dependency to the copy torch already mapped, so
+        # torch tensors and this library share one runtime (and one device context).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(SO_PATH)
         L.ck_last_error.restype = C.c_char_p
         L.ck_last_error.argtypes = [C.c_void_p]

@@ -125,6 +125,9 @@ void ora_cnn_forward(const ora_cnn_weights* W, const uint8_t* patches, int n,
 /* NNCache.predict_all_stones: labels 19x19 u8 {0=E,1=B,2=W}, conf 19x19 double */
 void ora_decode_all(const float* y /*100x81*/, uint8_t* labels, double* conf);
 
+/* threads the OpenMP-parallel routines (median rows, CNN patches) will use */
+int ora_num_threads(void);
+
 #ifdef __cplusplus
 }
 #endif

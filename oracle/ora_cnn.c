@@ -68,6 +68,9 @@ static void dense(const float* in, int nin, const float* w, const float* b, int 
 void ora_cnn_forward(const ora_cnn_weights* Wt, const uint8_t* patches, int n,
                      float* y_out, float* logits_out)
 {
+    /* patches are independent: OpenMP over patches (the CPU baseline uses every core) */
+#pragma omp parallel
+    {
     float* x0 = (float*)malloc(sizeof(float) * 40 * 40 * 3);
     float* a1 = (float*)malloc(sizeof(float) * 36 * 36 * 32);
     float* a2 = (float*)malloc(sizeof(float) * 32 * 32 * 32);
@@ -76,6 +79,7 @@ void ora_cnn_forward(const ora_cnn_weights* Wt, const uint8_t* patches, int n,
     float* a4 = (float*)malloc(sizeof(float) * 12 * 12 * 90);
     float* p4 = (float*)malloc(sizeof(float) * 6 * 6 * 90);
     float h1[160], lg[81];
+#pragma omp for schedule(dynamic)
     for (int p = 0; p < n; p++) {
         const uint8_t* src = patches + (size_t)p * 4800;
         for (int i = 0; i < 4800; i++) x0[i] = (float)src[i];
@@ -96,6 +100,7 @@ void ora_cnn_forward(const ora_cnn_weights* Wt, const uint8_t* patches, int n,
         for (int i = 0; i < 81; i++) y_out[(size_t)p * 81 + i] = e[i] / sum;
     }
     free(p4); free(a4); free(a3); free(p2); free(a2); free(a1); free(x0);
+    }
 }
 
 /* NNManager._subregion + _get_rect_nn, gsize=19, split=10, step=2, 380x380 image:

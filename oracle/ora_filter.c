@@ -23,6 +23,7 @@ void ora_median(const uint8_t* src, int h, int w, int cn, int ksize, uint8_t* ds
     const int r = ksize / 2;
     const int rank = (ksize * ksize) / 2;
     for (int c = 0; c < cn; c++) {
+#pragma omp parallel for schedule(static)
         for (int y = 0; y < h; y++) {
             int fine[256];
             int coarse[16];
@@ -140,3 +141,10 @@ void ora_canny(const uint8_t* src, int h, int w, int cn, int low, int high,
     for (size_t i = 0; i < npx; i++) edges[i] = (uint8_t)-(map[i] >> 1);
     free(stack); free(map); free(gy); free(gx); free(mag);
 }
+
+#ifdef _OPENMP
+#include <omp.h>
+int ora_num_threads(void) { return omp_get_max_threads(); }
+#else
+int ora_num_threads(void) { return 1; }
+#endif

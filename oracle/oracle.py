@@ -45,6 +45,10 @@ def lib():
     return _lib
 
 
+def num_threads():
+    return int(lib().ora_num_threads())
+
+
 def _vp(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
