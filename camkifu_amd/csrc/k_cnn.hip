@@ -361,7 +361,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
     // frames are processed in chunks so the activation scratch stays bounded
     const int CHUNK = 32;
     const size_t a1_sz = (size_t)CHUNK * 100 * 36 * 36 * 32 * 4;      // conv1 out, later conv3 out
-    const size_t p2_sz = (size_t)CHUNK * 100 * 16 * 16 * 32 * 4;      // conv2+pool out, later conv4 out
+    const size_t p2_sz = (size_t)CHUNK * 100 * 12 * 12 * 90 * 4;      // conv2+pool out (16*16*32), later conv4 out (12*12*90)
     CK_TRY(ck_ensure(ctx, ctx->act0, a1_sz));
     CK_TRY(ck_ensure(ctx, ctx->act1, p2_sz));
     CK_TRY(ck_ensure(ctx, ctx->act2, (size_t)CHUNK * 100 * (3240 + 160) * 4));
