@@ -1,0 +1,64 @@
+"""Headless controller: the sink the finders talk to (same `pipe` instruction names and board
+queries as the reference's vgui/ControllerV and test/objects/ControllerVDev: "append",
+"delete", "bulk", "auto_save"; is_empty_blocking, locate, get_stones).  Instructions run
+synchronously on the caller's thread; there are no Go rules (no captures) -- SURVEY.md 8f rank 4."""
+import numpy as np
+
+from .golib_shim import gsize, E, Kifu
+
+
+class ControllerHeadless:
+    def __init__(self, video=None, bounds=(0, 1), autosave_path=None):
+        self.video = video
+        self.bounds = bounds
+        self.kifu = Kifu()
+        self.board = [[None] * gsize for _ in range(gsize)]      # board[x][y] -> Move
+        self.autosave_path = autosave_path
+        self.ignored = set()
+        self.api = {"append": self._append, "delete": self._delete, "bulk": self._bulk, "auto_save": self._auto_save}
+
+    def pipe(self, instruction, *args):
+        fn = self.api.get(instruction)
+        if fn is None:
+            self.ignored.add(instruction)
+            return
+        fn(*args)
+
+    def _append(self, move):
+        if self.board[move.x][move.y] is not None:
+            raise ValueError("occupied: %s" % move)
+        self.board[move.x][move.y] = move
+        self.kifu.append(move)
+
+    def _delete(self, x, y):
+        mv = self.board[x][y]
+        if mv is not None:
+            self.board[x][y] = None
+            self.kifu.pop_at(x, y)
+        return mv
+
+    def _bulk(self, moves):
+        for mv in moves:
+            if mv.color == E:
+                self._delete(mv.x, mv.y)
+            else:
+                self._append(mv)
+
+    def _auto_save(self):
+        if self.autosave_path:
+            self.kifu.save(self.autosave_path)
+
+    def is_empty_blocking(self, x, y):
+        return self.board[x][y] is None
+
+    def locate(self, x, y):
+        return self.board[x][y]
+
+    def get_stones(self):
+        """copy of the goban in numpy coordinates: stones[r][c] in {'E','B','W'}"""
+        out = np.full((gsize, gsize), E, dtype=object)
+        for x in range(gsize):
+            for y in range(gsize):
+                if self.board[x][y] is not None:
+                    out[y, x] = self.board[x][y].color
+        return out

@@ -15,14 +15,22 @@ GSIZE = 19
 E, B, W = 0, 1, 2
 
 
-def random_corners(h, w, rng, jitter=0.08, fill=0.84):
+def random_corners(h, w, rng, jitter=0.05, fill=0.84, slant=0.06):
     """Four board corners (outer wood edge), clockwise from top-left, as float32 (4,2) (x,y).
-    The quad covers well over a third of the frame (area gate, bf_auto.py:82)."""
+    The quad covers well over a third of the frame (area gate, bf_auto.py:82).  Both vertical
+    sides are slanted by at least `slant`/2 of the board side: the reference groups line
+    intersections by their x coordinate only (bf_auto.py:161, imgutil.py:59), so a board whose
+    left (or right) corners share an x can never be detected by it."""
     side = fill * min(h, w)
     cx, cy = w / 2.0, h / 2.0
     base = np.array([[cx - side / 2, cy - side / 2], [cx + side / 2, cy - side / 2],
                      [cx + side / 2, cy + side / 2], [cx - side / 2, cy + side / 2]], np.float64)
     base += rng.uniform(-jitter, jitter, (4, 2)) * side
+    for top, bot in ((0, 3), (1, 2)):
+        sgn = 1.0 if rng.random() < 0.5 else -1.0
+        mid = 0.5 * (base[top, 0] + base[bot, 0])
+        half = rng.uniform(0.5, 1.0) * slant * side * 0.5
+        base[top, 0], base[bot, 0] = mid + sgn * half, mid - sgn * half
     return base.astype(np.float32)
 
 
