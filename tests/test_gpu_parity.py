@@ -230,3 +230,88 @@ def test_errors_are_reported_not_thrown(ck):
     with pytest.raises(capi.CkError):
         ck2.cnn_predict(np.zeros((380, 380, 3), np.uint8))        # weights not set
     ck2.close()
+
+
+# ---------------------------------------------------------------- drop-in finders, end to end
+def test_finders_end_to_end_match_oracle_backed_run(synth):
+    """The same clip through VManagerSeq twice: finders on the HIP library vs finders answered by
+    the oracle.  Corners, transform and the recorded game must be identical."""
+    from camkifu_amd import capi
+    from camkifu_amd.controller import ControllerHeadless
+    from camkifu_amd.core.vmanager import VManagerSeq
+    from camkifu_amd.stone.nn_manager import NNManager
+    from .stub_ctx import OracleCtx
+
+    rng = np.random.default_rng(5)
+    corners = synth.random_corners(480, 640, rng)
+    stones = synth.random_stones(rng, density=0.25)
+    frames = np.stack([synth.render(480, 640, stones, corners, seed=100 + f).numpy() for f in range(75)])
+    # a change on the board after the first assessment, so that the steady-state path runs too
+    stones2 = stones.copy()
+    stones2[9, 9] = 1
+    for f in range(58, 75):
+        frames[f] = synth.render(480, 640, stones2, corners, seed=100 + f).numpy()
+
+    def run(make_ctx):
+        global _REAL_CLS
+        NNManager._network = None
+        real = capi.Context
+        if _REAL_CLS is None:
+            _REAL_CLS = real
+        capi.Context = make_ctx
+        try:
+            ctrl = ControllerHeadless(video=frames)
+            vm = VManagerSeq(ctrl)
+            vm.run()
+        finally:
+            capi.Context = real
+        assert getattr(vm, "error", None) is None
+        return vm, ctrl
+
+    vm_gpu, c_gpu = run(_real)
+    octx = OracleCtx()
+    vm_ora, c_ora = run(lambda device=0: octx)
+    assert vm_gpu.board_finder.corners.hull == vm_ora.board_finder.corners.hull
+    assert np.array_equal(vm_gpu.board_finder.mtx, vm_ora.board_finder.mtx)
+    assert vm_gpu.stones_finder.total_f_processed == vm_ora.stones_finder.total_f_processed
+    assert np.array_equal(vm_gpu.stones_finder.targets, vm_ora.stones_finder.targets)
+    assert c_gpu.kifu.to_sgf() == c_ora.kifu.to_sgf()
+    assert (c_gpu.get_stones() == c_ora.get_stones()).all()
+
+
+_REAL_CTX = None
+
+
+_REAL_CLS = None
+
+
+def _real(device=0):
+    """one shared real context (capi.Context is monkey-patched while the finders are built)"""
+    global _REAL_CTX
+    if _REAL_CTX is None:
+        _REAL_CTX = _REAL_CLS(device)
+    return _REAL_CTX
+
+
+def test_fast_file_pipeline_on_gpu(ck, synth):
+    """batch path: records from the HIP core folded in order == records from the oracle folded"""
+    from camkifu_amd import pipeline
+    from camkifu_amd.controller import ControllerHeadless
+    from .stub_ctx import OracleCtx
+    rng = np.random.default_rng(8)
+    corners = synth.random_corners(480, 640, rng)
+    stones = synth.random_stones(rng, density=0.3)
+    frames = np.stack([synth.render(480, 640, stones, corners, seed=300 + f).numpy() for f in range(12)])
+    W = synth.cnn_weights()
+    ck.cnn_set_weights(W)
+    octx = OracleCtx()
+    octx.cnn_set_weights(W)
+    outs = []
+    for ctx in (ck, octx):
+        ctrl = ControllerHeadless()
+        pipe = pipeline.FastFilePipeline(480, 640, ctrl, ctx=ctx)
+        e1 = pipe.process_batch(frames, len(frames))       # finds the board
+        e2 = pipe.process_batch(frames, len(frames))       # reads the stones with that transform
+        outs.append((pipe.board.mtx, ctrl.kifu.to_sgf(), [[repr(m) for m in mv] for mv in e1 + e2]))
+    assert outs[0][0] is not None and np.array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
