@@ -122,7 +122,7 @@ void ck_ctx_destroy(ck_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = { &ctx->in_stage, &ctx->in_stage2, &ctx->planes, &ctx->edges, &ctx->map, &ctx->labels,
-                       &ctx->labels2, &ctx->ghost, &ctx->misc, &ctx->comp, &ctx->pts, &ctx->accum, &ctx->peaks,
+                       &ctx->labels2, &ctx->ghost, &ctx->misc, &ctx->comp, &ctx->lists, &ctx->pts, &ctx->accum, &ctx->peaks,
                        &ctx->goban, &ctx->act0, &ctx->act1, &ctx->act2, &ctx->ybuf, &ctx->lblbuf, &ctx->confbuf,
                        &ctx->out_stage, &ctx->mats,
                        &ctx->cnn.c1w, &ctx->cnn.c1b, &ctx->cnn.c2w, &ctx->cnn.c2b, &ctx->cnn.c3w, &ctx->cnn.c3b,

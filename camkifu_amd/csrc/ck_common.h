@@ -59,6 +59,7 @@ struct ck_ctx {
     DevBuf ghost;        // n*h*w
     DevBuf misc;         // small per-frame counters
     DevBuf comp;         // per-frame component tables
+    DevBuf lists;        // per-frame edge / border pixel lists
     DevBuf pts;          // compacted border points
     DevBuf accum;        // hough accumulators
     DevBuf peaks;

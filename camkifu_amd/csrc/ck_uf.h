@@ -19,15 +19,44 @@ __device__ __forceinline__ int uf_find(const int* L, int a)
     return a;
 }
 
+// find with path compression: the start node is re-pointed at the root.  Only non-root nodes
+// are ever written with a plain store, and always with an ancestor of smaller index, so a
+// concurrent atomicMin on the same node still sees a valid (older or newer) ancestor.
+__device__ __forceinline__ int uf_find_compress(int* L, int a)
+{
+    const int start = a;
+    int p = uf_load(L, a);
+    const int first = p;
+    while (p != a) { a = p; p = uf_load(L, a); }
+    if (first != a && start != a)
+        __hip_atomic_store(L + start, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return a;
+}
+
 __device__ __forceinline__ void uf_union(int* L, int a, int b)
 {
     for (;;) {
-        a = uf_find(L, a);
-        b = uf_find(L, b);
+        a = uf_find_compress(L, a);
+        b = uf_find_compress(L, b);
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; }          // a > b: hook a under b
         const int old = atomicMin(L + a, b);
         if (old == a) return;                             // a was still a root: done
         a = old;                                          // somebody re-parented a meanwhile
     }
+}
+
+// Wave-aggregated append: every lane with `flag` gets a unique slot of a global list whose
+// element count lives at *counter.  One atomic per wave.  Returns the slot (or -1).
+__device__ __forceinline__ int wave_append(int* counter, bool flag)
+{
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(flag);
+    if (mask == 0) return -1;
+    const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int leader = __builtin_ctzll(mask);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __builtin_popcountll(mask));
+    base = __builtin_amdgcn_readlane(base, leader);
+    if (!flag) return -1;
+    return base + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
 }

@@ -19,7 +19,8 @@ constexpr int MW = TW + 2, MH = TH + 2;     // magnitude tile with 1-px halo
 
 __global__ __launch_bounds__(256) void canny_nms_kernel(const uint8_t* __restrict__ planes, int h, int w, int pitch,
                                                         int low, int high, uint8_t* __restrict__ map,
-                                                        int32_t* __restrict__ labels)
+                                                        int32_t* __restrict__ labels, int32_t* __restrict__ cand,
+                                                        int* __restrict__ cand_count)
 {
     __shared__ uint8_t px[3][LH][LW + 4];
     __shared__ int32_t mg[MH][MW + 1];       // mag | sector << 16
@@ -69,77 +70,93 @@ __global__ __launch_bounds__(256) void canny_nms_kernel(const uint8_t* __restric
     }
     __syncthreads();
 
-    for (int i = tid; i < TH * TW; i += 256) {
+    int* cnt = cand_count + f;
+    int32_t* clist = cand + (size_t)f * h * w;
+    for (int i = tid; i < TH * TW; i += 256) {          // TH*TW is a multiple of 256: wave-uniform trip count
         const int r = i / TW, col = i % TW;
         const int y = oy + r, x = ox + col;
-        if (y >= h || x >= w) continue;
-        const int32_t pk = mg[r + 1][col + 1];
-        const int m = pk & 0xFFFF, sector = pk >> 16;
+        const bool inside = y < h && x < w;
         bool keep = false;
-        if (m > low) {
-            if (sector == 0) keep = m > (mg[r + 1][col] & 0xFFFF) && m >= (mg[r + 1][col + 2] & 0xFFFF);
-            else if (sector == 1) keep = m > (mg[r][col + 1] & 0xFFFF) && m >= (mg[r + 2][col + 1] & 0xFFFF);
-            else {
-                const int s = sector == 3 ? -1 : 1;
-                keep = m > (mg[r][col + 1 - s] & 0xFFFF) && m > (mg[r + 2][col + 1 + s] & 0xFFFF);
+        int m = 0;
+        if (inside) {
+            const int32_t pk = mg[r + 1][col + 1];
+            m = pk & 0xFFFF;
+            const int sector = pk >> 16;
+            if (m > low) {
+                if (sector == 0) keep = m > (mg[r + 1][col] & 0xFFFF) && m >= (mg[r + 1][col + 2] & 0xFFFF);
+                else if (sector == 1) keep = m > (mg[r][col + 1] & 0xFFFF) && m >= (mg[r + 2][col + 1] & 0xFFFF);
+                else {
+                    const int s = sector == 3 ? -1 : 1;
+                    keep = m > (mg[r][col + 1 - s] & 0xFFFF) && m > (mg[r + 2][col + 1 + s] & 0xFFFF);
+                }
             }
+            const size_t idx = ((size_t)f * h + y) * w + x;
+            map[idx] = keep ? (m > high ? 2 : 0) : 1;
+            if (keep) labels[idx] = y * w + x;
         }
-        const size_t idx = ((size_t)f * h + y) * w + x;
-        map[idx] = keep ? (m > high ? 2 : 0) : 1;
-        if (keep) labels[idx] = y * w + x;
+        const int slot = wave_append(cnt, keep);
+        if (keep) clist[slot] = y * w + x;
     }
 }
+
+// The three hysteresis kernels walk the per-frame candidate list (a few % of the pixels)
+// with a fixed grid and a grid-stride loop; the count is read from device memory.
+constexpr int LIST_BLOCKS = 64;
 
 // link every candidate with its already-scanned 8-neighbours (W, N, and NW / NE only when
 // N is not itself a candidate -- otherwise the link is implied)
-__global__ void canny_link_kernel(const uint8_t* __restrict__ map, int h, int w, int32_t* __restrict__ labels)
+__global__ __launch_bounds__(256) void canny_link_kernel(const uint8_t* __restrict__ map, int h, int w,
+                                                         int32_t* __restrict__ labels, const int32_t* __restrict__ cand,
+                                                         const int* __restrict__ cand_count)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    const int f = blockIdx.z;
-    if (x >= w) return;
+    const int f = blockIdx.y;
+    const int n = cand_count[f];
     const uint8_t* m = map + (size_t)f * h * w;
     int32_t* L = labels + (size_t)f * h * w;
-    const int p = y * w + x;
-    if (m[p] == 1) return;
-    if (x > 0 && m[p - 1] != 1) uf_union(L, p, p - 1);
-    if (y > 0) {
-        if (m[p - w] != 1) uf_union(L, p, p - w);
-        else {
-            if (x > 0 && m[p - w - 1] != 1) uf_union(L, p, p - w - 1);
-            if (x < w - 1 && m[p - w + 1] != 1) uf_union(L, p, p - w + 1);
+    const int32_t* C = cand + (size_t)f * h * w;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += LIST_BLOCKS * 256) {
+        const int p = C[i];
+        const int y = p / w, x = p - y * w;
+        if (x > 0 && m[p - 1] != 1) uf_union(L, p, p - 1);
+        if (y > 0) {
+            if (m[p - w] != 1) uf_union(L, p, p - w);
+            else {
+                if (x > 0 && m[p - w - 1] != 1) uf_union(L, p, p - w - 1);
+                if (x < w - 1 && m[p - w + 1] != 1) uf_union(L, p, p - w + 1);
+            }
         }
     }
 }
 
-__global__ void canny_flatten_mark_kernel(const uint8_t* __restrict__ map, int h, int w,
-                                          int32_t* __restrict__ labels, uint8_t* __restrict__ edges)
+__global__ __launch_bounds__(256) void canny_flatten_mark_kernel(const uint8_t* __restrict__ map, int h, int w,
+                                                                 int32_t* __restrict__ labels, uint8_t* __restrict__ edges,
+                                                                 const int32_t* __restrict__ cand, const int* __restrict__ cand_count)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    const int f = blockIdx.z;
-    if (x >= w) return;
+    const int f = blockIdx.y;
+    const int n = cand_count[f];
     const size_t off = (size_t)f * h * w;
-    const int p = y * w + x;
-    const uint8_t v = map[off + p];
-    if (v == 1) return;
-    const int root = uf_find(labels + off, p);
-    labels[off + p] = root;
-    if (v == 2) edges[off + root] = 255;
+    const int32_t* C = cand + off;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += LIST_BLOCKS * 256) {
+        const int p = C[i];
+        const int root = uf_find(labels + off, p);
+        labels[off + p] = root;
+        if (map[off + p] == 2) edges[off + root] = 255;
+    }
 }
 
-__global__ void canny_final_kernel(const uint8_t* __restrict__ map, int h, int w,
-                                   const int32_t* __restrict__ labels, uint8_t* __restrict__ edges)
+__global__ __launch_bounds__(256) void canny_final_kernel(int h, int w, const int32_t* __restrict__ labels,
+                                                          uint8_t* __restrict__ edges, const int32_t* __restrict__ cand,
+                                                          const int* __restrict__ cand_count)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    const int f = blockIdx.z;
-    if (x >= w) return;
+    const int f = blockIdx.y;
+    const int n = cand_count[f];
     const size_t off = (size_t)f * h * w;
-    const int p = y * w + x;
-    if (map[off + p] == 1) return;
-    const int root = labels[off + p];
-    if (root != p) edges[off + p] = edges[off + root];
+    const int32_t* C = cand + off;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += LIST_BLOCKS * 256) {
+        const int p = C[i];
+        const int root = labels[off + p];
+        if (root != p) edges[off + p] = edges[off + root];
+    }
 }
 
 }  // namespace
@@ -149,20 +166,29 @@ int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, in
 {
     if (low > high) { int t = low; low = high; high = t; }
     const size_t npx = (size_t)n * h * w;
+    CK_TRY(ck_ensure(ctx, ctx->labels2, npx * 4));                 // candidate lists (one slab per frame)
+    CK_TRY(ck_ensure(ctx, ctx->misc, (size_t)n * 64 + 4096));
+    int32_t* d_cand = (int32_t*)ctx->labels2.p;
+    int* d_count = (int*)ctx->misc.p;
     {
         TimeScope ts(ctx, "canny_nms");
+        CK_HIP(ctx, hipMemsetAsync(d_count, 0, (size_t)n * 4, ctx->stream));
         dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, n);
-        hipLaunchKernelGGL(canny_nms_kernel, grid, dim3(256), 0, ctx->stream, d_planes, h, w, pitch, low, high, d_map, d_labels);
+        hipLaunchKernelGGL(canny_nms_kernel, grid, dim3(256), 0, ctx->stream, d_planes, h, w, pitch, low, high, d_map,
+                           d_labels, d_cand, d_count);
         CK_HIP(ctx, hipGetLastError());
     }
     if (d_map_out) CK_HIP(ctx, hipMemcpyAsync(d_map_out, d_map, npx, hipMemcpyDeviceToDevice, ctx->stream));
     {
         TimeScope ts(ctx, "canny_hyst");
         CK_HIP(ctx, hipMemsetAsync(d_edges, 0, npx, ctx->stream));
-        dim3 grid((w + 255) / 256, h, n);
-        hipLaunchKernelGGL(canny_link_kernel, grid, dim3(256), 0, ctx->stream, d_map, h, w, d_labels);
-        hipLaunchKernelGGL(canny_flatten_mark_kernel, grid, dim3(256), 0, ctx->stream, d_map, h, w, d_labels, d_edges);
-        hipLaunchKernelGGL(canny_final_kernel, grid, dim3(256), 0, ctx->stream, d_map, h, w, d_labels, d_edges);
+        dim3 grid(LIST_BLOCKS, n);
+        hipLaunchKernelGGL(canny_link_kernel, grid, dim3(256), 0, ctx->stream, (const uint8_t*)d_map, h, w, d_labels,
+                           (const int32_t*)d_cand, (const int*)d_count);
+        hipLaunchKernelGGL(canny_flatten_mark_kernel, grid, dim3(256), 0, ctx->stream, (const uint8_t*)d_map, h, w,
+                           d_labels, d_edges, (const int32_t*)d_cand, (const int*)d_count);
+        hipLaunchKernelGGL(canny_final_kernel, grid, dim3(256), 0, ctx->stream, h, w, (const int32_t*)d_labels, d_edges,
+                           (const int32_t*)d_cand, (const int*)d_count);
         CK_HIP(ctx, hipGetLastError());
     }
     return CK_OK;

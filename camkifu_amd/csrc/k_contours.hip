@@ -38,24 +38,31 @@ constexpr int PEAK_CAP = 1 << 14;       // Hough peaks per frame
 constexpr int NUMANGLE = 180;
 
 struct FrameTab {        // device-side per-frame counters
+    int n_edges;
+    int n_border;
     int n_roots;
     int n_hough_pts;
     int n_peaks;
     int overflow;
+    int pad0, pad1;
 };
 
-// ---- A. frame clearing + parent initialisation ------------------------------------------
+constexpr int LIST_BLOCKS = 48;          // grid-stride blocks per frame for the list kernels
+
+// ---- A. frame clearing + parent initialisation + edge list -----------------------------
 // one wave per image row; walks the row in 64-pixel segments carrying the position of the
-// last edge pixel seen so far
+// last edge pixel seen so far.  Dense pass: reads 1 B/px, writes 1 + 4 B/px.
 __global__ __launch_bounds__(256) void prep_rows_kernel(const uint8_t* __restrict__ edges, int h, int w,
-                                                        uint8_t* __restrict__ ez, int32_t* __restrict__ L)
+                                                        uint8_t* __restrict__ ez, int32_t* __restrict__ L,
+                                                        FrameTab* __restrict__ tab, int32_t* __restrict__ elist)
 {
     const int lane = threadIdx.x & 63;
     const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int f = blockIdx.y;
-    if (y >= h) return;
+    if (y >= h) return;                                  // whole wave leaves together
     const size_t off = ((size_t)f * h + y) * w;
     const bool row_inner = y > 0 && y < h - 1;
+    int32_t* E = elist + (size_t)f * h * w;
     int last_edge = -1;                       // wave-uniform
     for (int x0 = 0; x0 < w; x0 += 64) {
         const int x = x0 + lane;
@@ -73,46 +80,67 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const uint8_t* __restric
             }
             L[off + x] = parent;
         }
-        if (mask) last_edge = x0 + 63 - __builtin_clzll(mask);
+        if (mask) {
+            const int slot = wave_append(&tab[f].n_edges, e);
+            if (e) E[slot] = y * w + x;
+            last_edge = x0 + 63 - __builtin_clzll(mask);
+        }
     }
 }
 
-// ---- B. unions ---------------------------------------------------------------------------
-__global__ void link_kernel(const uint8_t* __restrict__ ez, int h, int w, int32_t* __restrict__ labels)
+// ---- B. unions: edge pixels (8-connectivity) and background runs (4-connectivity) -------
+// Work items: every edge pixel, plus one item per image row for the run that starts at x = 0.
+// A stretch of columns where this row and the row above are both background starts either at
+// x = 0 or right after an edge pixel of one of the two rows: one union per stretch.
+__global__ __launch_bounds__(256) void link_list_kernel(const uint8_t* __restrict__ ez, int h, int w,
+                                                        int32_t* __restrict__ labels, const FrameTab* __restrict__ tab,
+                                                        const int32_t* __restrict__ elist)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    const int f = blockIdx.z;
-    if (x >= w) return;
+    const int f = blockIdx.y;
+    const int ne = tab[f].n_edges;
     const uint8_t* e = ez + (size_t)f * h * w;
     int32_t* L = labels + (size_t)f * h * w;
-    const int p = y * w + x;
-    if (e[p]) {
-        if (e[p - 1]) uf_union(L, p, p - 1);          // frame is cleared: x >= 1, y >= 1 here
-        if (e[p - w]) uf_union(L, p, p - w);
-        else {
-            if (e[p - w - 1]) uf_union(L, p, p - w - 1);
-            if (e[p - w + 1]) uf_union(L, p, p - w + 1);
+    const int32_t* E = elist + (size_t)f * h * w;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ne + h - 1; i += LIST_BLOCKS * 256) {
+        if (i < ne) {
+            const int p = E[i];                        // 1 <= x <= w-2, 1 <= y <= h-2
+            if (e[p - 1]) uf_union(L, p, p - 1);
+            if (e[p - w]) uf_union(L, p, p - w);
+            else {
+                if (e[p - w - 1]) uf_union(L, p, p - w - 1);
+                if (e[p - w + 1]) uf_union(L, p, p - w + 1);
+            }
+            const int q1 = p + 1, q2 = p + w + 1;      // background stretches opening right of p
+            if (!e[q1] && !e[q1 - w]) uf_union(L, q1, q1 - w);
+            if (!e[q2] && !e[q2 - w]) uf_union(L, q2, q2 - w);
+        } else {
+            const int q = (i - ne + 1) * w;            // x = 0 of rows 1 .. h-1: always background
+            uf_union(L, q, q - w);
         }
-    } else if (y > 0 && !e[p - w]) {
-        // first column of a stretch where this row and the row above are both background
-        const bool first = x == 0 || e[p - 1] || e[p - w - 1];
-        if (first) uf_union(L, p, p - w);
     }
 }
 
-// ---- C. flatten nodes ----------------------------------------------------------------------
-__global__ void flatten_kernel(const uint8_t* __restrict__ ez, int h, int w, int32_t* __restrict__ labels)
+// ---- C. flatten the nodes that later lookups go through --------------------------------
+__global__ __launch_bounds__(256) void flatten_list_kernel(const uint8_t* __restrict__ ez, int h, int w,
+                                                           int32_t* __restrict__ labels, const FrameTab* __restrict__ tab,
+                                                           const int32_t* __restrict__ elist)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    const int f = blockIdx.z;
-    if (x >= w) return;
+    const int f = blockIdx.y;
+    const int ne = tab[f].n_edges;
     const size_t off = (size_t)f * h * w;
-    const int p = y * w + x;
-    const bool node = ez[off + p] || x == 0 || ez[off + p - 1];
-    if (!node) return;
-    labels[off + p] = uf_find(labels + off, p);
+    const uint8_t* e = ez + off;
+    int32_t* L = labels + off;
+    const int32_t* E = elist + off;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ne + h; i += LIST_BLOCKS * 256) {
+        if (i < ne) {
+            const int p = E[i];
+            L[p] = uf_find(L, p);
+            if (!e[p + 1]) L[p + 1] = uf_find(L, p + 1);       // head of the run right of p
+        } else {
+            const int q = (i - ne) * w;
+            L[q] = uf_find(L, q);
+        }
+    }
 }
 
 __device__ __forceinline__ bool in_s0(const int32_t* L, int q, int root0)
@@ -122,104 +150,120 @@ __device__ __forceinline__ bool in_s0(const int32_t* L, int q, int root0)
 }
 
 // ---- D. top-level roots -------------------------------------------------------------------
-__global__ void roots_kernel(const uint8_t* __restrict__ ez, int h, int w, const int32_t* __restrict__ labels,
-                             int32_t* __restrict__ compid, FrameTab* __restrict__ tab, int maxc,
-                             int32_t* __restrict__ roots, int32_t* __restrict__ aabb)
+__global__ __launch_bounds__(256) void roots_list_kernel(int h, int w, const int32_t* __restrict__ labels,
+                                                         int32_t* __restrict__ compid, FrameTab* __restrict__ tab, int maxc,
+                                                         int32_t* __restrict__ roots, int32_t* __restrict__ aabb,
+                                                         const int32_t* __restrict__ elist)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    const int f = blockIdx.z;
-    if (x >= w) return;
+    const int f = blockIdx.y;
+    const int ne = tab[f].n_edges;
     const size_t off = (size_t)f * h * w;
-    const int p = y * w + x;
-    if (!ez[off + p]) return;
     const int32_t* L = labels + off;
-    if (L[p] != p) return;
+    const int32_t* E = elist + off;
     const int root0 = L[0];
-    if (!in_s0(L, p - 1, root0)) return;        // west neighbour of a first pixel is background
-    const int slot = atomicAdd(&tab[f].n_roots, 1);
-    if (slot >= maxc) { tab[f].overflow = 1; compid[off + p] = -1; return; }
-    compid[off + p] = slot;
-    roots[(size_t)f * maxc + slot] = p;
-    int32_t* bb = aabb + ((size_t)f * maxc + slot) * 4;
-    bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ne; i += LIST_BLOCKS * 256) {
+        const int p = E[i];
+        if (L[p] != p) continue;
+        if (!in_s0(L, p - 1, root0)) continue;      // west neighbour of a first pixel is background
+        const int slot = atomicAdd(&tab[f].n_roots, 1);
+        if (slot >= maxc) { tab[f].overflow = 1; compid[off + p] = -1; continue; }
+        compid[off + p] = slot;
+        roots[(size_t)f * maxc + slot] = p;
+        int32_t* bb = aabb + ((size_t)f * maxc + slot) * 4;
+        bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1;
+    }
 }
 
-// ---- E. outer-border flags + bounding boxes ---------------------------------------------
-__global__ void border_kernel(const uint8_t* __restrict__ ez, int h, int w, const int32_t* __restrict__ labels,
-                              const int32_t* __restrict__ compid, int maxc, uint8_t* __restrict__ bflag,
-                              int32_t* __restrict__ aabb)
+// ---- E. outer-border list + bounding boxes ----------------------------------------------
+__global__ __launch_bounds__(256) void border_list_kernel(const uint8_t* __restrict__ ez, int h, int w,
+                                                          const int32_t* __restrict__ labels, const int32_t* __restrict__ compid,
+                                                          int maxc, FrameTab* __restrict__ tab, int32_t* __restrict__ aabb,
+                                                          const int32_t* __restrict__ elist, int32_t* __restrict__ blist)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    const int f = blockIdx.z;
-    if (x >= w) return;
+    const int f = blockIdx.y;
+    const int ne = tab[f].n_edges;
     const size_t off = (size_t)f * h * w;
-    const int p = y * w + x;
-    uint8_t flag = 0;
-    if (ez[off + p]) {
-        const uint8_t* e = ez + off;
-        const int32_t* L = labels + off;
-        const int root0 = L[0];
-        const bool b = (!e[p - 1] && in_s0(L, p - 1, root0)) || (!e[p + 1] && in_s0(L, p + 1, root0)) ||
-                       (!e[p - w] && in_s0(L, p - w, root0)) || (!e[p + w] && in_s0(L, p + w, root0));
-        if (b) {
-            const int slot = compid[off + L[p]];
-            if ((unsigned)slot < (unsigned)maxc) {
-                // a pixel in the middle of a straight run cannot be a hull vertex
-                const bool mid = (e[p - 1] && e[p + 1]) || (e[p - w] && e[p + w]) ||
-                                 (e[p - w - 1] && e[p + w + 1]) || (e[p - w + 1] && e[p + w - 1]);
-                flag = mid ? 1 : 3;
-                int32_t* bb = aabb + ((size_t)f * maxc + slot) * 4;
-                atomicMin(bb + 0, x); atomicMax(bb + 1, x);
-                atomicMin(bb + 2, y); atomicMax(bb + 3, y);
+    const uint8_t* e = ez + off;
+    const int32_t* L = labels + off;
+    const int32_t* E = elist + off;
+    int32_t* B = blist + off;
+    const int root0 = L[0];
+    const int trips = (ne + LIST_BLOCKS * 256 - 1) / (LIST_BLOCKS * 256);      // uniform trip count
+    for (int t = 0; t < trips; t++) {
+        const int i = t * LIST_BLOCKS * 256 + blockIdx.x * 256 + threadIdx.x;
+        bool b = false;
+        int p = 0;
+        if (i < ne) {
+            p = E[i];
+            b = (!e[p - 1] && in_s0(L, p - 1, root0)) || (!e[p + 1] && in_s0(L, p + 1, root0)) ||
+                (!e[p - w] && in_s0(L, p - w, root0)) || (!e[p + w] && in_s0(L, p + w, root0));
+            if (b) {
+                const int slot = compid[off + L[p]];
+                if ((unsigned)slot < (unsigned)maxc) {
+                    const int y = p / w, x = p - y * w;
+                    int32_t* bb = aabb + ((size_t)f * maxc + slot) * 4;
+                    atomicMin(bb + 0, x); atomicMax(bb + 1, x);
+                    atomicMin(bb + 2, y); atomicMax(bb + 3, y);
+                } else b = false;
             }
         }
+        const int slot = wave_append(&tab[f].n_border, b);
+        if (b) B[slot] = p;
     }
-    bflag[off + p] = flag;
+}
+
+// a border pixel in the middle of a straight run cannot be a hull vertex
+__device__ __forceinline__ bool mid_of_run(const uint8_t* e, int p, int w)
+{
+    return (e[p - 1] && e[p + 1]) || (e[p - w] && e[p + w]) ||
+           (e[p - w - 1] && e[p + w + 1]) || (e[p - w + 1] && e[p + w - 1]);
 }
 
 // ---- F. gather hull-candidate points of the components the host asked for ---------------
-__global__ void gather_points_kernel(const uint8_t* __restrict__ bflag, int h, int w, const int32_t* __restrict__ labels,
-                                     const int32_t* __restrict__ compid, int maxc, const uint8_t* __restrict__ want,
-                                     int32_t* __restrict__ counter, int cap, int32_t* __restrict__ pts /* x|y<<16, f<<17|slot */)
+__global__ __launch_bounds__(256) void gather_points_kernel(const uint8_t* __restrict__ ez, int h, int w,
+                                                            const int32_t* __restrict__ labels, const int32_t* __restrict__ compid,
+                                                            int maxc, const uint8_t* __restrict__ want, const FrameTab* __restrict__ tab,
+                                                            const int32_t* __restrict__ blist, int32_t* __restrict__ counter, int cap,
+                                                            int32_t* __restrict__ pts /* x|y<<16, slot ; then frame */)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    const int f = blockIdx.z;
-    if (x >= w) return;
+    const int f = blockIdx.y;
+    const int nb = tab[f].n_border;
     const size_t off = (size_t)f * h * w;
-    const int p = y * w + x;
-    if (bflag[off + p] != 3) return;
-    const int slot = compid[off + labels[off + p]];
-    if (!want[(size_t)f * maxc + slot]) return;
-    const int i = atomicAdd(counter, 1);
-    if (i >= cap) return;
-    pts[2 * (size_t)i] = x | (y << 16);
-    pts[2 * (size_t)i + 1] = slot;
-    pts[2 * (size_t)cap + i] = f;
+    const int32_t* B = blist + off;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nb; i += LIST_BLOCKS * 256) {
+        const int p = B[i];
+        const int slot = compid[off + labels[off + p]];
+        if (!want[(size_t)f * maxc + slot]) continue;
+        if (mid_of_run(ez + off, p, w)) continue;
+        const int k = atomicAdd(counter, 1);
+        if (k >= cap) continue;
+        const int y = p / w, x = p - y * w;
+        pts[2 * (size_t)k] = x | (y << 16);
+        pts[2 * (size_t)k + 1] = slot;
+        pts[2 * (size_t)cap + k] = f;
+    }
 }
 
 // ---- G. ghost image + Hough point list ------------------------------------------------------
-__global__ void ghost_kernel(const uint8_t* __restrict__ bflag, int h, int w, const int32_t* __restrict__ labels,
-                             const int32_t* __restrict__ compid, const int32_t* __restrict__ sel /* f*4: 3 slots + go */,
-                             FrameTab* __restrict__ tab, int pcap, uint32_t* __restrict__ hpts, uint8_t* __restrict__ ghost)
+__global__ __launch_bounds__(256) void ghost_list_kernel(int h, int w, const int32_t* __restrict__ labels,
+                                                         const int32_t* __restrict__ compid, const int32_t* __restrict__ sel,
+                                                         FrameTab* __restrict__ tab, const int32_t* __restrict__ blist, int pcap,
+                                                         uint32_t* __restrict__ hpts, uint8_t* __restrict__ ghost)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    const int f = blockIdx.z;
-    if (x >= w) return;
+    const int f = blockIdx.y;
+    if (!sel[f * 4 + 3]) return;
+    const int nb = tab[f].n_border;
     const size_t off = (size_t)f * h * w;
-    const int p = y * w + x;
-    bool on = false;
-    if (bflag[off + p] && sel[f * 4 + 3]) {
+    const int32_t* B = blist + off;
+    const int s0 = sel[f * 4], s1 = sel[f * 4 + 1], s2 = sel[f * 4 + 2];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nb; i += LIST_BLOCKS * 256) {
+        const int p = B[i];
         const int slot = compid[off + labels[off + p]];
-        on = slot == sel[f * 4] || slot == sel[f * 4 + 1] || slot == sel[f * 4 + 2];
-    }
-    if (ghost) ghost[off + p] = on ? 255 : 0;
-    if (on) {
-        const int i = atomicAdd(&tab[f].n_hough_pts, 1);
-        if (i < pcap) hpts[(size_t)f * pcap + i] = (uint32_t)x | ((uint32_t)y << 16);
+        if (slot != s0 && slot != s1 && slot != s2) continue;
+        if (ghost) ghost[off + p] = 255;
+        const int k = atomicAdd(&tab[f].n_hough_pts, 1);
+        const int y = p / w, x = p - y * w;
+        if (k < pcap) hpts[(size_t)f * pcap + k] = (uint32_t)x | ((uint32_t)y << 16);
         else tab[f].overflow = 1;
     }
 }
@@ -317,17 +361,18 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
     if (w > 65535 || h > 65535) return ck_fail(ctx, CK_ERR_ARG, "image side > 65535");
 
     CK_TRY(ck_ensure(ctx, ctx->ghost, npx));                       // ez
-    CK_TRY(ck_ensure(ctx, ctx->map, npx));                         // bflag
     CK_TRY(ck_ensure(ctx, ctx->labels, npx * 4));
     CK_TRY(ck_ensure(ctx, ctx->labels2, npx * 4));                 // compid (only read at roots)
+    CK_TRY(ck_ensure(ctx, ctx->lists, npx * 8));                   // edge list + border list
     const size_t tab_bytes = sizeof(FrameTab) * (size_t)n;
     const size_t sel_bytes = sizeof(int32_t) * 4 * (size_t)n;
     CK_TRY(ck_ensure(ctx, ctx->misc, tab_bytes + sel_bytes + 4 * NUMANGLE * 2 + 64));
     CK_TRY(ck_ensure(ctx, ctx->comp, (size_t)n * maxc * (4 + 16 + 1)));
     uint8_t* ez = (uint8_t*)ctx->ghost.p;
-    uint8_t* bflag = (uint8_t*)ctx->map.p;
     int32_t* L = (int32_t*)ctx->labels.p;
     int32_t* compid = (int32_t*)ctx->labels2.p;
+    int32_t* elist = (int32_t*)ctx->lists.p;
+    int32_t* blist = elist + npx;
     FrameTab* d_tab = (FrameTab*)ctx->misc.p;
     int32_t* d_sel = (int32_t*)((char*)ctx->misc.p + tab_bytes);
     float* d_trig = (float*)((char*)ctx->misc.p + tab_bytes + sel_bytes);
@@ -335,42 +380,52 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
     int32_t* d_aabb = d_roots + (size_t)n * maxc;
     uint8_t* d_want = (uint8_t*)(d_aabb + (size_t)n * maxc * 4);
 
-    const dim3 pgrid((w + 255) / 256, h, n), pblock(256);
+    const dim3 lgrid(LIST_BLOCKS, n), lblock(256);
     {
         TimeScope ts(ctx, "ccl");
         CK_HIP(ctx, hipMemsetAsync(d_tab, 0, tab_bytes, ctx->stream));
-        hipLaunchKernelGGL(prep_rows_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L);
-        hipLaunchKernelGGL(link_kernel, pgrid, pblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L);
-        hipLaunchKernelGGL(flatten_kernel, pgrid, pblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L);
-        hipLaunchKernelGGL(roots_kernel, pgrid, pblock, 0, ctx->stream, (const uint8_t*)ez, h, w, (const int32_t*)L,
-                           compid, d_tab, maxc, d_roots, d_aabb);
-        hipLaunchKernelGGL(border_kernel, pgrid, pblock, 0, ctx->stream, (const uint8_t*)ez, h, w, (const int32_t*)L,
-                           (const int32_t*)compid, maxc, bflag, d_aabb);
+        hipLaunchKernelGGL(prep_rows_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
+        hipLaunchKernelGGL(link_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
+                           (const FrameTab*)d_tab, (const int32_t*)elist);
+        hipLaunchKernelGGL(flatten_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
+                           (const FrameTab*)d_tab, (const int32_t*)elist);
+        hipLaunchKernelGGL(roots_list_kernel, lgrid, lblock, 0, ctx->stream, h, w, (const int32_t*)L, compid, d_tab, maxc,
+                           d_roots, d_aabb, (const int32_t*)elist);
+        hipLaunchKernelGGL(border_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, (const int32_t*)L,
+                           (const int32_t*)compid, maxc, d_tab, d_aabb, (const int32_t*)elist, blist);
         CK_HIP(ctx, hipGetLastError());
     }
 
-    // ---- host: component tables -------------------------------------------------------------
+    // ---- host: component tables (one strided copy each) -------------------------------------
     std::vector<FrameTab> tab((size_t)n);
     CK_HIP(ctx, hipMemcpyAsync(tab.data(), d_tab, tab_bytes, hipMemcpyDeviceToHost, ctx->stream));
     CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int f = 0; f < n; f++)
+    int nc_max = 0;
+    for (int f = 0; f < n; f++) {
         if (tab[f].overflow) return ck_fail(ctx, CK_ERR_CAPACITY, "frame %d: more than %d external contours", f, maxc);
+        nc_max = std::max(nc_max, tab[f].n_roots);
+    }
     std::vector<std::vector<Comp>> comps((size_t)n);
     {
-        std::vector<int32_t> hroots, haabb;
+        std::vector<int32_t> hroots((size_t)n * nc_max), haabb((size_t)n * nc_max * 4);
+        if (nc_max) {
+            CK_HIP(ctx, hipMemcpy2DAsync(hroots.data(), (size_t)nc_max * 4, d_roots, (size_t)maxc * 4, (size_t)nc_max * 4, n,
+                                         hipMemcpyDeviceToHost, ctx->stream));
+            CK_HIP(ctx, hipMemcpy2DAsync(haabb.data(), (size_t)nc_max * 16, d_aabb, (size_t)maxc * 16, (size_t)nc_max * 16, n,
+                                         hipMemcpyDeviceToHost, ctx->stream));
+            CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
         for (int f = 0; f < n; f++) {
             const int nc = tab[f].n_roots;
             res[f].status = nc == 0 ? CK_BOARD_NO_CONTOUR : CK_BOARD_LINES;
             res[f].n_contours = nc; res[f].n_lines = 0; res[f].reserved = 0; res[f].biggest_area = 0;
-            if (!nc) continue;
-            hroots.resize((size_t)nc); haabb.resize((size_t)nc * 4);
-            CK_HIP(ctx, hipMemcpy(hroots.data(), d_roots + (size_t)f * maxc, (size_t)nc * 4, hipMemcpyDeviceToHost));
-            CK_HIP(ctx, hipMemcpy(haabb.data(), d_aabb + (size_t)f * maxc * 4, (size_t)nc * 16, hipMemcpyDeviceToHost));
             auto& cv = comps[f];
             cv.resize((size_t)nc);
+            const int32_t* hr = hroots.data() + (size_t)f * nc_max;
+            const int32_t* hb = haabb.data() + (size_t)f * nc_max * 4;
             for (int s = 0; s < nc; s++) {
-                const double dx = (double)haabb[4 * s + 1] - haabb[4 * s], dy = (double)haabb[4 * s + 3] - haabb[4 * s + 2];
-                cv[s] = { hroots[s], s, dx * dy, 0.0, dx * dy == 0.0 };
+                const double dx = (double)hb[4 * s + 1] - hb[4 * s], dy = (double)hb[4 * s + 3] - hb[4 * s + 2];
+                cv[s] = { hr[s], s, dx * dy, 0.0, dx * dy == 0.0 };
             }
         }
     }
@@ -380,7 +435,7 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
     CK_TRY(ck_ensure(ctx, ctx->pts, (size_t)gcap * 12 + 64));
     int32_t* d_pts = (int32_t*)ctx->pts.p;
     int32_t* d_counter = d_pts + (size_t)gcap * 3;
-    std::vector<uint8_t> want((size_t)n * maxc);
+    std::vector<uint8_t> want((size_t)n * std::max(nc_max, 1));
     auto third_best = [](const std::vector<Comp>& cv) {
         double b[3] = { -1, -1, -1 };
         for (const Comp& c : cv) if (c.known) {
@@ -389,32 +444,35 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         }
         return b[2];          // -1 while fewer than three areas are known
     };
-    for (int round = 0; round < 3; round++) {
+    for (int round = 0; round < 3 && nc_max > 0; round++) {
         bool any = false;
         std::fill(want.begin(), want.end(), 0);
         for (int f = 0; f < n; f++) {
             auto& cv = comps[f];
             if (cv.empty()) continue;
+            uint8_t* wf = want.data() + (size_t)f * nc_max;
             if (round == 0) {
                 std::vector<int> idx;
                 for (int s = 0; s < (int)cv.size(); s++) if (!cv[s].known) idx.push_back(s);
                 const int k = std::min<int>(16, (int)idx.size());
                 std::partial_sort(idx.begin(), idx.begin() + k, idx.end(), [&](int a, int b) { return cv[a].ub > cv[b].ub; });
-                for (int i = 0; i < k; i++) { want[(size_t)f * maxc + idx[i]] = 1; any = true; }
+                for (int i = 0; i < k; i++) { wf[idx[i]] = 1; any = true; }
             } else {
                 const double third = third_best(cv);
                 for (auto& c : cv)
-                    if (!c.known && c.ub * (1.0 + 1e-5) >= third) { want[(size_t)f * maxc + c.slot] = 1; any = true; }
+                    if (!c.known && c.ub * (1.0 + 1e-5) >= third) { wf[c.slot] = 1; any = true; }
             }
         }
         if (!any) break;
         if (round == 2) return ck_fail(ctx, CK_ERR_STATE, "contour selection did not converge");
         {
             TimeScope ts(ctx, "contour_gather");
-            CK_HIP(ctx, hipMemcpyAsync(d_want, want.data(), want.size(), hipMemcpyHostToDevice, ctx->stream));
+            CK_HIP(ctx, hipMemcpy2DAsync(d_want, (size_t)maxc, want.data(), (size_t)nc_max, (size_t)nc_max, n,
+                                         hipMemcpyHostToDevice, ctx->stream));
             CK_HIP(ctx, hipMemsetAsync(d_counter, 0, 4, ctx->stream));
-            hipLaunchKernelGGL(gather_points_kernel, pgrid, pblock, 0, ctx->stream, (const uint8_t*)bflag, h, w,
-                               (const int32_t*)L, (const int32_t*)compid, maxc, (const uint8_t*)d_want, d_counter, gcap, d_pts);
+            hipLaunchKernelGGL(gather_points_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w,
+                               (const int32_t*)L, (const int32_t*)compid, maxc, (const uint8_t*)d_want,
+                               (const FrameTab*)d_tab, (const int32_t*)blist, d_counter, gcap, d_pts);
             CK_HIP(ctx, hipGetLastError());
         }
         int npts = 0;
@@ -423,8 +481,9 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         if (npts > gcap) return ck_fail(ctx, CK_ERR_CAPACITY, "too many contour points (%d > %d)", npts, gcap);
         std::vector<int32_t> hp((size_t)npts * 2), hf((size_t)npts);
         if (npts) {
-            CK_HIP(ctx, hipMemcpy(hp.data(), d_pts, (size_t)npts * 8, hipMemcpyDeviceToHost));
-            CK_HIP(ctx, hipMemcpy(hf.data(), d_pts + (size_t)gcap * 2, (size_t)npts * 4, hipMemcpyDeviceToHost));
+            CK_HIP(ctx, hipMemcpyAsync(hp.data(), d_pts, (size_t)npts * 8, hipMemcpyDeviceToHost, ctx->stream));
+            CK_HIP(ctx, hipMemcpyAsync(hf.data(), d_pts + (size_t)gcap * 2, (size_t)npts * 4, hipMemcpyDeviceToHost, ctx->stream));
+            CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
         // bucket by (frame, slot)
         std::vector<std::vector<std::vector<int32_t>>> bucket((size_t)n);
@@ -437,7 +496,7 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         parallel_for(n, [&](int f) {
             auto& cv = comps[f];
             for (size_t s = 0; s < cv.size(); s++) {
-                if (!want[(size_t)f * maxc + s]) continue;
+                if (!want[(size_t)f * nc_max + s]) continue;
                 float wh[2];
                 ck_min_area_rect(bucket[f][s].data(), (int)(bucket[f][s].size() / 2), wh);
                 cv[s].area = (double)wh[0] * (double)wh[1];
@@ -448,6 +507,7 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
 
     // ---- selection: bisect.insort order = (area ascending, discovery order descending) ------
     std::vector<int32_t> sel((size_t)n * 4, -1);
+    bool any_go = false;
     for (int f = 0; f < n; f++) {
         auto& cv = comps[f];
         sel[(size_t)f * 4 + 3] = 0;
@@ -463,7 +523,10 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         if (!(frame_area / 3 < known[0]->area)) { res[f].status = CK_BOARD_TOO_SMALL; continue; }
         for (int i = 0; i < 3 && i < (int)known.size(); i++) sel[(size_t)f * 4 + i] = known[i]->slot;
         sel[(size_t)f * 4 + 3] = 1;
+        any_go = true;
     }
+    if (d_ghost_out) CK_HIP(ctx, hipMemsetAsync(d_ghost_out, 0, npx, ctx->stream));
+    if (!any_go) return CK_OK;
 
     // ---- ghost, Hough --------------------------------------------------------------------------
     std::vector<float> trig(2 * NUMANGLE);
@@ -484,8 +547,8 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         TimeScope ts(ctx, "ghost");
         CK_HIP(ctx, hipMemcpyAsync(d_sel, sel.data(), sel_bytes, hipMemcpyHostToDevice, ctx->stream));
         CK_HIP(ctx, hipMemcpyAsync(d_trig, trig.data(), trig.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(ghost_kernel, pgrid, pblock, 0, ctx->stream, (const uint8_t*)bflag, h, w, (const int32_t*)L,
-                           (const int32_t*)compid, (const int32_t*)d_sel, d_tab, pcap, d_hpts, d_ghost_out);
+        hipLaunchKernelGGL(ghost_list_kernel, lgrid, lblock, 0, ctx->stream, h, w, (const int32_t*)L, (const int32_t*)compid,
+                           (const int32_t*)d_sel, d_tab, (const int32_t*)blist, pcap, d_hpts, d_ghost_out);
         CK_HIP(ctx, hipGetLastError());
     }
     {
@@ -508,25 +571,33 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
     }
     CK_HIP(ctx, hipMemcpyAsync(tab.data(), d_tab, tab_bytes, hipMemcpyDeviceToHost, ctx->stream));
     CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<int32_t> pk;
+    int np_max = 0;
     for (int f = 0; f < n; f++) {
         if (tab[f].overflow) return ck_fail(ctx, CK_ERR_CAPACITY, "frame %d: Hough point/peak capacity exceeded", f);
+        if (res[f].status == CK_BOARD_LINES) np_max = std::max(np_max, tab[f].n_peaks);
+    }
+    if (!np_max) return CK_OK;
+    std::vector<int32_t> pk((size_t)n * np_max * 2);
+    CK_HIP(ctx, hipMemcpy2DAsync(pk.data(), (size_t)np_max * 8, d_peaks, (size_t)PEAK_CAP * 8, (size_t)np_max * 8, n,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const float theta = (float)(3.1415926535897932384626433832795 / 180);
+    const double scale = 1. / (numrho + 2);
+    std::vector<int> order;
+    for (int f = 0; f < n; f++) {
         if (res[f].status != CK_BOARD_LINES) continue;
         const int np = tab[f].n_peaks;
         res[f].n_lines = np;
         if (!np) continue;
-        pk.resize((size_t)np * 2);
-        CK_HIP(ctx, hipMemcpy(pk.data(), d_peaks + (size_t)f * PEAK_CAP * 2, (size_t)np * 8, hipMemcpyDeviceToHost));
-        std::vector<int> order((size_t)np);
+        const int32_t* pf = pk.data() + (size_t)f * np_max * 2;
+        order.resize((size_t)np);
         for (int i = 0; i < np; i++) order[i] = i;
         std::sort(order.begin(), order.end(), [&](int a, int b) {
-            if (pk[2 * a + 1] != pk[2 * b + 1]) return pk[2 * a + 1] > pk[2 * b + 1];
-            return pk[2 * a] < pk[2 * b];
+            if (pf[2 * a + 1] != pf[2 * b + 1]) return pf[2 * a + 1] > pf[2 * b + 1];
+            return pf[2 * a] < pf[2 * b];
         });
-        const float theta = (float)(3.1415926535897932384626433832795 / 180);
-        const double scale = 1. / (numrho + 2);
         for (int i = 0; i < np && i < cap; i++) {
-            const int idx = pk[2 * order[i]];
+            const int idx = pf[2 * order[i]];
             const int nn = (int)floor(idx * scale) - 1;
             const int rr = idx - (nn + 1) * (numrho + 2) - 1;
             lines[((size_t)f * cap + i) * 2] = (rr - (numrho - 1) * 0.5f) * 1.f;

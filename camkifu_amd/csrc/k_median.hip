@@ -26,10 +26,12 @@ constexpr int HIN = HOUT + 14;        // input rows per lane
 constexpr int TILE_W = 48;            // valid output columns per wave
 constexpr int TILE_H = 4 * HOUT;      // output rows per wave
 
-__device__ __forceinline__ uint32_t lane_right(uint32_t v, int k)
+template <int K>
+__device__ __forceinline__ uint32_t lane_right(uint32_t v)
 {
-    // value held by the lane k places to the right inside the 16-lane row
-    return (uint32_t)__shfl_down((int)v, k, 16);
+    // value held by the lane K places to the right inside the 16-lane DPP row (row_shl:K);
+    // lanes shifted in from beyond the row read 0.  A VALU move, no LDS crossbar traffic.
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + K, 0xf, 0xf, true);
 }
 
 __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t nbytes)
@@ -41,11 +43,11 @@ __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t
 // sum_{k=0..14} V[4*lx + i + k]
 __device__ __forceinline__ uint32_t hsum15(uint32_t w)
 {
-    uint32_t s1 = w + alignbyte(lane_right(w, 1), w, 1);             // pairs
-    uint32_t s2 = s1 + alignbyte(lane_right(s1, 1), s1, 2);          // 4
-    uint32_t s3 = s2 + lane_right(s2, 1);                            // 8
-    uint32_t t14 = alignbyte(lane_right(w, 4), lane_right(w, 3), 2); // element +14
-    return s3 + lane_right(s2, 2) + lane_right(s1, 3) + t14;         // 8 + 4 + 2 + 1
+    uint32_t s1 = w + alignbyte(lane_right<1>(w), w, 1);               // pairs
+    uint32_t s2 = s1 + alignbyte(lane_right<1>(s1), s1, 2);            // 4
+    uint32_t s3 = s2 + lane_right<1>(s2);                              // 8
+    uint32_t t14 = alignbyte(lane_right<4>(w), lane_right<3>(w), 2);   // element +14
+    return s3 + lane_right<2>(s2) + lane_right<3>(s1) + t14;           // 8 + 4 + 2 + 1
 }
 
 struct Set256 {
