@@ -14,7 +14,8 @@
 namespace {
 
 constexpr int TW = 64, TH = 16;
-constexpr int LW = TW + 4, LH = TH + 4;     // pixel tile with 2-px halo
+constexpr int LH = TH + 4;                   // pixel tile rows (2-px halo)
+constexpr int LWD = TW / 4 + 2;              // pixel tile dwords per row (4-px halo each side)
 constexpr int MW = TW + 2, MH = TH + 2;     // magnitude tile with 1-px halo
 
 __global__ __launch_bounds__(256) void canny_nms_kernel(const uint8_t* __restrict__ planes, int h, int w, int pitch,
@@ -22,21 +23,28 @@ __global__ __launch_bounds__(256) void canny_nms_kernel(const uint8_t* __restric
                                                         int32_t* __restrict__ labels, int32_t* __restrict__ cand,
                                                         int* __restrict__ cand_count)
 {
-    __shared__ uint8_t px[3][LH][LW + 4];
+    // pixel tile: columns ox-4 .. ox+67 (18 aligned dwords per row), rows oy-2 .. oy+17
+    __shared__ uint32_t pxw[3][LH][LWD];
     __shared__ int32_t mg[MH][MW + 1];       // mag | sector << 16
+    __shared__ int32_t cbuf[TH * TW];        // candidates of this tile
+    __shared__ int ccount, cbase;
     const int f = blockIdx.z;
     const int ox = blockIdx.x * TW, oy = blockIdx.y * TH;
     const int tid = threadIdx.x;
     const uint8_t* base = planes + (size_t)f * 3 * h * pitch;
+    if (tid == 0) ccount = 0;
 
-    for (int i = tid; i < 3 * LH * LW; i += 256) {
-        const int c = i / (LH * LW), r = (i / LW) % LH, col = i % LW;
-        int y = oy - 2 + r, x = ox - 2 + col;
+    for (int i = tid; i < 3 * LH * LWD; i += 256) {
+        const int c = i / (LH * LWD), r = (i / LWD) % LH, cd = i % LWD;
+        int y = oy - 2 + r;
         y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-        x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
-        px[c][r][col] = base[((size_t)c * h + y) * pitch + x];
+        const int x = ox - 4 + 4 * cd;                 // pitch is a multiple of 64 and ox of 64: aligned
+        uint32_t v = 0;
+        if (x >= 0 && x < pitch) v = *reinterpret_cast<const uint32_t*>(base + ((size_t)c * h + y) * pitch + x);
+        pxw[c][r][cd] = v;
     }
     __syncthreads();
+    const uint8_t (*px)[LH][LWD * 4] = reinterpret_cast<const uint8_t (*)[LH][LWD * 4]>(pxw);
 
     const int TG22 = 13573;   // (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
     for (int i = tid; i < MH * MW; i += 256) {
@@ -44,9 +52,9 @@ __global__ __launch_bounds__(256) void canny_nms_kernel(const uint8_t* __restric
         const int y = oy - 1 + r, x = ox - 1 + col;
         int32_t packed = 0;                       // outside the image the magnitude is 0
         if (y >= 0 && y < h && x >= 0 && x < w) {
-            // Sobel taps use replicate border relative to the IMAGE, so re-clamp here
+            // Sobel taps use replicate border relative to the IMAGE: clamp, then index the tile
             const int r0 = (y - 1 < 0 ? 0 : y - 1) - (oy - 2), r1 = y - (oy - 2), r2 = (y + 1 > h - 1 ? h - 1 : y + 1) - (oy - 2);
-            const int c0 = (x - 1 < 0 ? 0 : x - 1) - (ox - 2), c1 = x - (ox - 2), c2 = (x + 1 > w - 1 ? w - 1 : x + 1) - (ox - 2);
+            const int c0 = (x - 1 < 0 ? 0 : x - 1) - (ox - 4), c1 = x - (ox - 4), c2 = (x + 1 > w - 1 ? w - 1 : x + 1) - (ox - 4);
             int best = -1, bdx = 0, bdy = 0;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -70,33 +78,59 @@ __global__ __launch_bounds__(256) void canny_nms_kernel(const uint8_t* __restric
     }
     __syncthreads();
 
-    int* cnt = cand_count + f;
-    int32_t* clist = cand + (size_t)f * h * w;
-    for (int i = tid; i < TH * TW; i += 256) {          // TH*TW is a multiple of 256: wave-uniform trip count
-        const int r = i / TW, col = i % TW;
-        const int y = oy + r, x = ox + col;
-        const bool inside = y < h && x < w;
-        bool keep = false;
-        int m = 0;
-        if (inside) {
-            const int32_t pk = mg[r + 1][col + 1];
-            m = pk & 0xFFFF;
-            const int sector = pk >> 16;
-            if (m > low) {
-                if (sector == 0) keep = m > (mg[r + 1][col] & 0xFFFF) && m >= (mg[r + 1][col + 2] & 0xFFFF);
-                else if (sector == 1) keep = m > (mg[r][col + 1] & 0xFFFF) && m >= (mg[r + 2][col + 1] & 0xFFFF);
-                else {
-                    const int s = sector == 3 ? -1 : 1;
-                    keep = m > (mg[r][col + 1 - s] & 0xFFFF) && m > (mg[r + 2][col + 1 + s] & 0xFFFF);
+    // NMS: one thread = 4 consecutive pixels of one row (one dword of the map)
+    {
+        const int r = tid >> 4, col0 = (tid & 15) * 4;
+        const int y = oy + r;
+        uint32_t mapw = 0x01010101u;
+        int keepmask = 0;
+        if (y < h) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int col = col0 + k, x = ox + col;
+                if (x >= w) continue;
+                const int32_t pk = mg[r + 1][col + 1];
+                const int m = pk & 0xFFFF, sector = pk >> 16;
+                bool keep = false;
+                if (m > low) {
+                    if (sector == 0) keep = m > (mg[r + 1][col] & 0xFFFF) && m >= (mg[r + 1][col + 2] & 0xFFFF);
+                    else if (sector == 1) keep = m > (mg[r][col + 1] & 0xFFFF) && m >= (mg[r + 2][col + 1] & 0xFFFF);
+                    else {
+                        const int s = sector == 3 ? -1 : 1;
+                        keep = m > (mg[r][col + 1 - s] & 0xFFFF) && m > (mg[r + 2][col + 1 + s] & 0xFFFF);
+                    }
+                }
+                if (keep) {
+                    const uint32_t v = m > high ? 2u : 0u;
+                    mapw = (mapw & ~(0xFFu << (8 * k))) | (v << (8 * k));
+                    keepmask |= 1 << k;
                 }
             }
-            const size_t idx = ((size_t)f * h + y) * w + x;
-            map[idx] = keep ? (m > high ? 2 : 0) : 1;
-            if (keep) labels[idx] = y * w + x;
+            const int x0 = ox + col0;
+            const size_t idx = ((size_t)f * h + y) * w + x0;
+            if (x0 + 3 < w && ((idx & 3) == 0)) *reinterpret_cast<uint32_t*>(map + idx) = mapw;
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (x0 + k < w) map[idx + k] = (uint8_t)(mapw >> (8 * k));
+            }
         }
-        const int slot = wave_append(cnt, keep);
-        if (keep) clist[slot] = y * w + x;
+        const int nk = __builtin_popcount(keepmask);
+        int slot = nk ? atomicAdd(&ccount, nk) : 0;
+        if (nk) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (keepmask & (1 << k)) {
+                    const int p = y * w + ox + col0 + k;
+                    labels[(size_t)f * h * w + p] = p;
+                    cbuf[slot++] = p;
+                }
+        }
     }
+    __syncthreads();
+    if (tid == 0) cbase = ccount ? atomicAdd(cand_count + f, ccount) : 0;
+    __syncthreads();
+    int32_t* clist = cand + (size_t)f * h * w + cbase;
+    for (int i = tid; i < ccount; i += 256) clist[i] = cbuf[i];
 }
 
 // The three hysteresis kernels walk the per-frame candidate list (a few % of the pixels)

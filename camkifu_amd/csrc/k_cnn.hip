@@ -219,11 +219,9 @@ __global__ __launch_bounds__(64) void fc1_mfma_f32_kernel(const float* __restric
     }
 }
 
-// dense 160 -> 81, softmax, argmax/base-3 decode and confidence.  One wave per patch.
-__global__ __launch_bounds__(64) void fc2_softmax_decode_kernel(const float* __restrict__ h1, const float* __restrict__ w,
-                                                                const float* __restrict__ bias, float* __restrict__ y,
-                                                                uint8_t* __restrict__ labels, double* __restrict__ conf,
-                                                                int npatch)
+// dense 160 -> 81 and softmax.  One wave per patch.
+__global__ __launch_bounds__(64) void fc2_softmax_kernel(const float* __restrict__ h1, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int npatch)
 {
 #pragma clang fp contract(off)
     __shared__ float lg[96];
@@ -248,68 +246,42 @@ __global__ __launch_bounds__(64) void fc2_softmax_decode_kernel(const float* __r
         ex[o] = v;
         y[(size_t)patch * 81 + o] = v;
     }
-    __syncthreads();
-    if (lane == 0) {
-        int label = 0;
-        double s = 0.0;
-        for (int k = 0; k < 81; k++) {
-            if (ex[k] > ex[label]) label = k;       // first maximum, like np.argmax
-            s += (double)ex[k];                      // python sum(): float64, index order
-        }
-        const double cf = (double)ex[label] / s;
-        const int frame = patch / 100, reg = patch % 100;
-        const int i = reg / 10, j = reg % 10;
-        const int rs = i == 9 ? 17 : 2 * i, cs = j == 9 ? 17 : 2 * j;
-        int kk = label;
-        const int d3 = kk / 27; kk %= 27;
-        const int d2 = kk / 9; kk %= 9;
-        const int d1 = kk / 3;
-        const int d0 = kk % 3;
-        const int dg[4] = { d0, d1, d2, d3 };
-        uint8_t* L = labels + (size_t)frame * 361;
-        double* C = conf + (size_t)frame * 361;
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            const int r = rs + d / 2, c = cs + d % 2;
-            L[r * 19 + c] = (uint8_t)dg[d];
-            C[r * 19 + c] = cf;
-        }
-    }
 }
 
 }  // namespace
 
-// Regions are decoded by independent waves, but NNCache.predict_all_stones writes them in
-// (i, j) raster order, so where the last region overlaps its neighbour (rows/cols 17) the
-// LATER region must win.  Regions 9 overlap regions 8 on intersection row/col 17 only; the
-// decode kernel is therefore launched twice: first regions with i<9 and j<9, then the rest
-// in an order-preserving second pass (see k_cnn_predict).
+// K12 decode, one workgroup per frame.  NNCache.predict_all_stones writes the 100 regions in
+// (i, j) raster order, so where region 9 overlaps region 8 (intersection row / column 17) the
+// later region wins: cell (r, c) takes its value from region (I(r), I(c)) with I(17) = I(18) = 9.
 namespace {
-__global__ __launch_bounds__(64) void decode_fix_kernel(const float* __restrict__ y, uint8_t* __restrict__ labels,
-                                                        double* __restrict__ conf, int nframes)
+__global__ __launch_bounds__(128) void decode_kernel(const float* __restrict__ y, uint8_t* __restrict__ labels,
+                                                     double* __restrict__ conf, int nframes)
 {
-    // one thread per frame re-applies regions in raster order for the overlapping band
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int lab[100];
+    __shared__ double cf[100];
+    const int f = blockIdx.x, t = threadIdx.x;
     if (f >= nframes) return;
-    for (int reg = 0; reg < 100; reg++) {
-        const int i = reg / 10, j = reg % 10;
-        if (i < 8 && j < 8) continue;              // cannot touch row/col 17
-        const float* yy = y + ((size_t)f * 100 + reg) * 81;
+    if (t < 100) {
+        const float* yy = y + ((size_t)f * 100 + t) * 81;
         int label = 0;
         double s = 0.0;
-        for (int k = 0; k < 81; k++) { if (yy[k] > yy[label]) label = k; s += (double)yy[k]; }
-        const double cf = (double)yy[label] / s;
-        const int rs = i == 9 ? 17 : 2 * i, cs = j == 9 ? 17 : 2 * j;
-        int kk = label;
-        const int d3 = kk / 27; kk %= 27;
-        const int d2 = kk / 9; kk %= 9;
-        const int d1 = kk / 3, d0 = kk % 3;
-        const int dg[4] = { d0, d1, d2, d3 };
-        for (int d = 0; d < 4; d++) {
-            const int r = rs + d / 2, c = cs + d % 2;
-            labels[(size_t)f * 361 + r * 19 + c] = (uint8_t)dg[d];
-            conf[(size_t)f * 361 + r * 19 + c] = cf;
+        for (int k = 0; k < 81; k++) {
+            if (yy[k] > yy[label]) label = k;       // first maximum, like np.argmax
+            s += (double)yy[k];                      // python sum(): float64, index order
         }
+        lab[t] = label;
+        cf[t] = (double)yy[label] / s;
+    }
+    __syncthreads();
+    for (int cell = t; cell < 361; cell += 128) {
+        const int r = cell / 19, c = cell % 19;
+        const int i = r >= 17 ? 9 : r / 2, j = c >= 17 ? 9 : c / 2;
+        const int rs = i == 9 ? 17 : 2 * i, cs = j == 9 ? 17 : 2 * j;
+        const int d = (r - rs) * 2 + (c - cs);       // base-3 digit index (compute_stones)
+        int kk = lab[i * 10 + j];
+        for (int q = 0; q < d; q++) kk /= 3;
+        labels[(size_t)f * 361 + cell] = (uint8_t)(kk % 3);
+        conf[(size_t)f * 361 + cell] = cf[i * 10 + j];
     }
 }
 }  // namespace
@@ -358,22 +330,24 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
 
 int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, uint8_t* d_labels, double* d_conf)
 {
-    // frames are processed in chunks so the activation scratch stays bounded
+    // convolutions run in chunks of frames so the activation scratch stays bounded; the dense
+    // tail runs once over the whole batch (its 32-patch MFMA tiles need many waves in flight)
     const int CHUNK = 32;
-    const size_t a1_sz = (size_t)CHUNK * 100 * 36 * 36 * 32 * 4;      // conv1 out, later conv3 out
+    const size_t a1_sz = (size_t)CHUNK * 100 * 36 * 36 * 32 * 4;      // conv1 out (36*36*32), later conv3 out (14*14*90)
     const size_t p2_sz = (size_t)CHUNK * 100 * 12 * 12 * 90 * 4;      // conv2+pool out (16*16*32), later conv4 out (12*12*90)
     CK_TRY(ck_ensure(ctx, ctx->act0, a1_sz));
     CK_TRY(ck_ensure(ctx, ctx->act1, p2_sz));
-    CK_TRY(ck_ensure(ctx, ctx->act2, (size_t)CHUNK * 100 * (3240 + 160) * 4));
+    CK_TRY(ck_ensure(ctx, ctx->act2, (size_t)nframes * 100 * (3240 + 160) * 4));
     float* a1 = (float*)ctx->act0.p;
     float* p2 = (float*)ctx->act1.p;
-    float* p4 = (float*)ctx->act2.p;
-    float* h1 = p4 + (size_t)CHUNK * 100 * 3240;
+    float* p4_all = (float*)ctx->act2.p;
+    float* h1 = p4_all + (size_t)nframes * 100 * 3240;
     const CnnWeights& W = ctx->cnn;
     for (int f0 = 0; f0 < nframes; f0 += CHUNK) {
         const int nf = nframes - f0 < CHUNK ? nframes - f0 : CHUNK;
         const int np = nf * 100;
         const uint8_t* gob = d_goban + (size_t)f0 * 380 * 380 * 3;
+        float* p4 = p4_all + (size_t)f0 * 100 * 3240;
         {
             TimeScope ts(ctx, "cnn_conv1");
             // 41 M tiles: 4 groups of (4 waves x 3 tiles)
@@ -398,21 +372,20 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             TimeScope ts(ctx, "cnn_conv4");
             hipLaunchKernelGGL((conv_mfma_f32_kernel<14, 14, 90, 3, 3, 90, 5, 1, false, false>), dim3(np, 1), dim3(192), 0,
                                ctx->stream, (const void*)a3, (const float*)W.c4w.p, (const float*)W.c4b.p, a4);
-        }
-        {
-            TimeScope ts(ctx, "cnn_tail");
             const size_t total = (size_t)np * 6 * 6 * 90;
             hipLaunchKernelGGL(pool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const float*)a4, 12, 12, 90, p4, total);
-            hipLaunchKernelGGL(fc1_mfma_f32_kernel, dim3((np + 31) / 32, 5), dim3(64), 0, ctx->stream,
-                               (const float*)p4, (const float*)W.d1w.p, (const float*)W.d1b.p, h1, np);
-            hipLaunchKernelGGL(fc2_softmax_decode_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float*)h1,
-                               (const float*)W.d2w.p, (const float*)W.d2b.p, d_y + (size_t)f0 * 8100,
-                               d_labels + (size_t)f0 * 361, d_conf + (size_t)f0 * 361, np);
-            hipLaunchKernelGGL(decode_fix_kernel, dim3((nf + 63) / 64), dim3(64), 0, ctx->stream,
-                               (const float*)(d_y + (size_t)f0 * 8100), d_labels + (size_t)f0 * 361,
-                               d_conf + (size_t)f0 * 361, nf);
         }
+        CK_HIP(ctx, hipGetLastError());
+    }
+    {
+        TimeScope ts(ctx, "cnn_tail");
+        const int np = nframes * 100;
+        hipLaunchKernelGGL(fc1_mfma_f32_kernel, dim3((np + 31) / 32, 5), dim3(64), 0, ctx->stream,
+                           (const float*)p4_all, (const float*)W.d1w.p, (const float*)W.d1b.p, h1, np);
+        hipLaunchKernelGGL(fc2_softmax_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float*)h1,
+                           (const float*)W.d2w.p, (const float*)W.d2b.p, d_y, np);
+        hipLaunchKernelGGL(decode_kernel, dim3(nframes), dim3(128), 0, ctx->stream, (const float*)d_y, d_labels, d_conf, nframes);
         CK_HIP(ctx, hipGetLastError());
     }
     return CK_OK;

@@ -88,6 +88,68 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const uint8_t* __restric
     }
 }
 
+// Same as above for w % 4 == 0: a lane owns 4 consecutive pixels (one dword of the edge map),
+// a wave covers 256 pixels per step; 4 ballots give every edge pixel its list slot.
+__global__ __launch_bounds__(256) void prep_rows4_kernel(const uint8_t* __restrict__ edges, int h, int w,
+                                                         uint8_t* __restrict__ ez, int32_t* __restrict__ L,
+                                                         FrameTab* __restrict__ tab, int32_t* __restrict__ elist)
+{
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int f = blockIdx.y;
+    if (y >= h) return;                                  // whole wave leaves together
+    const size_t off = ((size_t)f * h + y) * w;
+    const bool row_inner = y > 0 && y < h - 1;
+    int32_t* E = elist + (size_t)f * h * w;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int last_edge = -1;                       // wave-uniform: last edge column of earlier steps
+    for (int x0 = 0; x0 < w; x0 += 256) {
+        const int x = x0 + 4 * lane;
+        uint32_t v = 0;
+        if (x < w && row_inner) v = *reinterpret_cast<const uint32_t*>(edges + off + x);
+        int nib = ((v & 0xFFu) ? 1 : 0) | ((v & 0xFF00u) ? 2 : 0) | ((v & 0xFF0000u) ? 4 : 0) | ((v & 0xFF000000u) ? 8 : 0);
+        if (x == 0) nib &= ~1;                           // cleared frame: first and last column
+        if (x + 3 == w - 1) nib &= ~8;
+        const unsigned long long has = __builtin_amdgcn_ballot_w64(nib != 0);
+        // column of the last edge pixel in lanes before this one (or in earlier steps)
+        const int my_last = nib ? x + 31 - __builtin_clz((unsigned)nib) : -1;
+        const unsigned long long below = has & lt;
+        const int src = below ? 63 - __builtin_clzll(below) : 0;
+        int prev_last = __shfl(my_last, src);
+        if (!below) prev_last = last_edge;
+        if (x < w) {
+            *reinterpret_cast<uint32_t*>(ez + off + x) =
+                (nib & 1 ? 1u : 0u) | (nib & 2 ? 0x100u : 0u) | (nib & 4 ? 0x10000u : 0u) | (nib & 8 ? 0x1000000u : 0u);
+            int4 par;
+            int le = prev_last;
+            par.x = (nib & 1) ? y * w + x : y * w + le + 1;
+            if (nib & 1) le = x;
+            par.y = (nib & 2) ? y * w + x + 1 : y * w + le + 1;
+            if (nib & 2) le = x + 1;
+            par.z = (nib & 4) ? y * w + x + 2 : y * w + le + 1;
+            if (nib & 4) le = x + 2;
+            par.w = (nib & 8) ? y * w + x + 3 : y * w + le + 1;
+            *reinterpret_cast<int4*>(L + off + x) = par;
+        }
+        if (has) {
+            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(nib & 1), b1 = __builtin_amdgcn_ballot_w64(nib & 2);
+            const unsigned long long b2 = __builtin_amdgcn_ballot_w64(nib & 4), b3 = __builtin_amdgcn_ballot_w64(nib & 8);
+            const int total = __builtin_popcountll(b0) + __builtin_popcountll(b1) + __builtin_popcountll(b2) + __builtin_popcountll(b3);
+            const int leader = __builtin_ctzll(has);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&tab[f].n_edges, total);
+            base = __builtin_amdgcn_readlane(base, leader);
+            int slot = base + __builtin_popcountll(b0 & lt) + __builtin_popcountll(b1 & lt) +
+                       __builtin_popcountll(b2 & lt) + __builtin_popcountll(b3 & lt);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (nib & (1 << k)) E[slot++] = y * w + x + k;
+            const int hl = 63 - __builtin_clzll(has);
+            last_edge = __shfl(my_last, hl);
+        }
+    }
+}
+
 // ---- B. unions: edge pixels (8-connectivity) and background runs (4-connectivity) -------
 // Work items: every edge pixel, plus one item per image row for the run that starts at x = 0.
 // A stretch of columns where this row and the row above are both background starts either at
@@ -384,7 +446,11 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
     {
         TimeScope ts(ctx, "ccl");
         CK_HIP(ctx, hipMemsetAsync(d_tab, 0, tab_bytes, ctx->stream));
-        hipLaunchKernelGGL(prep_rows_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
+        // the dword path needs 4-byte aligned rows: w % 4 == 0 and an aligned base pointer
+        if ((w & 3) == 0 && ((uintptr_t)d_edges & 3) == 0)
+            hipLaunchKernelGGL(prep_rows4_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
+        else
+            hipLaunchKernelGGL(prep_rows_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
         hipLaunchKernelGGL(link_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
                            (const FrameTab*)d_tab, (const int32_t*)elist);
         hipLaunchKernelGGL(flatten_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
