@@ -13,7 +13,13 @@
 // Everything else (pooling, 160->81 dense, softmax, base-3 decode) is byte/float VALU work.
 #include <math.h>
 
+#include <type_traits>
+
 #include "ck_common.h"
+
+#ifndef UNROLL_CC
+#define UNROLL_CC 16
+#endif
 
 #pragma clang fp contract(off)
 
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(64 * WAVES_M * cdiv(COUT, 32)) void conv_mfma_f32_k
 
     // ---- stage the input rows this workgroup needs ---------------------------------------
     constexpr int NTHREADS = 64 * WAVES_M * NT;
-    if (U8IN) {
+    if constexpr (U8IN) {
         const uint8_t* g = (const uint8_t*)in_;
         const int frame = patch / 100, reg = patch % 100;
         const int py0 = region_origin(reg / 10), px0 = region_origin(reg % 10);
@@ -95,17 +101,25 @@ __global__ __launch_bounds__(64 * WAVES_M * cdiv(COUT, 32)) void conv_mfma_f32_k
         for (int e = 0; e < 16; e++) acc[r][e] = 0.f;
 
     const float* wcol = wc + wn * 32 + l31;
-    if (tile0 * 32 < M) {
+    // number of real (non-padding) M tiles of this wave: wave-uniform; the K loop is
+    // instantiated per count so the MFMA stream stays branch-free
+    constexpr int MT = cdiv(M, 32);
+    int nv = MT - tile0;
+    nv = nv > R ? R : nv;
+    auto k_loop = [&](auto nv_tag) {
+        constexpr int NV = decltype(nv_tag)::value;
         if constexpr (CIN % 2 == 0) {
+#pragma unroll
             for (int i = 0; i < KH; i++) {
+#pragma unroll
                 for (int j = 0; j < KW; j++) {
                     const int aoff = (i * W + j) * CS + hi;
                     const float* wrow = wcol + (size_t)((i * KW + j) * CIN + hi) * COUTP;
-#pragma unroll 8
+#pragma unroll UNROLL_CC
                     for (int cc = 0; cc < CIN / 2; cc++) {
                         const float b = wrow[(size_t)(2 * cc) * COUTP];
 #pragma unroll
-                        for (int r = 0; r < R; r++) {
+                        for (int r = 0; r < NV; r++) {
                             const float a = lds[abase[r] + aoff + 2 * cc];
                             acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[r], 0, 0, 0);
                         }
@@ -122,12 +136,20 @@ __global__ __launch_bounds__(64 * WAVES_M * cdiv(COUT, 32)) void conv_mfma_f32_k
                 const int aoff = live ? (i * W + j) * CS + c : 0;
                 const float b = wcol[(size_t)k * COUTP];
 #pragma unroll
-                for (int r = 0; r < R; r++) {
+                for (int r = 0; r < NV; r++) {
                     float a = lds[abase[r] + aoff];
                     a = live ? a : 0.f;
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[r], 0, 0, 0);
                 }
             }
+        }
+    };
+    if (nv >= R) k_loop(std::integral_constant<int, R>{});
+    else if constexpr (R > 1) {
+        if (nv == R - 1) k_loop(std::integral_constant<int, R - 1>{});
+        else if constexpr (R > 2) {
+            if (nv == R - 2) k_loop(std::integral_constant<int, R - 2>{});
+            else if constexpr (R > 3) { if (nv == R - 3) k_loop(std::integral_constant<int, R - 3>{}); }
         }
     }
 
@@ -363,8 +385,8 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         float* a3 = a1;
         {
             TimeScope ts(ctx, "cnn_conv3");
-            // 7 M tiles x 3 N tiles: one wave per N tile, 7 tiles register-blocked
-            hipLaunchKernelGGL((conv_mfma_f32_kernel<16, 16, 32, 3, 3, 90, 7, 1, false, false>), dim3(np, 1), dim3(192), 0,
+            // 7 M tiles x 3 N tiles: 6 waves = (4 + 3 tiles) x 3 N tiles
+            hipLaunchKernelGGL((conv_mfma_f32_kernel<16, 16, 32, 3, 3, 90, 4, 2, false, false>), dim3(np, 1), dim3(384), 0,
                                ctx->stream, (const void*)p2, (const float*)W.c3w.p, (const float*)W.c3b.p, a3);
         }
         float* a4 = p2;
