@@ -29,6 +29,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// float -> bf16, round to nearest even (activations are finite)
+__host__ __device__ __forceinline__ uint16_t f2bf(float f)
+{
+    union { float f; uint32_t u; } x;
+    x.f = f;
+    return (uint16_t)((x.u + 0x7FFFu + ((x.u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h)
+{
+    union { float f; uint32_t u; } x;
+    x.u = (uint32_t)h << 16;
+    return x.f;
+}
+
 // region index -> first pixel row/col of its 40x40 patch (nn_manager.py:92-126, 256-275)
 __device__ __forceinline__ int region_origin(int i) { return i == 9 ? 340 : 40 * i; }
 
@@ -40,7 +54,7 @@ __device__ __forceinline__ int region_origin(int i) { return i == 9 ? 340 : 40 *
 //   out: [patch][OH*OW or pooled][COUT] f32
 // Work split: blockIdx.x = patch, blockIdx.y = group of WAVES_M*R consecutive M tiles;
 // wave (wm, wn) owns R M-tiles x one 32-wide N tile.
-template <int H, int W, int CIN, int KH, int KW, int COUT, int R, int WAVES_M, bool U8IN, bool POOL>
+template <int H, int W, int CIN, int KH, int KW, int COUT, int R, int WAVES_M, bool U8IN, bool POOL, bool OUTBF = false>
 __global__ __launch_bounds__(64 * WAVES_M * cdiv(COUT, 32)) void conv_mfma_f32_kernel(
     const void* __restrict__ in_, const float* __restrict__ wc, const float* __restrict__ bias,
     float* __restrict__ out)
@@ -184,9 +198,187 @@ __global__ __launch_bounds__(64 * WAVES_M * cdiv(COUT, 32)) void conv_mfma_f32_k
                 const int m = (tile0 + r) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
                 float v = acc[r][e] + bv;
                 v = v > 0.f ? v : 0.f;
-                if (m < M && co < COUT) o[(size_t)m * COUT + co] = v;
+                if (m < M && co < COUT) {
+                    if constexpr (OUTBF) reinterpret_cast<uint16_t*>(out)[((size_t)patch * M + m) * COUT + co] = f2bf(v);
+                    else o[(size_t)m * COUT + co] = v;
+                }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 mode (CK_CNN_BF16): same implicit GEMM on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
+//   in : [patch][H][W][CINP] bf16, CINP a multiple of 16 (padding channels are zero)
+//   wt : [COUTS][KH*KW*CINP] bf16 -- one contiguous K vector per output channel, so a lane's
+//        B fragment (8 consecutive k of one column) is a single 16-byte load
+//   out: [patch][pixels][COUTS] bf16 (channels >= COUT written as zero)
+// LDS pixel stride is CINP + 8 elements: 16-byte fragments of 16 consecutive pixels land on
+// disjoint 4-bank groups (conflict-free ds_read_b128).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int H, int W, int CINP, int KH, int KW, int COUT, int COUTS, int R, int WAVES_M, bool POOL>
+__global__ __launch_bounds__(64 * WAVES_M * (COUTS / 32)) void conv_mfma_bf16_kernel(
+    const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt, const float* __restrict__ bias,
+    uint16_t* __restrict__ out)
+{
+    constexpr int OH = H - KH + 1, OW = W - KW + 1, M = OH * OW;
+    constexpr int NT = COUTS / 32, KP = KH * KW * CINP;
+    constexpr int CP = CINP + 8;
+    constexpr int TILES_WG = WAVES_M * R;
+    constexpr int ROWS = (TILES_WG * 32 + OW - 2) / OW + 1 + KH - 1;
+    constexpr int ROWS_C = ROWS < H ? ROWS : H;
+    __shared__ __attribute__((aligned(16))) uint16_t lds[ROWS_C * W * CP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NT, wn = wave % NT;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int patch = blockIdx.x;
+    const int m_wg0 = blockIdx.y * TILES_WG * 32;
+    const int oy_min = m_wg0 / OW;
+    int row_cnt = H - oy_min;
+    if (row_cnt > ROWS_C) row_cnt = ROWS_C;
+    constexpr int NTHREADS = 64 * WAVES_M * NT;
+    {
+        constexpr int CH8 = CINP / 8;
+        const uint4* g = reinterpret_cast<const uint4*>(in + ((size_t)patch * H + oy_min) * W * CINP);
+        const int total = row_cnt * W * CH8;
+#pragma unroll 4
+        for (int i = tid; i < total; i += NTHREADS) {
+            const int pxl = i / CH8, ch = i % CH8;
+            *reinterpret_cast<uint4*>(&lds[pxl * CP + ch * 8]) = g[i];
+        }
+    }
+    __syncthreads();
+
+    int abase[R];
+    const int tile0 = (blockIdx.y * WAVES_M + wm) * R;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int m = (tile0 + r) * 32 + l31;
+        if (m > M - 1) m = M - 1;
+        const int oy = m / OW, ox = m % OW;
+        abase[r] = ((oy - oy_min) * W + ox) * CP + 8 * hi;
+    }
+    f32x16 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[r][e] = 0.f;
+
+    constexpr int MT = cdiv(M, 32);
+    int nv = MT - tile0;
+    nv = nv > R ? R : nv;
+    const uint16_t* wrow0 = wt + (size_t)(wn * 32 + l31) * KP + 8 * hi;
+    auto k_loop = [&](auto nv_tag) {
+        constexpr int NV = decltype(nv_tag)::value;
+#pragma unroll
+        for (int i = 0; i < KH; i++) {
+#pragma unroll
+            for (int j = 0; j < KW; j++) {
+#pragma unroll
+                for (int c16 = 0; c16 < CINP / 16; c16++) {
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wrow0 + (i * KW + j) * CINP + c16 * 16));
+#pragma unroll
+                    for (int r = 0; r < NV; r++) {
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&lds[abase[r] + (i * W + j) * CP + c16 * 16]));
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    if (nv >= R) k_loop(std::integral_constant<int, R>{});
+    else if constexpr (R > 1) {
+        if (nv == R - 1) k_loop(std::integral_constant<int, R - 1>{});
+        else if constexpr (R > 2) {
+            if (nv == R - 2) k_loop(std::integral_constant<int, R - 2>{});
+            else if constexpr (R > 3) { if (nv == R - 3) k_loop(std::integral_constant<int, R - 3>{}); }
+        }
+    }
+
+    const int co = wn * 32 + l31;
+    const float bv = co < COUT ? bias[co] : 0.f;
+    if constexpr (POOL) {
+        static_assert(!POOL || (OW == 32 && R % 2 == 0), "fused pooling needs one tile per output row");
+        constexpr int PW = OW / 2;
+        uint16_t* o = out + (size_t)patch * (OH / 2) * PW * COUTS;
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            const int oy = tile0 + r;
+            if (oy >= OH) continue;
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const int ox = (e & 3) + 8 * (e >> 2) + 4 * hi;
+                float v0 = acc[r][e] + bv, v1 = acc[r][e + 1] + bv;
+                float v2 = acc[r + 1][e] + bv, v3 = acc[r + 1][e + 1] + bv;
+                float mx = v0 > v1 ? v0 : v1; mx = mx > v2 ? mx : v2; mx = mx > v3 ? mx : v3;
+                mx = mx > 0.f ? mx : 0.f;
+                o[((size_t)(oy / 2) * PW + ox / 2) * COUTS + co] = co < COUT ? f2bf(mx) : (uint16_t)0;
+            }
+        }
+    } else {
+        uint16_t* o = out + (size_t)patch * M * COUTS;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int m = (tile0 + r) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                float v = acc[r][e] + bv;
+                v = v > 0.f ? v : 0.f;
+                if (m < M) o[(size_t)m * COUTS + co] = co < COUT ? f2bf(v) : (uint16_t)0;
+            }
+        }
+    }
+}
+
+// 2x2 max pool on bf16, channels-last
+__global__ void pool2_bf16_kernel(const uint16_t* __restrict__ in, int H, int W, int C, uint16_t* __restrict__ out, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int OW = W / 2, OH = H / 2;
+    const int c = (int)(i % C);
+    const int x = (int)((i / C) % OW);
+    const int y = (int)((i / ((size_t)C * OW)) % OH);
+    const size_t p = i / ((size_t)C * OW * OH);
+    const uint16_t* b = in + ((p * H + 2 * y) * W + 2 * x) * C + c;
+    // non-negative bf16 values order like their bit patterns
+    uint16_t m = b[0];
+    uint16_t v = b[C]; m = m > v ? m : v;
+    v = b[(size_t)W * C]; m = m > v ? m : v;
+    v = b[(size_t)W * C + C]; m = m > v ? m : v;
+    out[i] = m;
+}
+
+// dense 3456(=36 px x 96 padded channels) -> 160 + relu, bf16 operands: one wave = 32 patches x 32 outputs
+__global__ __launch_bounds__(64) void fc1_mfma_bf16_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int npatch)
+{
+    constexpr int KIN = 3456, NOUT = 160;
+    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    const int p0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    int p = p0 + l31;
+    if (p > npatch - 1) p = npatch - 1;
+    const uint16_t* xa = x + (size_t)p * KIN + 8 * hi;
+    const uint16_t* wb = wt + (size_t)(n0 + l31) * KIN + 8 * hi;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < KIN / 16; s++) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + 16 * s));
+        const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wb + 16 * s));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+    const int co = n0 + l31;
+    const float bv = bias[co];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int pp = p0 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        float v = acc[e] + bv;
+        v = v > 0.f ? v : 0.f;
+        if (pp < npatch) out[(size_t)pp * NOUT + co] = v;
     }
 }
 
@@ -346,6 +538,31 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
     CK_TRY(up(ctx->cnn.c3b, host[5])); CK_TRY(up(ctx->cnn.c4b, host[7]));
     CK_TRY(up(ctx->cnn.d1w, host[8])); CK_TRY(up(ctx->cnn.d1b, host[9]));
     CK_TRY(up(ctx->cnn.d2w, host[10])); CK_TRY(up(ctx->cnn.d2b, host[11]));
+    // bf16 packs: [cout padded][kh*kw*cin padded], flip applied, padding rows / channels zero
+    auto pack_bf = [&](const float* k, int KH, int KW, int CIN, int CINP, int COUT, int COUTS, DevBuf& dst) -> int {
+        std::vector<uint16_t> v((size_t)COUTS * KH * KW * CINP, 0);
+        for (int o = 0; o < COUT; o++)
+            for (int i = 0; i < KH; i++)
+                for (int j = 0; j < KW; j++)
+                    for (int c = 0; c < CIN; c++)
+                        v[(size_t)o * KH * KW * CINP + (i * KW + j) * CINP + c] =
+                            f2bf(k[(((size_t)(KH - 1 - i) * KW + (KW - 1 - j)) * CIN + c) * COUT + o]);
+        CK_TRY(ck_ensure(ctx, dst, v.size() * 2));
+        CK_HIP(ctx, hipMemcpy(dst.p, v.data(), v.size() * 2, hipMemcpyHostToDevice));
+        return CK_OK;
+    };
+    CK_TRY(pack_bf(host[2].data(), 5, 5, 32, 32, 32, 32, ctx->cnn.c2w_bf));
+    CK_TRY(pack_bf(host[4].data(), 3, 3, 32, 32, 90, 96, ctx->cnn.c3w_bf));
+    CK_TRY(pack_bf(host[6].data(), 3, 3, 90, 96, 90, 96, ctx->cnn.c4w_bf));
+    {
+        std::vector<uint16_t> v((size_t)160 * 3456, 0);
+        for (int o = 0; o < 160; o++)
+            for (int px = 0; px < 36; px++)
+                for (int c = 0; c < 90; c++)
+                    v[(size_t)o * 3456 + px * 96 + c] = f2bf(host[8][(size_t)(px * 90 + c) * 160 + o]);
+        CK_TRY(ck_ensure(ctx, ctx->cnn.d1w_bf, v.size() * 2));
+        CK_HIP(ctx, hipMemcpy(ctx->cnn.d1w_bf.p, v.data(), v.size() * 2, hipMemcpyHostToDevice));
+    }
     ctx->cnn.set = true;
     return CK_OK;
 }
@@ -365,6 +582,55 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
     float* p4_all = (float*)ctx->act2.p;
     float* h1 = p4_all + (size_t)nframes * 100 * 3240;
     const CnnWeights& W = ctx->cnn;
+    if (ctx->cnn_mode == CK_CNN_BF16) {
+        // conv1 stays on the f32 MFMA (K = 75 is tiny; u8 pixels and f32 weights are exact) but
+        // writes bf16; conv2..4 and the first dense layer run v_mfma_f32_32x32x16_bf16
+        uint16_t* b1 = (uint16_t*)ctx->act0.p;           // conv1 out 36*36*32, later conv3 out 14*14*96
+        uint16_t* b2 = (uint16_t*)ctx->act1.p;           // conv2+pool out 16*16*32, later conv4 out 12*12*96
+        uint16_t* q4_all = (uint16_t*)ctx->act2.p;       // pooled conv4 out, all frames: 36*96
+        float* hb = (float*)(q4_all + (((size_t)nframes * 100 * 3456 + 7) & ~(size_t)7));
+        for (int f0 = 0; f0 < nframes; f0 += CHUNK) {
+            const int nf = nframes - f0 < CHUNK ? nframes - f0 : CHUNK;
+            const int np = nf * 100;
+            const uint8_t* gob = d_goban + (size_t)f0 * 380 * 380 * 3;
+            uint16_t* q4 = q4_all + (size_t)f0 * 100 * 3456;
+            {
+                TimeScope ts(ctx, "cnn_conv1");
+                hipLaunchKernelGGL((conv_mfma_f32_kernel<40, 40, 3, 5, 5, 32, 3, 4, true, false, true>), dim3(np, 4), dim3(256), 0,
+                                   ctx->stream, (const void*)gob, (const float*)W.c1w.p, (const float*)W.c1b.p, (float*)b1);
+            }
+            {
+                TimeScope ts(ctx, "cnn_conv2");
+                hipLaunchKernelGGL((conv_mfma_bf16_kernel<36, 36, 32, 5, 5, 32, 32, 2, 4, true>), dim3(np, 4), dim3(256), 0,
+                                   ctx->stream, (const uint16_t*)b1, (const uint16_t*)W.c2w_bf.p, (const float*)W.c2b.p, b2);
+            }
+            uint16_t* b3 = b1;
+            {
+                TimeScope ts(ctx, "cnn_conv3");
+                hipLaunchKernelGGL((conv_mfma_bf16_kernel<16, 16, 32, 3, 3, 90, 96, 4, 2, false>), dim3(np, 1), dim3(384), 0,
+                                   ctx->stream, (const uint16_t*)b2, (const uint16_t*)W.c3w_bf.p, (const float*)W.c3b.p, b3);
+            }
+            uint16_t* b4 = b2;
+            {
+                TimeScope ts(ctx, "cnn_conv4");
+                hipLaunchKernelGGL((conv_mfma_bf16_kernel<14, 14, 96, 3, 3, 90, 96, 3, 2, false>), dim3(np, 1), dim3(384), 0,
+                                   ctx->stream, (const uint16_t*)b3, (const uint16_t*)W.c4w_bf.p, (const float*)W.c4b.p, b4);
+                const size_t total = (size_t)np * 6 * 6 * 96;
+                hipLaunchKernelGGL(pool2_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   (const uint16_t*)b4, 12, 12, 96, q4, total);
+            }
+            CK_HIP(ctx, hipGetLastError());
+        }
+        TimeScope ts(ctx, "cnn_tail");
+        const int np = nframes * 100;
+        hipLaunchKernelGGL(fc1_mfma_bf16_kernel, dim3((np + 31) / 32, 5), dim3(64), 0, ctx->stream,
+                           (const uint16_t*)q4_all, (const uint16_t*)W.d1w_bf.p, (const float*)W.d1b.p, hb, np);
+        hipLaunchKernelGGL(fc2_softmax_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float*)hb,
+                           (const float*)W.d2w.p, (const float*)W.d2b.p, d_y, np);
+        hipLaunchKernelGGL(decode_kernel, dim3(nframes), dim3(128), 0, ctx->stream, (const float*)d_y, d_labels, d_conf, nframes);
+        CK_HIP(ctx, hipGetLastError());
+        return CK_OK;
+    }
     for (int f0 = 0; f0 < nframes; f0 += CHUNK) {
         const int nf = nframes - f0 < CHUNK ? nframes - f0 : CHUNK;
         const int np = nf * 100;

@@ -315,3 +315,28 @@ def test_fast_file_pipeline_on_gpu(ck, synth):
         outs.append((pipe.board.mtx, ctrl.kifu.to_sgf(), [[repr(m) for m in mv] for mv in e1 + e2]))
     assert outs[0][0] is not None and np.array_equal(outs[0][0], outs[1][0])
     assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+
+
+def test_cnn_bf16_mode_close_to_fp32(ck, ora, synth):
+    """bf16 MFMA mode (BASELINE config 5): not bit-exact by construction (8-bit mantissas), so the
+    bar is agreement of the decoded labels and a loose bound on the softmax outputs"""
+    from camkifu_amd import capi
+    from camkifu_amd.stone.nn_manager import NNManager
+    W = NNManager.init_net()
+    ck.cnn_set_weights(W)
+    gobans = []
+    dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
+    for seed in range(6):
+        sc = synth.scene(480, 640, seed=40 + seed, density=0.1 + 0.08 * seed)
+        gobans.append(ora.warp_perspective(sc["frame"].numpy(), ora.get_perspective_transform(sc["corners"], dst)))
+    gobans = np.stack(gobans)
+    y32, l32, c32 = ck.cnn_predict(gobans)
+    ck.cnn_set_mode(capi.CK_CNN_BF16)
+    try:
+        y16, l16, c16 = ck.cnn_predict(gobans)
+    finally:
+        ck.cnn_set_mode(capi.CK_CNN_FP32)
+    agree = float((l32 == l16).mean())
+    print("bf16 vs fp32: label agreement %.5f, max |dy| %.4f" % (agree, float(np.abs(y32 - y16).max())))
+    assert agree >= 0.99
+    assert np.abs(y32 - y16).max() < 0.25
