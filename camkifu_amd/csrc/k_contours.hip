@@ -254,24 +254,69 @@ __global__ __launch_bounds__(256) void border_list_kernel(const uint8_t* __restr
     for (int t = 0; t < trips; t++) {
         const int i = t * LIST_BLOCKS * 256 + blockIdx.x * 256 + threadIdx.x;
         bool b = false;
-        int p = 0;
+        int p = 0, cslot = -1;
         if (i < ne) {
             p = E[i];
             b = (!e[p - 1] && in_s0(L, p - 1, root0)) || (!e[p + 1] && in_s0(L, p + 1, root0)) ||
                 (!e[p - w] && in_s0(L, p - w, root0)) || (!e[p + w] && in_s0(L, p + w, root0));
             if (b) {
-                const int slot = compid[off + L[p]];
-                if ((unsigned)slot < (unsigned)maxc) {
-                    const int y = p / w, x = p - y * w;
-                    int32_t* bb = aabb + ((size_t)f * maxc + slot) * 4;
+                cslot = compid[off + L[p]];
+                if ((unsigned)cslot >= (unsigned)maxc) b = false;
+            }
+        }
+        // bounding boxes: neighbouring list entries usually belong to one component, so reduce
+        // inside the wave first and let one lane issue the four atomics
+        {
+            const unsigned long long bm = __builtin_amdgcn_ballot_w64(b);
+            if (bm) {
+                const int lead = __builtin_ctzll(bm);
+                const int s_lead = __builtin_amdgcn_readlane(cslot, lead);
+                const int y = p / w, x = p - y * w;
+                if (__builtin_amdgcn_ballot_w64(b && cslot != s_lead) == 0) {
+                    int mnx = b ? x : 0x7fffffff, mxx = b ? x : -1, mny = b ? y : 0x7fffffff, mxy = b ? y : -1;
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) {
+                        mnx = min(mnx, __shfl_xor(mnx, d)); mxx = max(mxx, __shfl_xor(mxx, d));
+                        mny = min(mny, __shfl_xor(mny, d)); mxy = max(mxy, __shfl_xor(mxy, d));
+                    }
+                    if ((threadIdx.x & 63) == lead) {
+                        int32_t* bb = aabb + ((size_t)f * maxc + s_lead) * 4;
+                        atomicMin(bb + 0, mnx); atomicMax(bb + 1, mxx);
+                        atomicMin(bb + 2, mny); atomicMax(bb + 3, mxy);
+                    }
+                } else if (b) {
+                    int32_t* bb = aabb + ((size_t)f * maxc + cslot) * 4;
                     atomicMin(bb + 0, x); atomicMax(bb + 1, x);
                     atomicMin(bb + 2, y); atomicMax(bb + 3, y);
-                } else b = false;
+                }
             }
         }
         const int slot = wave_append(&tab[f].n_border, b);
         if (b) B[slot] = p;
     }
+}
+
+// pack the first `k` entries of every frame's root / bounding-box table into dense arrays so the
+// host needs one contiguous copy instead of a strided one
+__global__ void pack_tables_kernel(const int32_t* __restrict__ roots, const int32_t* __restrict__ aabb, int maxc, int k, int n,
+                                   int32_t* __restrict__ out /* n*k roots, then n*k*4 boxes */)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * k) return;
+    const int f = i / k, s = i % k;
+    out[i] = roots[(size_t)f * maxc + s];
+    const int32_t* bb = aabb + ((size_t)f * maxc + s) * 4;
+    int32_t* ob = out + (size_t)n * k + (size_t)i * 4;
+    ob[0] = bb[0]; ob[1] = bb[1]; ob[2] = bb[2]; ob[3] = bb[3];
+}
+
+__global__ void pack_peaks_kernel(const int32_t* __restrict__ peaks, int k, int n, int32_t* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * k) return;
+    const int f = i / k, s = i % k;
+    out[2 * (size_t)i] = peaks[((size_t)f * PEAK_CAP + s) * 2];
+    out[2 * (size_t)i + 1] = peaks[((size_t)f * PEAK_CAP + s) * 2 + 1];
 }
 
 // a border pixel in the middle of a straight run cannot be a hull vertex
@@ -284,7 +329,7 @@ __device__ __forceinline__ bool mid_of_run(const uint8_t* e, int p, int w)
 // ---- F. gather hull-candidate points of the components the host asked for ---------------
 __global__ __launch_bounds__(256) void gather_points_kernel(const uint8_t* __restrict__ ez, int h, int w,
                                                             const int32_t* __restrict__ labels, const int32_t* __restrict__ compid,
-                                                            int maxc, const uint8_t* __restrict__ want, const FrameTab* __restrict__ tab,
+                                                            int maxc, const uint8_t* __restrict__ want, int wpitch, const FrameTab* __restrict__ tab,
                                                             const int32_t* __restrict__ blist, int32_t* __restrict__ counter, int cap,
                                                             int32_t* __restrict__ pts /* x|y<<16, slot ; then frame */)
 {
@@ -292,17 +337,23 @@ __global__ __launch_bounds__(256) void gather_points_kernel(const uint8_t* __res
     const int nb = tab[f].n_border;
     const size_t off = (size_t)f * h * w;
     const int32_t* B = blist + off;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nb; i += LIST_BLOCKS * 256) {
-        const int p = B[i];
-        const int slot = compid[off + labels[off + p]];
-        if (!want[(size_t)f * maxc + slot]) continue;
-        if (mid_of_run(ez + off, p, w)) continue;
-        const int k = atomicAdd(counter, 1);
-        if (k >= cap) continue;
-        const int y = p / w, x = p - y * w;
-        pts[2 * (size_t)k] = x | (y << 16);
-        pts[2 * (size_t)k + 1] = slot;
-        pts[2 * (size_t)cap + k] = f;
+    const int trips = (nb + LIST_BLOCKS * 256 - 1) / (LIST_BLOCKS * 256);       // uniform trip count
+    for (int t = 0; t < trips; t++) {
+        const int i = t * LIST_BLOCKS * 256 + blockIdx.x * 256 + threadIdx.x;
+        bool take = false;
+        int p = 0, slot = 0;
+        if (i < nb) {
+            p = B[i];
+            slot = compid[off + labels[off + p]];
+            take = want[(size_t)f * wpitch + slot] && !mid_of_run(ez + off, p, w);
+        }
+        const int k = wave_append(counter, take);           // one atomic per wave
+        if (take && k < cap) {
+            const int y = p / w, x = p - y * w;
+            pts[2 * (size_t)k] = x | (y << 16);
+            pts[2 * (size_t)k + 1] = slot;
+            pts[2 * (size_t)cap + k] = f;
+        }
     }
 }
 
@@ -475,10 +526,13 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
     {
         std::vector<int32_t> hroots((size_t)n * nc_max), haabb((size_t)n * nc_max * 4);
         if (nc_max) {
-            CK_HIP(ctx, hipMemcpy2DAsync(hroots.data(), (size_t)nc_max * 4, d_roots, (size_t)maxc * 4, (size_t)nc_max * 4, n,
-                                         hipMemcpyDeviceToHost, ctx->stream));
-            CK_HIP(ctx, hipMemcpy2DAsync(haabb.data(), (size_t)nc_max * 16, d_aabb, (size_t)maxc * 16, (size_t)nc_max * 16, n,
-                                         hipMemcpyDeviceToHost, ctx->stream));
+            const size_t cnt = (size_t)n * nc_max;
+            CK_TRY(ck_ensure(ctx, ctx->pts, cnt * 20 + 64));
+            int32_t* d_pack = (int32_t*)ctx->pts.p;
+            hipLaunchKernelGGL(pack_tables_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const int32_t*)d_roots, (const int32_t*)d_aabb, maxc, nc_max, n, d_pack);
+            CK_HIP(ctx, hipMemcpyAsync(hroots.data(), d_pack, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+            CK_HIP(ctx, hipMemcpyAsync(haabb.data(), d_pack + cnt, cnt * 16, hipMemcpyDeviceToHost, ctx->stream));
             CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
         for (int f = 0; f < n; f++) {
@@ -533,11 +587,10 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         if (round == 2) return ck_fail(ctx, CK_ERR_STATE, "contour selection did not converge");
         {
             TimeScope ts(ctx, "contour_gather");
-            CK_HIP(ctx, hipMemcpy2DAsync(d_want, (size_t)maxc, want.data(), (size_t)nc_max, (size_t)nc_max, n,
-                                         hipMemcpyHostToDevice, ctx->stream));
+            CK_HIP(ctx, hipMemcpyAsync(d_want, want.data(), (size_t)n * nc_max, hipMemcpyHostToDevice, ctx->stream));
             CK_HIP(ctx, hipMemsetAsync(d_counter, 0, 4, ctx->stream));
             hipLaunchKernelGGL(gather_points_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w,
-                               (const int32_t*)L, (const int32_t*)compid, maxc, (const uint8_t*)d_want,
+                               (const int32_t*)L, (const int32_t*)compid, maxc, (const uint8_t*)d_want, nc_max,
                                (const FrameTab*)d_tab, (const int32_t*)blist, d_counter, gcap, d_pts);
             CK_HIP(ctx, hipGetLastError());
         }
@@ -644,8 +697,13 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
     }
     if (!np_max) return CK_OK;
     std::vector<int32_t> pk((size_t)n * np_max * 2);
-    CK_HIP(ctx, hipMemcpy2DAsync(pk.data(), (size_t)np_max * 8, d_peaks, (size_t)PEAK_CAP * 8, (size_t)np_max * 8, n,
-                                 hipMemcpyDeviceToHost, ctx->stream));
+    {
+        const size_t cnt = (size_t)n * np_max;
+        CK_TRY(ck_ensure(ctx, ctx->pts, cnt * 8 + 64));
+        hipLaunchKernelGGL(pack_peaks_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const int32_t*)d_peaks, np_max, n, (int32_t*)ctx->pts.p);
+        CK_HIP(ctx, hipMemcpyAsync(pk.data(), ctx->pts.p, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
     CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const float theta = (float)(3.1415926535897932384626433832795 / 180);
     const double scale = 1. / (numrho + 2);
