@@ -84,8 +84,10 @@ def main():
     corners = synth.random_corners(H, W, rng)
     frames = torch.empty((F, H, W, 3), dtype=torch.uint8, device=dev)
     nd = min(args.distinct, F)
+    truth = np.zeros((F, 19, 19), np.uint8)
     for i in range(nd):
         stones = synth.random_stones(rng, density=0.1 + 0.4 * i / max(1, nd - 1))
+        truth[i::nd] = stones
         frames[i] = synth.render(H, W, stones, corners, seed=synth.SEED + 1000 * rank + i, device=dev)
     for i in range(nd, F):                       # remaining frames: earlier scenes with fresh noise
         base = frames[i % nd].to(torch.int16)
@@ -93,7 +95,9 @@ def main():
         g.manual_seed(synth.SEED + 7 * i + rank)
         noise = torch.randint(-2, 3, base.shape, generator=g, device=dev, dtype=torch.int16)
         frames[i] = (base + noise).clamp_(0, 255).to(torch.uint8)
-    weights = synth.cnn_weights()
+    from camkifu_amd.stone.nn_manager import NNManager, GOLDEN_WEIGHTS
+    weights = NNManager.init_net()               # trained fixture when present, else seeded He-normal
+    torch.cuda.synchronize()
     ctx.cnn_set_weights({k: torch.from_numpy(v).to(dev) for k, v in weights.items()})
     ctx.cnn_set_mode(capi.CK_CNN_BF16 if args.cnn == "bf16" else capi.CK_CNN_FP32)
     dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
@@ -136,6 +140,14 @@ def main():
             if cnt:
                 stages[nme] = dict(ms_total=round(ms, 3), launches=cnt, us_per_frame=round(1e3 * ms / (args.steps * F), 3))
         ctx.timing_enable(False)
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.isfile(pmc_path) and (H, W) == (1080, 1920):
+            pmc = json.load(open(pmc_path))
+
+        def traffic_of(stage, frames_per_launch):
+            t = pmc.get(stage)
+            return None if not t else int(t["hbm_bytes_per_frame"] * frames_per_launch)
         # roofline of the dominant kernel
         dom = max(stages, key=lambda k: stages[k]["ms_total"]) if stages else None
         roof = None
@@ -146,20 +158,21 @@ def main():
                 peak = MFMA_BF16_PEAK_TF if args.cnn == "bf16" else MFMA_F32_PEAK_TF
                 ach = 2.0 * MACS[dom] * per_launch_frames / avg_s / 1e12
                 roof = dict(kernel=dom, bound="mfma", achieved=round(ach, 3), peak=peak, unit="TFLOP/s",
-                            frac=round(ach / peak, 5), traffic=None)
+                            frac=round(ach / peak, 5), traffic=traffic_of(dom, per_launch_frames))
             else:
                 bytes_per_frame = {"median": 2 * 3 * W * H, "canny_nms": 4 * W * H, "warp": 433200 + 3 * W * H,
                                    "ccl": 6 * W * H, "canny_hyst": 2 * W * H}.get(dom, 4 * W * H)
                 ach = bytes_per_frame * per_launch_frames / avg_s / 1e9
                 roof = dict(kernel=dom, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBS, 5), traffic=None)
+                            frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic_of(dom, per_launch_frames))
         # the filter pass (K1) is always reported as well: north_star quotes HBM roofline on it
         filt = None
         if "median" in stages:
             avg_s = stages["median"]["ms_total"] / stages["median"]["launches"] * 1e-3
             ach = 2 * 3 * W * H * (args.steps * F / stages["median"]["launches"]) / avg_s / 1e9
             filt = dict(kernel="median", bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(ach / HBM_PEAK_GBS, 5))
+                        frac=round(ach / HBM_PEAK_GBS, 5),
+                        traffic=traffic_of("median", args.steps * F / stages["median"]["launches"]))
         out = {
             "metric": "frames/sec on 1920x1080 video + 19x19 stone-grid match % vs reference SGF",
             "value": round(world * F * args.steps / dt, 2),
@@ -175,6 +188,9 @@ def main():
             "filter_pass": filt,
             "stages": stages,
             "lines_found_frame0": int(board[0]["n_lines"]),
+            "stone_grid_match_pct": round(100.0 * float((labels.cpu().numpy() == truth).mean()), 3),
+            "cnn_weights": "trained on synthetic boards (tests/golden/cnn_weights.npz)" if os.path.isfile(GOLDEN_WEIGHTS)
+                           else "seeded random (labels meaningless)",
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, W, frames, corners, weights, args.cpu_frames)

@@ -39,15 +39,19 @@ __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t
     return __builtin_amdgcn_alignbyte(hi, lo, nbytes);
 }
 
-// 15-wide horizontal box sum of packed byte counters: result byte i of lane lx is
-// sum_{k=0..14} V[4*lx + i + k]
+// 15-wide horizontal box sum of packed byte counters: result byte t of lane lx is
+// sum_{k=0..14} V[4*lx + t + k].  Per lane: PS = inclusive byte prefix sums of its word,
+// G = the word total in every byte; the window is (suffix of this word) + (two full words)
+// + (a 3+t pixel prefix spanning the words 3 and 4 lanes to the right): 4 row shifts.
 __device__ __forceinline__ uint32_t hsum15(uint32_t w)
 {
-    uint32_t s1 = w + alignbyte(lane_right<1>(w), w, 1);               // pairs
-    uint32_t s2 = s1 + alignbyte(lane_right<1>(s1), s1, 2);            // 4
-    uint32_t s3 = s2 + lane_right<1>(s2);                              // 8
-    uint32_t t14 = alignbyte(lane_right<4>(w), lane_right<3>(w), 2);   // element +14
-    return s3 + lane_right<2>(s2) + lane_right<3>(s1) + t14;           // 8 + 4 + 2 + 1
+    const uint32_t a = w + (w << 8);
+    const uint32_t PS = a + (a << 16);
+    const uint32_t G = __builtin_amdgcn_perm(PS, PS, 0x03030303u);
+    const uint32_t SS = G - (PS << 8);                                  // suffix sums
+    const uint32_t PS3 = lane_right<3>(PS), PS4 = lane_right<4>(PS);
+    const uint32_t tail = alignbyte(PS4, PS3, 2) + __builtin_amdgcn_perm(PS3, PS3, 0x03030C0Cu);
+    return SS + lane_right<1>(G) + lane_right<2>(G) + tail;
 }
 
 struct Set256 {
@@ -127,14 +131,13 @@ __global__ __launch_bounds__(64) void median15_kernel(const uint8_t* __restrict_
                 for (int j = 0; j < HOUT; j++) {
                     if (j > 0) V = V + B[j + 14] - B[j - 1];
                     const uint32_t S = hsum15(V);
-                    const uint32_t D = 0xF0F0F0F0u - S;            // bit7 set <=> S < 113
-                    const uint32_t x = lo[j] ^ Q;
-                    const uint32_t z = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;   // bit7 set <=> byte != 0
-                    const uint32_t eq7 = ~z & vm80;
-                    const uint32_t upd7 = D & eq7;
+                    const uint32_t nD = S + 0x0F0F0F0Fu;                          // bit7 set <=> S >= 113
+                    const uint32_t nz = __builtin_amdgcn_lerp(lo[j] ^ Q, 0xFFFFFFFFu, 0u);   // bit7 set <=> prefix != q
+                    const uint32_t eq7 = (~nz & vm80);      // ~nz & vm80
+                    const uint32_t upd7 = (~nD & eq7);      // eq & (S < 113): median above t
                     lo[j] += upd7 >> (7 - b);
                     any_hi |= upd7;
-                    any_lo |= eq7 ^ upd7;
+                    any_lo |= eq7 & nD;
                 }
                 if (__builtin_amdgcn_ballot_w64(any_hi != 0)) nxt.set(q + half);
                 if (__builtin_amdgcn_ballot_w64(any_lo != 0)) nxt.set(q);

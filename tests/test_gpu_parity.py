@@ -340,3 +340,31 @@ def test_cnn_bf16_mode_close_to_fp32(ck, ora, synth):
     print("bf16 vs fp32: label agreement %.5f, max |dy| %.4f" % (agree, float(np.abs(y32 - y16).max())))
     assert agree >= 0.99
     assert np.abs(y32 - y16).max() < 0.25
+
+
+def test_4k_frame_full_chain(ck, ora, synth):
+    """BASELINE config 4 geometry: one 3840x2160 frame through the whole board path and the warp"""
+    from camkifu_amd import capi
+    sc = synth.scene(2160, 3840, seed=77, density=0.3)
+    fr = sc["frame"].numpy()
+    edges = ck.board_edges(fr)
+    assert np.array_equal(edges, ora.canny(ora.median(fr, 15), 25, 75))
+    out, ghost = ck.board_lines(edges, want_ghost=True)
+    _cmp_board(out[0], ghost, ora.board_lines(edges))
+    dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
+    M = capi.get_perspective_transform(sc["corners"], dst)
+    assert np.array_equal(ck.warp_perspective(fr, M), ora.warp_perspective(fr, M))
+
+
+def test_ragged_and_tiny_inputs(ck, ora):
+    """odd sizes, widths not a multiple of 4 (byte paths), 3x3 minimum, single-row-of-interior"""
+    rng = np.random.default_rng(21)
+    for (h, w) in [(3, 3), (5, 7), (33, 65), (17, 130), (64, 31)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(ck.median15(img), ora.median(img, 15)), (h, w)
+        e, m = ck.canny(img, 25, 75, want_map=True)
+        e2, m2, _, _, _ = ora.canny(img, 25, 75, want_map=True)
+        assert np.array_equal(m, m2) and np.array_equal(e, e2), (h, w)
+        edges = (rng.random((h, w)) < 0.35).astype(np.uint8) * 255
+        out, ghost = ck.board_lines(edges, hough_thresh=3, want_ghost=True)
+        _cmp_board(out[0], ghost, ora.board_lines(edges, hough_thresh=3))
