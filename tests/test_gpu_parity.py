@@ -366,5 +366,5 @@ def test_ragged_and_tiny_inputs(ck, ora):
         e2, m2, _, _, _ = ora.canny(img, 25, 75, want_map=True)
         assert np.array_equal(m, m2) and np.array_equal(e, e2), (h, w)
         edges = (rng.random((h, w)) < 0.35).astype(np.uint8) * 255
-        out, ghost = ck.board_lines(edges, hough_thresh=3, want_ghost=True)
-        _cmp_board(out[0], ghost, ora.board_lines(edges, hough_thresh=3))
+        out, ghost = ck.board_lines(edges, hough_thresh=4, cap=4096, want_ghost=True)
+        _cmp_board(out[0], ghost, ora.board_lines(edges, hough_thresh=4, cap=4096))
