@@ -123,15 +123,24 @@ __global__ __launch_bounds__(64 * WAVES_M * cdiv(COUT, 32)) void conv_mfma_f32_k
     auto k_loop = [&](auto nv_tag) {
         constexpr int NV = decltype(nv_tag)::value;
         if constexpr (CIN % 2 == 0) {
+            // K = (kh, kw, cin) is walked in fully unrolled order, so the B row index is linear
+            // in the step (k = 2*step + hi) and the weight loads run PF steps ahead of the MFMAs
+            // through a register ring with compile-time indices: no vmcnt(0) drain at a seam
+            constexpr int PF = 12;
+            const float* wp = wcol + (size_t)hi * COUTP;
+            float bq[PF];
+#pragma unroll
+            for (int u = 0; u < PF; u++) bq[u] = u < KS ? wp[(size_t)(2 * u) * COUTP] : 0.f;
 #pragma unroll
             for (int i = 0; i < KH; i++) {
 #pragma unroll
                 for (int j = 0; j < KW; j++) {
                     const int aoff = (i * W + j) * CS + hi;
-                    const float* wrow = wcol + (size_t)((i * KW + j) * CIN + hi) * COUTP;
-#pragma unroll UNROLL_CC
+#pragma unroll
                     for (int cc = 0; cc < CIN / 2; cc++) {
-                        const float b = wrow[(size_t)(2 * cc) * COUTP];
+                        const int step = (i * KW + j) * (CIN / 2) + cc;
+                        const float b = bq[step % PF];
+                        if (step + PF < KS) bq[step % PF] = wp[(size_t)(2 * (step + PF)) * COUTP];
 #pragma unroll
                         for (int r = 0; r < NV; r++) {
                             const float a = lds[abase[r] + aoff + 2 * cc];
@@ -571,7 +580,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
 {
     // convolutions run in chunks of frames so the activation scratch stays bounded; the dense
     // tail runs once over the whole batch (its 32-patch MFMA tiles need many waves in flight)
-    const int CHUNK = 32;
+    const int CHUNK = 128;
     const size_t a1_sz = (size_t)CHUNK * 100 * 36 * 36 * 32 * 4;      // conv1 out (36*36*32), later conv3 out (14*14*90)
     const size_t p2_sz = (size_t)CHUNK * 100 * 12 * 12 * 90 * 4;      // conv2+pool out (16*16*32), later conv4 out (12*12*90)
     CK_TRY(ck_ensure(ctx, ctx->act0, a1_sz));
