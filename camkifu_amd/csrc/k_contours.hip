@@ -24,6 +24,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <chrono>
 #include <thread>
 
 #include "ck_common.h"
@@ -465,6 +466,15 @@ struct Comp {
 int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int hough_thresh,
                   float* lines, int cap, ck_board_result* res, uint8_t* d_ghost_out)
 {
+    static const bool prof = getenv("CK_PROFILE_HOST") != nullptr;   // debugging aid: host-side lap times on stderr
+    auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!prof) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[board_lines] %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_start).count());
+        t_start = now;
+    };
     const size_t fpx = (size_t)h * w, npx = fpx * n;
     int maxc = (int)(fpx / 4 + 1);
     if (maxc > MAXC_LIMIT) maxc = MAXC_LIMIT;
@@ -513,6 +523,7 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         CK_HIP(ctx, hipGetLastError());
     }
 
+    lap("ccl kernels");
     // ---- host: component tables (one strided copy each) -------------------------------------
     std::vector<FrameTab> tab((size_t)n);
     CK_HIP(ctx, hipMemcpyAsync(tab.data(), d_tab, tab_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -550,6 +561,7 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         }
     }
 
+    lap("tables d2h");
     // ---- exact areas for the components that can still reach the top three -------------------
     const int gcap = (int)(npx < (1u << 22) ? npx : (1u << 22));     // points per gather round
     CK_TRY(ck_ensure(ctx, ctx->pts, (size_t)gcap * 12 + 64));
@@ -604,6 +616,7 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
             CK_HIP(ctx, hipMemcpyAsync(hf.data(), d_pts + (size_t)gcap * 2, (size_t)npts * 4, hipMemcpyDeviceToHost, ctx->stream));
             CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
+        lap("  gather kernel+d2h");
         // bucket by (frame, slot)
         std::vector<std::vector<std::vector<int32_t>>> bucket((size_t)n);
         for (int f = 0; f < n; f++) bucket[f].resize(comps[f].size());
@@ -612,6 +625,7 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
             b.push_back(hp[2 * (size_t)i] & 0xFFFF);
             b.push_back(hp[2 * (size_t)i] >> 16);
         }
+        lap("  bucket");
         parallel_for(n, [&](int f) {
             auto& cv = comps[f];
             for (size_t s = 0; s < cv.size(); s++) {
@@ -622,8 +636,10 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
                 cv[s].known = true;
             }
         });
+        lap("  hull+calipers");
     }
 
+    lap("gather+calipers");
     // ---- selection: bisect.insort order = (area ascending, discovery order descending) ------
     std::vector<int32_t> sel((size_t)n * 4, -1);
     bool any_go = false;
@@ -688,6 +704,7 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
                            (const int32_t*)d_accum, numrho, hough_thresh, d_tab, d_peaks);
         CK_HIP(ctx, hipGetLastError());
     }
+    lap("ghost+hough");
     CK_HIP(ctx, hipMemcpyAsync(tab.data(), d_tab, tab_bytes, hipMemcpyDeviceToHost, ctx->stream));
     CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int np_max = 0;
@@ -728,5 +745,6 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
             lines[((size_t)f * cap + i) * 2 + 1] = 0.f + nn * theta;
         }
     }
+    lap("peaks d2h+sort");
     return CK_OK;
 }

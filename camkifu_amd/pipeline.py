@@ -153,21 +153,33 @@ class FastFilePipeline:
     """compute(frames, mtx) -> (board list, labels, conf) is the stateless per-shard core; by
     default it is the HIP context (ck_board_detect + ck_stones_detect)."""
 
-    def __init__(self, h, w, controller, ctx=None, rank=0, world=1, device=None, compute=None):
+    def __init__(self, h, w, controller, ctx=None, rank=0, world=1, device=None, compute=None, ctx_board=None):
+        """ctx runs the stones path; ctx_board (optional second context = second HIP stream) lets the
+        board path run concurrently on its own host thread, as the reference's two finder threads do"""
         self.h, self.w = h, w
         self.rank, self.world, self.device = rank, world, device
         self.ctx = ctx
+        self.ctx_board = ctx_board
+        self._pool = None
         self.compute = compute or self._gpu_compute
         self.board = BoardFold(h, w)
         self.stones = StonesFold(controller)
         self.frames_done = 0
 
     def _gpu_compute(self, frames, mtx):
-        board = self.ctx.board_detect(frames, cap=LMAX)
-        n = len(board)
-        if mtx is None:
-            return board, np.zeros((n, 19, 19), np.uint8), np.zeros((n, 19, 19), np.float64)
-        labels, conf = self.ctx.stones_detect(frames, mtx)
+        if self.ctx_board is not None and mtx is not None:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(1)
+            fut = self._pool.submit(self.ctx_board.board_detect, frames, -1, LMAX)
+            labels, conf = self.ctx.stones_detect(frames, mtx)
+            board = fut.result()
+        else:
+            board = (self.ctx_board or self.ctx).board_detect(frames, cap=LMAX)
+            if mtx is None:
+                n = len(board)
+                return board, np.zeros((n, 19, 19), np.uint8), np.zeros((n, 19, 19), np.float64)
+            labels, conf = self.ctx.stones_detect(frames, mtx)
         if hasattr(labels, "cpu"):
             labels, conf = labels.cpu().numpy(), conf.cpu().numpy()
         return board, labels, conf
