@@ -80,3 +80,25 @@ def test_board_fold_matches_finder(clip):
         fold.step(r)
     assert fold.finder.corners.hull is not None
     assert np.abs(np.array(fold.finder.corners.hull, np.float64) - corners).max() < 12
+
+
+def test_kifu_checker_scoring(tmp_path):
+    from camkifu_amd.golib_shim import Kifu, Move, NP_TYPE
+    from camkifu_amd.kifu_checker import KifuChecker, report
+    ref = Kifu()
+    for k, (col, r, c) in enumerate([('B', 3, 3), ('W', 15, 15), ('B', 3, 15), ('W', 15, 3)]):
+        ref.append(Move(NP_TYPE, (col, r, c)))
+    path = str(tmp_path / "ref.sgf")
+    ref.save(path)
+    again = Kifu(sgffile=path)
+    assert [repr(m) for m in again.moves] == [repr(m) for m in ref.moves]       # SGF round trip
+    found = Kifu()
+    for m in ref.moves[:3]:
+        found.append(Move(NP_TYPE, (m.color, m.y, m.x)))
+    mt = KifuChecker(path).check(found)
+    assert abs(mt.ratio() - 2 * 3 / 7) < 1e-12
+    assert report("x", mt, 1.0).startswith("[x: 85.7% in")
+    with pytest.raises(AssertionError):
+        bad = Kifu()
+        bad.append(Move(NP_TYPE, ('W', 3, 3)))
+        KifuChecker(path, failfast=True).check(bad)

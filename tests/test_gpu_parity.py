@@ -368,3 +368,15 @@ def test_ragged_and_tiny_inputs(ck, ora):
         edges = (rng.random((h, w)) < 0.35).astype(np.uint8) * 255
         out, ghost = ck.board_lines(edges, hough_thresh=4, cap=4096, want_ghost=True)
         _cmp_board(out[0], ghost, ora.board_lines(edges, hough_thresh=4, cap=4096))
+
+
+def test_detectiontest_harness_on_gpu():
+    """BASELINE config 1 on the HIP path: synthetic 640x480 clip -> recorded game == reference game"""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "detectiontest.py"), "--synthetic", "640x480",
+                          "--frames", "70"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "[synthetic-640x480: 100.0% in" in out.stdout, out.stdout[-500:]
