@@ -4,7 +4,8 @@
 One "step" = one pass of the hot path over one batch of frames that is already resident in
 HBM: board detect (K1..K6: median -> Canny -> contours -> Hough lines, lines back on the
 host) and stones detect (K8, K10..K12: warp -> 100 patches -> CNN -> 19x19 labels) for every
-frame of the batch, then (N > 1) an RCCL all-gather of the per-frame 19x19 labels.
+frame of the batch, then (N > 1) ONE RCCL all-gather of the fixed-size per-frame records and the
+ordered host fold (line accumulation -> corners; label acceptance -> moves) on every rank.
 Workload (BASELINE.json configs[2]): 1080p, 256-frame batches on one MI355X; with N GPUs
 every rank processes its own 256-frame shard of the video (weak scaling, no data-path
 collective except the label gather).
@@ -50,12 +51,11 @@ def cpu_baseline(h, w, frames, corners, weights, nframes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=256, help="frames per batch per GPU")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--distinct", type=int, default=16, help="distinct rendered scenes per batch")
     ap.add_argument("--cnn", choices=["fp32", "bf16"], default="fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
@@ -81,25 +81,37 @@ def main():
     # context (= HIP stream + scratch), so the host-side gaps of one path are filled by the other
     ctx_b = capi.Context(local_rank)
     ctx = capi.Context(local_rank)
-    pool = ThreadPoolExecutor(1)
     H, W, F = args.height, args.width, args.frames
 
     # ---- synthetic video shard of this rank, rendered straight into HBM --------------------
     rng = np.random.default_rng(synth.SEED + rank)
     corners = synth.random_corners(H, W, rng)
     frames = torch.empty((F, H, W, 3), dtype=torch.uint8, device=dev)
-    nd = min(args.distinct, F)
+    # one game filmed by a fixed camera: a random mid-game position, then one new stone every 5
+    # frames; every distinct position is rendered once, the frames in between are
+    # the same position under fresh sensor noise
     truth = np.zeros((F, 19, 19), np.uint8)
-    for i in range(nd):
-        stones = synth.random_stones(rng, density=0.1 + 0.4 * i / max(1, nd - 1))
-        truth[i::nd] = stones
-        frames[i] = synth.render(H, W, stones, corners, seed=synth.SEED + 1000 * rank + i, device=dev)
-    for i in range(nd, F):                       # remaining frames: earlier scenes with fresh noise
-        base = frames[i % nd].to(torch.int16)
-        g = torch.Generator(device=dev)
-        g.manual_seed(synth.SEED + 7 * i + rank)
-        noise = torch.randint(-2, 3, base.shape, generator=g, device=dev, dtype=torch.int16)
-        frames[i] = (base + noise).clamp_(0, 255).to(torch.uint8)
+    stones = synth.random_stones(rng, density=0.3)
+    true_moves = [("EBW"[stones[r, c]], r, c) for r in range(19) for c in range(19) if stones[r, c]]
+    color, last = 1, None
+    for i in range(F):
+        if i % 5 == 0:
+            if i > 0:
+                while True:
+                    r, c = rng.integers(1, 18, 2)
+                    if stones[r, c] == 0:
+                        break
+                stones[r, c] = color
+                true_moves.append(("EBW"[color], int(r), int(c)))
+                color = 3 - color
+            frames[i] = synth.render(H, W, stones, corners, seed=synth.SEED + 1000 * rank + i, device=dev)
+            last = i
+        else:
+            g = torch.Generator(device=dev)
+            g.manual_seed(synth.SEED + 7 * i + rank)
+            noise = torch.randint(-2, 3, frames[last].shape, generator=g, device=dev, dtype=torch.int16)
+            frames[i] = (frames[last].to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
+        truth[i] = stones
     from camkifu_amd.stone.nn_manager import NNManager, GOLDEN_WEIGHTS
     weights = NNManager.init_net()               # trained fixture when present, else seeded He-normal
     torch.cuda.synchronize()
@@ -107,14 +119,38 @@ def main():
     ctx.cnn_set_mode(capi.CK_CNN_BF16 if args.cnn == "bf16" else capi.CK_CNN_FP32)
     dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
     M = capi.get_perspective_transform(corners, dst)
-    gathered = torch.empty((world * F, 19, 19), dtype=torch.uint8, device=dev) if world > 1 else None
+    from camkifu_amd import pipeline
+    from camkifu_amd.controller import ControllerHeadless
+    pipe = pipeline.FastFilePipeline(H, W, ControllerHeadless(), ctx=ctx, ctx_board=ctx_b, rank=rank, world=world,
+                                     device=dev)
+    pool2 = ThreadPoolExecutor(2)
 
-    def step():
-        fut = pool.submit(ctx_b.board_detect, frames)          # K1..K6, lines on the host
-        labels, conf = ctx.stones_detect(frames, M)            # K8, K10..K12, labels in HBM
-        board = fut.result()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, labels)      # RCCL over xGMI: 361 B / frame
+    def launch():
+        """GPU part of one step, on two host threads / two HIP streams"""
+        return (pool2.submit(ctx_b.board_detect, frames, -1, pipeline.LMAX, True),   # K1..K6, lines on the host
+                pool2.submit(ctx.stones_detect, frames, M))                       # K8, K10..K12, labels in HBM
+
+    def finish_host(board, labels, conf):
+        """pack the fixed-size per-frame records, one all-gather (RCCL over xGMI), ordered fold"""
+        rec = pipeline.pack_records_raw(board[0], board[1], labels.cpu().numpy(), conf.cpu().numpy())
+        full = pipeline.gather_records(rec, world * F, rank, world, dev) if world > 1 else rec
+        pipe.stones = pipeline.StonesFold(ControllerHeadless())     # every step replays the same game from scratch
+        pipe.fold(full)
+
+    def run_steps(k):
+        """k steps; the host part of batch i (records, gather, fold) overlaps the GPU work of batch i+1"""
+        futs = launch()
+        for i in range(k):
+            board = futs[0].result()
+            labels, conf = futs[1].result()
+            if i + 1 < k:
+                futs = launch()
+            finish_host(board, labels, conf)
+        return board, labels
+
+    def step_serial():
+        board = ctx_b.board_detect(frames, cap=pipeline.LMAX)
+        labels, conf = ctx.stones_detect(frames, M)
         return board, labels
 
     def sync():
@@ -122,17 +158,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step_serial():
-        board = ctx_b.board_detect(frames)
-        labels, conf = ctx.stones_detect(frames, M)
-        return board, labels
-
-    for _ in range(args.warmup):
-        step()
+    if args.warmup:
+        run_steps(args.warmup)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        board, labels = step()
+    board, labels = run_steps(args.steps)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -212,7 +242,13 @@ def main():
             "stages": stages,
             "stage_timing": "HIP events per context stream over %d serial steps after the timed region; the timed "
                             "region overlaps the board and stones paths on two streams" % prof_steps,
-            "lines_found_frame0": int(board[0]["n_lines"]),
+            "lines_found_frame0": int(board[0]["n_lines"][0]),
+            "board_found_by_fold": pipe.board.mtx is not None,
+            "moves_recorded_by_fold": len(pipe.stones.controller.kifu.moves),
+            "move_sequence_ratio": round(__import__("difflib").SequenceMatcher(
+                a=["%s%d,%d" % m for m in true_moves],
+                b=["%s%d,%d" % (m.color, m.y, m.x) for m in pipe.stones.controller.kifu.moves[:len(true_moves)]]).ratio(), 4)
+                if world == 1 else None,
             "stone_grid_match_pct": round(100.0 * float((labels.cpu().numpy() == truth).mean()), 3),
             "cnn_weights": "trained on synthetic boards (tests/golden/cnn_weights.npz)" if os.path.isfile(GOLDEN_WEIGHTS)
                            else "seeded random (labels meaningless)",

@@ -37,6 +37,10 @@ class BoardResult(C.Structure):
                 ("reserved", C.c_int32), ("biggest_area", C.c_double)]
 
 
+BOARD_DTYPE = np.dtype([("status", "<i4"), ("n_contours", "<i4"), ("n_lines", "<i4"), ("reserved", "<i4"),
+                        ("biggest_area", "<f8")])          # ck_board_result, 24 bytes
+
+
 class CkError(RuntimeError):
     pass
 
@@ -198,14 +202,19 @@ class Context:
         out = self._lines_out(n, cap, lines, res)
         return (out, ghost) if want_ghost else out
 
-    def board_detect(self, bgr, hough_thresh=-1, cap=1024):
+    def board_detect(self, bgr, hough_thresh=-1, cap=1024, raw=False):
+        """raw=True: (structured array of BOARD_DTYPE, lines (n, cap, 2)) without per-frame python objects"""
         n, h, w = self._shape(bgr, 3)
         p, sp, keep = _in(bgr)
         lines = np.zeros((n, cap, 2), np.float32)
-        res = (BoardResult * n)()
+        res = np.zeros(n, BOARD_DTYPE)
         self._chk(lib().ck_board_detect(self._h, p, n, h, w, sp, int(hough_thresh),
-                                        lines.ctypes.data_as(C.c_void_p), cap, res))
-        return self._lines_out(n, cap, lines, res)
+                                        lines.ctypes.data_as(C.c_void_p), cap, res.ctypes.data_as(C.c_void_p)))
+        if raw:
+            return res, lines
+        return [dict(status=int(r["status"]), n_contours=int(r["n_contours"]), n_lines=int(r["n_lines"]),
+                     biggest_area=float(r["biggest_area"]), lines=lines[f, :min(int(r["n_lines"]), cap)].copy())
+                for f, r in enumerate(res)]
 
     # ---- K8 ---------------------------------------------------------------------------------
     def warp_perspective(self, bgr, M, dsize=380):

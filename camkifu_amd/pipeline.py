@@ -49,6 +49,23 @@ def pack_records(board, labels, conf):
     return rec
 
 
+def pack_records_raw(res, lines, labels, conf):
+    """vectorised pack_records for Context.board_detect(raw=True) output"""
+    n = len(res)
+    if (res["n_lines"] > LMAX).any():
+        raise ValueError("frame record holds %d Hough lines, %d found" % (LMAX, int(res["n_lines"].max())))
+    rec = np.zeros((n, REC_BYTES), np.uint8)
+    rec[:, REC_LABELS:REC_LABELS + 361] = np.asarray(labels, np.uint8).reshape(n, 361)
+    rec[:, REC_CONF:REC_CONF + 361 * 8] = np.ascontiguousarray(conf, np.float64).reshape(n, 361).view(np.uint8)
+    hdr = np.stack([res["status"], res["n_contours"], res["n_lines"], np.zeros(n, np.int32)], 1).astype(np.int32)
+    rec[:, REC_HDR:REC_HDR + 16] = hdr.view(np.uint8).reshape(n, 16)
+    rec[:, REC_AREA:REC_AREA + 8] = np.ascontiguousarray(res["biggest_area"], np.float64).view(np.uint8).reshape(n, 8)
+    keep = np.arange(LMAX)[None, :] < res["n_lines"][:, None]               # lines beyond n_lines are zeroed
+    ln = np.where(keep[..., None], np.ascontiguousarray(lines[:, :LMAX], np.float32), np.float32(0))
+    rec[:, REC_LINES:REC_LINES + LMAX * 8] = np.ascontiguousarray(ln).view(np.uint8).reshape(n, LMAX * 8)
+    return rec
+
+
 def unpack_record(rec):
     hdr = rec[REC_HDR:REC_HDR + 16].view(np.int32)
     k = int(hdr[2])
@@ -57,6 +74,18 @@ def unpack_record(rec):
                 lines=rec[REC_LINES:REC_LINES + 8 * k].view(np.float32).reshape(k, 2).copy(),
                 labels=rec[REC_LABELS:REC_LABELS + 361].reshape(19, 19).copy(),
                 conf=rec[REC_CONF:REC_CONF + 361 * 8].view(np.float64).reshape(19, 19).copy())
+
+
+def unpack_records(rec):
+    """vectorised view of an (n, REC_BYTES) record array -> dict of arrays (lines stay packed:
+    use lines[f, :n_lines[f]])"""
+    n = len(rec)
+    hdr = np.ascontiguousarray(rec[:, REC_HDR:REC_HDR + 16]).view(np.int32).reshape(n, 4)
+    return dict(status=hdr[:, 0], n_contours=hdr[:, 1], n_lines=hdr[:, 2],
+                biggest_area=np.ascontiguousarray(rec[:, REC_AREA:REC_AREA + 8]).view(np.float64).reshape(n),
+                lines=np.ascontiguousarray(rec[:, REC_LINES:REC_LINES + LMAX * 8]).view(np.float32).reshape(n, LMAX, 2),
+                labels=rec[:, REC_LABELS:REC_LABELS + 361].reshape(n, 19, 19),
+                conf=np.ascontiguousarray(rec[:, REC_CONF:REC_CONF + 361 * 8]).view(np.float64).reshape(n, 19, 19))
 
 
 def gather_records(local, n_total, rank, world, device=None):
@@ -128,25 +157,49 @@ class StonesFold:
 
     def __init__(self, controller):
         self.controller = controller
+        self.cur = None                        # cached goban as uint8 (19,19): 0 E, 1 B, 2 W
+
+    def resync(self):
+        """re-read the goban from the controller (once per batch: somebody else may edit it)"""
+        st = self.controller.get_stones()
+        self.cur = np.zeros((gsize, gsize), np.uint8)
+        self.cur[st == B] = 1
+        self.cur[st == W] = 2
 
     def step(self, labels, conf):
         from .golib_shim import Move, NP_TYPE
+        if self.cur is None:
+            self.resync()
+        change = (labels != 0) & (conf > self.MIN_CONFIDENCE) & (labels != self.cur)
+        if not change.any():
+            return []
         moves = []
-        for r in range(gsize):
-            for c in range(gsize):
-                color = _COLORS[labels[r, c]]
-                if color == E or not (conf[r, c] > self.MIN_CONFIDENCE):
-                    continue
-                existing = self.controller.locate(c, r)
-                if existing is not None:
-                    if existing.color == color:
-                        continue
-                    moves.append(Move(NP_TYPE, (E, r, c)))
-                moves.append(Move(NP_TYPE, (color, r, c)))
-        if moves:
-            self.controller.pipe("bulk", moves)
-            self.controller.pipe("auto_save")
+        for r, c in np.argwhere(change):          # raster order, like the reference's double loop
+            r, c = int(r), int(c)
+            color = _COLORS[labels[r, c]]
+            if self.cur[r, c] != 0:
+                moves.append(Move(NP_TYPE, (E, r, c)))       # clear first, then recolour
+            moves.append(Move(NP_TYPE, (color, r, c)))
+            self.cur[r, c] = labels[r, c]
+        self.controller.pipe("bulk", moves)
+        self.controller.pipe("auto_save")
         return moves
+
+    def step_batch(self, labels, conf):
+        """ordered fold of a whole batch; frames whose accepted labels equal the cached goban are
+        skipped without touching Python per frame -> list of per-frame move lists"""
+        if self.cur is None:
+            self.resync()
+        n = len(labels)
+        acc = np.where(conf > self.MIN_CONFIDENCE, labels, 0)           # accepted colour or 0
+        # a frame can only emit moves if it differs from the goban as left by its predecessor;
+        # cheap superset: differs from the previous frame's accepted labels or from the cache
+        prev = np.concatenate([self.cur[None], acc[:-1]])
+        cand = ((acc != prev) & (acc != 0)).reshape(n, -1).any(1)
+        out = [[] for _ in range(n)]
+        for f in np.flatnonzero(cand | (np.arange(n) == 0)):
+            out[f] = self.step(labels[f], conf[f])
+        return out
 
 
 class FastFilePipeline:
@@ -193,10 +246,21 @@ class FastFilePipeline:
         board, labels, conf = self.compute(my_frames, mtx)
         rec = pack_records(board, labels, conf)
         full = gather_records(rec, n_total, self.rank, self.world, self.device)
-        emitted = []
-        for f in range(n_total):
-            r = unpack_record(full[f])
-            self.board.step(r)
-            emitted.append(self.stones.step(r["labels"], r["conf"]) if mtx is not None else [])
-            self.frames_done += 1
+        return self.fold(full, mtx is not None)
+
+    def fold(self, full, have_mtx=True):
+        """ordered replay of the temporal logic on the gathered records of one batch"""
+        u = unpack_records(full)
+        n = len(full)
+        self.stones.resync()
+        for f in range(n):
+            if self.board.hold > 0:                    # hold-off after a hit: nothing to look at
+                self.board.hold -= 1
+                self.board.finder.total_f_processed += 1
+                continue
+            k = int(u["n_lines"][f])
+            self.board.step(dict(status=int(u["status"][f]), n_contours=int(u["n_contours"][f]), n_lines=k,
+                                 biggest_area=float(u["biggest_area"][f]), lines=u["lines"][f, :k]))
+        emitted = self.stones.step_batch(u["labels"], u["conf"]) if have_mtx else [[] for _ in range(n)]
+        self.frames_done += n
         return emitted

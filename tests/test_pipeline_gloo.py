@@ -94,3 +94,15 @@ def test_two_rank_fold_equals_single_process():
     for rank, out, sgf, mtx in res:
         assert out == ref[0] and sgf == ref[1]
         assert np.allclose(np.array(mtx), np.array(ref[2]))
+
+
+def test_raw_pack_equals_dict_pack():
+    from camkifu_amd import capi
+    board, labels, conf = _fake_compute(np.arange(9))(None, None)
+    res = np.zeros(9, capi.BOARD_DTYPE)
+    lines = np.zeros((9, pipeline.LMAX, 2), np.float32)
+    for f, b in enumerate(board):
+        res[f] = (b["status"], b["n_contours"], b["n_lines"], 0, b["biggest_area"])
+        lines[f, :b["n_lines"]] = b["lines"]
+        lines[f, b["n_lines"]:] = 7.0                      # stale scratch beyond n_lines must not leak
+    assert np.array_equal(pipeline.pack_records_raw(res, lines, labels, conf), pipeline.pack_records(board, labels, conf))
