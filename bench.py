@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--cnn", choices=["fp32", "bf16"], default="fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--cpu-frames", type=int, default=2)
     args = ap.parse_args()
 
@@ -70,10 +72,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")      # where collective buffers live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from camkifu_amd import capi, synth
     from concurrent.futures import ThreadPoolExecutor
@@ -84,34 +92,40 @@ def main():
     H, W, F = args.height, args.width, args.frames
 
     # ---- synthetic video shard of this rank, rendered straight into HBM --------------------
-    rng = np.random.default_rng(synth.SEED + rank)
+    # ONE game filmed by a fixed camera, world*F frames long: a random mid-game position, then one
+    # new stone every 5 frames.  Global frame g lives on rank g mod world (the
+    # pipeline's sharding), so every rank builds the same move list and renders only its frames;
+    # frames that show an unchanged position are the last render under fresh sensor noise.
+    rng = np.random.default_rng(synth.SEED)                     # identical on every rank
     corners = synth.random_corners(H, W, rng)
     frames = torch.empty((F, H, W, 3), dtype=torch.uint8, device=dev)
-    # one game filmed by a fixed camera: a random mid-game position, then one new stone every 5
-    # frames; every distinct position is rendered once, the frames in between are
-    # the same position under fresh sensor noise
+    stones0 = synth.random_stones(rng, density=0.3)
+    true_moves = [("EBW"[stones0[r, c]], r, c) for r in range(19) for c in range(19) if stones0[r, c]]
+    n_init = len(true_moves)
+    positions, st, color = [stones0.copy()], stones0.copy(), 1
+    for k in range((world * F - 1) // 5):
+        while True:
+            r, c = rng.integers(1, 18, 2)
+            if st[r, c] == 0:
+                break
+        st[r, c] = color
+        true_moves.append(("EBW"[color], int(r), int(c)))
+        color = 3 - color
+        positions.append(st.copy())
     truth = np.zeros((F, 19, 19), np.uint8)
-    stones = synth.random_stones(rng, density=0.3)
-    true_moves = [("EBW"[stones[r, c]], r, c) for r in range(19) for c in range(19) if stones[r, c]]
-    color, last = 1, None
+    last_pos, last = -1, None
     for i in range(F):
-        if i % 5 == 0:
-            if i > 0:
-                while True:
-                    r, c = rng.integers(1, 18, 2)
-                    if stones[r, c] == 0:
-                        break
-                stones[r, c] = color
-                true_moves.append(("EBW"[color], int(r), int(c)))
-                color = 3 - color
-            frames[i] = synth.render(H, W, stones, corners, seed=synth.SEED + 1000 * rank + i, device=dev)
-            last = i
+        g_idx = i * world + rank
+        pos = g_idx // 5
+        if pos != last_pos:
+            frames[i] = synth.render(H, W, positions[pos], corners, seed=synth.SEED + g_idx, device=dev)
+            last_pos, last = pos, i
         else:
             g = torch.Generator(device=dev)
-            g.manual_seed(synth.SEED + 7 * i + rank)
+            g.manual_seed(synth.SEED + 7 * g_idx)
             noise = torch.randint(-2, 3, frames[last].shape, generator=g, device=dev, dtype=torch.int16)
             frames[i] = (frames[last].to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
-        truth[i] = stones
+        truth[i] = positions[pos]
     from camkifu_amd.stone.nn_manager import NNManager, GOLDEN_WEIGHTS
     weights = NNManager.init_net()               # trained fixture when present, else seeded He-normal
     torch.cuda.synchronize()
@@ -122,7 +136,7 @@ def main():
     from camkifu_amd import pipeline
     from camkifu_amd.controller import ControllerHeadless
     pipe = pipeline.FastFilePipeline(H, W, ControllerHeadless(), ctx=ctx, ctx_board=ctx_b, rank=rank, world=world,
-                                     device=dev)
+                                     device=cdev)
     pool2 = ThreadPoolExecutor(2)
 
     def launch():
@@ -133,7 +147,7 @@ def main():
     def finish_host(board, labels, conf):
         """pack the fixed-size per-frame records, one all-gather (RCCL over xGMI), ordered fold"""
         rec = pipeline.pack_records_raw(board[0], board[1], labels.cpu().numpy(), conf.cpu().numpy())
-        full = pipeline.gather_records(rec, world * F, rank, world, dev) if world > 1 else rec
+        full = pipeline.gather_records(rec, world * F, rank, world, cdev) if world > 1 else rec
         pipe.stones = pipeline.StonesFold(ControllerHeadless())     # every step replays the same game from scratch
         pipe.fold(full)
 
@@ -166,7 +180,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -247,8 +261,7 @@ def main():
             "moves_recorded_by_fold": len(pipe.stones.controller.kifu.moves),
             "move_sequence_ratio": round(__import__("difflib").SequenceMatcher(
                 a=["%s%d,%d" % m for m in true_moves],
-                b=["%s%d,%d" % (m.color, m.y, m.x) for m in pipe.stones.controller.kifu.moves[:len(true_moves)]]).ratio(), 4)
-                if world == 1 else None,
+                b=["%s%d,%d" % (m.color, m.y, m.x) for m in pipe.stones.controller.kifu.moves[:len(true_moves)]]).ratio(), 4),
             "stone_grid_match_pct": round(100.0 * float((labels.cpu().numpy() == truth).mean()), 3),
             "cnn_weights": "trained on synthetic boards (tests/golden/cnn_weights.npz)" if os.path.isfile(GOLDEN_WEIGHTS)
                            else "seeded random (labels meaningless)",
