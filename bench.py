@@ -137,12 +137,13 @@ def main():
     from camkifu_amd.controller import ControllerHeadless
     pipe = pipeline.FastFilePipeline(H, W, ControllerHeadless(), ctx=ctx, ctx_board=ctx_b, rank=rank, world=world,
                                      device=cdev)
-    pool2 = ThreadPoolExecutor(2)
+    # one host thread per context (a context is single-threaded by contract), each with its own stream
+    pool_b, pool_s = ThreadPoolExecutor(1), ThreadPoolExecutor(1)
 
     def launch():
         """GPU part of one step, on two host threads / two HIP streams"""
-        return (pool2.submit(ctx_b.board_detect, frames, -1, pipeline.LMAX, True),   # K1..K6, lines on the host
-                pool2.submit(ctx.stones_detect, frames, M))                       # K8, K10..K12, labels in HBM
+        return (pool_b.submit(ctx_b.board_detect, frames, -1, pipeline.LMAX, True),   # K1..K6, lines on the host
+                pool_s.submit(ctx.stones_detect, frames, M))                       # K8, K10..K12, labels in HBM
 
     def finish_host(board, labels, conf):
         """pack the fixed-size per-frame records, one all-gather (RCCL over xGMI), ordered fold"""
@@ -152,13 +153,16 @@ def main():
         pipe.fold(full)
 
     def run_steps(k):
-        """k steps; the host part of batch i (records, gather, fold) overlaps the GPU work of batch i+1"""
-        futs = launch()
+        """k steps, two batches in flight: the host part of batch i (contour pruning inside board_detect,
+        records, gather, fold) overlaps the GPU work of batches i+1 and i+2"""
+        DEPTH = 2
+        inflight = [launch() for _ in range(min(DEPTH, k))]
         for i in range(k):
+            futs = inflight.pop(0)
             board = futs[0].result()
             labels, conf = futs[1].result()
-            if i + 1 < k:
-                futs = launch()
+            if i + DEPTH < k:
+                inflight.append(launch())
             finish_host(board, labels, conf)
         return board, labels
 

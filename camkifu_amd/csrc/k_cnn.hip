@@ -217,6 +217,129 @@ __global__ __launch_bounds__(64 * WAVES_M * cdiv(COUT, 32)) void conv_mfma_f32_k
 }
 
 // ------------------------------------------------------------------------------------------
+// The 3x3 layers (14x14 and 12x12 outputs, 90 channels) tile badly in 32x32 blocks (196 and
+// 144 pixels, 90 -> 96 channels: up to 28 % padding and 3-wave workgroups that leave SIMDs
+// idle), so they run on v_mfma_f32_16x16x4_f32: 16-pixel x 16-channel tiles, one wave per
+// 16-channel column owning all R pixel tiles of the patch (6 waves per workgroup).
+//   in : [patch][H][W][CIN] f32          wc : [KH*KW*CINP][COUTP] f32 (CINP = CIN rounded up to 4,
+//   out: POOL ? [patch][OH/2*OW/2][COUT] : [patch][OH*OW][COUT]          zero rows for padding)
+// With POOL the 16 rows of a tile are four 2x2 pooling windows (row 4q+e = window q, corner e):
+// the four accumulator registers of a lane are exactly one window, so max-pooling is in-lane.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int H, int W, int CIN, int KH, int KW, int COUT, int R, bool POOL>
+__global__ __launch_bounds__(64 * cdiv(COUT, 16)) void conv_mfma16_f32_kernel(
+    const float* __restrict__ in, const float* __restrict__ wc, const float* __restrict__ bias,
+    float* __restrict__ out)
+{
+#pragma clang fp contract(off)
+    constexpr int OH = H - KH + 1, OW = W - KW + 1, M = OH * OW;
+    constexpr int NT = cdiv(COUT, 16), COUTP = cdiv(COUT, 32) * 32;
+    constexpr int CINP = cdiv(CIN, 4) * 4;
+    constexpr int CS = (CINP % 2 == 0) ? CINP + 1 : CINP;
+    constexpr int KS = KH * KW * (CINP / 4);
+    constexpr int NTHREADS = 64 * NT;
+    static_assert(R * 16 >= M, "one wave owns every pixel tile of the patch");
+    static_assert(!POOL || (OW % 2 == 0 && OH % 2 == 0 && M % 16 == 0), "pooling windows must fill the tiles");
+    __shared__ float lds[H * W * CS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int patch = blockIdx.x;
+
+    {
+        const float* g = in + (size_t)patch * H * W * CIN;
+        if constexpr (CIN % 2 == 0) {
+            const float2* g2 = reinterpret_cast<const float2*>(g);
+#pragma unroll 4
+            for (int i = tid; i < H * W * CIN / 2; i += NTHREADS) {
+                const int pxl = i / (CIN / 2), c = i % (CIN / 2);
+                const float2 v = g2[i];
+                lds[pxl * CS + 2 * c] = v.x;
+                lds[pxl * CS + 2 * c + 1] = v.y;
+            }
+        } else {
+            for (int i = tid; i < H * W * CIN; i += NTHREADS) lds[(i / CIN) * CS + i % CIN] = g[i];
+        }
+        if constexpr (CINP > CIN)
+            for (int i = tid; i < H * W * (CINP - CIN); i += NTHREADS)
+                lds[(i / (CINP - CIN)) * CS + CIN + i % (CINP - CIN)] = 0.f;
+    }
+    __syncthreads();
+
+    int abase[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int oy, ox;
+        if constexpr (POOL) {
+            const int win = 4 * r + (l15 >> 2), sub = l15 & 3;
+            oy = 2 * (win / (OW / 2)) + (sub >> 1);
+            ox = 2 * (win % (OW / 2)) + (sub & 1);
+        } else {
+            int m = r * 16 + l15;
+            if (m > M - 1) m = M - 1;
+            oy = m / OW; ox = m % OW;
+        }
+        abase[r] = (oy * W + ox) * CS + kq;
+    }
+    f32x4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[r][e] = 0.f;
+
+    constexpr int PF = 12;
+    const float* wp = wc + (size_t)kq * COUTP + wn * 16 + l15;
+    float bq[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) bq[u] = u < KS ? wp[(size_t)(4 * u) * COUTP] : 0.f;
+#pragma unroll
+    for (int i = 0; i < KH; i++) {
+#pragma unroll
+        for (int j = 0; j < KW; j++) {
+#pragma unroll
+            for (int cc = 0; cc < CINP / 4; cc++) {
+                const int step = (i * KW + j) * (CINP / 4) + cc;
+                const float b = bq[step % PF];
+                if (step + PF < KS) bq[step % PF] = wp[(size_t)(4 * (step + PF)) * COUTP];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const float a = lds[abase[r] + (i * W + j) * CS + 4 * cc];
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[r], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const int co = wn * 16 + l15;
+    const float bv = co < COUT ? bias[co] : 0.f;
+    if constexpr (POOL) {
+        float* o = out + (size_t)patch * (M / 4) * COUT;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            float mx = acc[r][0] > acc[r][1] ? acc[r][0] : acc[r][1];
+            const float m2 = acc[r][2] > acc[r][3] ? acc[r][2] : acc[r][3];
+            mx = mx > m2 ? mx : m2;
+            mx = mx + bv;                     // max commutes with the (monotone) bias add and relu
+            mx = mx > 0.f ? mx : 0.f;
+            if (co < COUT) o[(size_t)(4 * r + kq) * COUT + co] = mx;
+        }
+    } else {
+        float* o = out + (size_t)patch * M * COUT;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int m = r * 16 + 4 * kq + e;
+                float v = acc[r][e] + bv;
+                v = v > 0.f ? v : 0.f;
+                if (m < M && co < COUT) o[(size_t)m * COUT + co] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // bf16 mode (CK_CNN_BF16): same implicit GEMM on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
 //   in : [patch][H][W][CINP] bf16, CINP a multiple of 16 (padding channels are zero)
 //   wt : [COUTS][KH*KW*CINP] bf16 -- one contiguous K vector per output channel, so a lane's
@@ -509,16 +632,19 @@ __global__ __launch_bounds__(128) void decode_kernel(const float* __restrict__ y
 }
 }  // namespace
 
-static void flip_pack(const float* k, int KH, int KW, int CIN, int COUT, std::vector<float>& dst)
+// correlation-layout pack: row (i*KW + j)*CINP + c, COUT padded to a multiple of 32; the rows of
+// padding channels (c >= CIN) and the odd tail row stay zero
+static void flip_pack(const float* k, int KH, int KW, int CIN, int COUT, std::vector<float>& dst, int CINP = 0)
 {
+    if (CINP == 0) CINP = CIN;
     const int NT = (COUT + 31) / 32, COUTP = NT * 32;
-    const int K = KH * KW * CIN, KS2 = ((K + 1) / 2) * 2;
+    const int K = KH * KW * CINP, KS2 = ((K + 1) / 2) * 2;
     dst.assign((size_t)KS2 * COUTP, 0.f);
     for (int i = 0; i < KH; i++)
         for (int j = 0; j < KW; j++)
             for (int c = 0; c < CIN; c++)
                 for (int o = 0; o < COUT; o++)
-                    dst[(size_t)((i * KW + j) * CIN + c) * COUTP + o] =
+                    dst[(size_t)((i * KW + j) * CINP + c) * COUTP + o] =
                         k[(((size_t)(KH - 1 - i) * KW + (KW - 1 - j)) * CIN + c) * COUT + o];
 }
 
@@ -542,7 +668,7 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
     flip_pack(host[0].data(), 5, 5, 3, 32, t);  CK_TRY(up(ctx->cnn.c1w, t));
     flip_pack(host[2].data(), 5, 5, 32, 32, t); CK_TRY(up(ctx->cnn.c2w, t));
     flip_pack(host[4].data(), 3, 3, 32, 90, t); CK_TRY(up(ctx->cnn.c3w, t));
-    flip_pack(host[6].data(), 3, 3, 90, 90, t); CK_TRY(up(ctx->cnn.c4w, t));
+    flip_pack(host[6].data(), 3, 3, 90, 90, t, 92); CK_TRY(up(ctx->cnn.c4w, t));
     CK_TRY(up(ctx->cnn.c1b, host[1])); CK_TRY(up(ctx->cnn.c2b, host[3]));
     CK_TRY(up(ctx->cnn.c3b, host[5])); CK_TRY(up(ctx->cnn.c4b, host[7]));
     CK_TRY(up(ctx->cnn.d1w, host[8])); CK_TRY(up(ctx->cnn.d1b, host[9]));
@@ -660,18 +786,16 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         float* a3 = a1;
         {
             TimeScope ts(ctx, "cnn_conv3");
-            // 7 M tiles x 3 N tiles: 6 waves = (4 + 3 tiles) x 3 N tiles
-            hipLaunchKernelGGL((conv_mfma_f32_kernel<16, 16, 32, 3, 3, 90, 4, 2, false, false>), dim3(np, 1), dim3(384), 0,
-                               ctx->stream, (const void*)p2, (const float*)W.c3w.p, (const float*)W.c3b.p, a3);
+            // 13 pixel tiles x 6 channel tiles of 16
+            hipLaunchKernelGGL((conv_mfma16_f32_kernel<16, 16, 32, 3, 3, 90, 13, false>), dim3(np), dim3(384), 0,
+                               ctx->stream, (const float*)p2, (const float*)W.c3w.p, (const float*)W.c3b.p, a3);
         }
-        float* a4 = p2;
+
         {
             TimeScope ts(ctx, "cnn_conv4");
-            hipLaunchKernelGGL((conv_mfma_f32_kernel<14, 14, 90, 3, 3, 90, 5, 1, false, false>), dim3(np, 1), dim3(192), 0,
-                               ctx->stream, (const void*)a3, (const float*)W.c4w.p, (const float*)W.c4b.p, a4);
-            const size_t total = (size_t)np * 6 * 6 * 90;
-            hipLaunchKernelGGL(pool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const float*)a4, 12, 12, 90, p4, total);
+            // 9 tiles of four pooling windows x 6 channel tiles; pooled 6x6x90 written directly
+            hipLaunchKernelGGL((conv_mfma16_f32_kernel<14, 14, 90, 3, 3, 90, 9, true>), dim3(np), dim3(384), 0,
+                               ctx->stream, (const float*)a3, (const float*)W.c4w.p, (const float*)W.c4b.p, p4);
         }
         CK_HIP(ctx, hipGetLastError());
     }
