@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libck_hip.so")
+# CK_HIP_LIB: developer override used to A/B kernel variants (tools/ab_variant.sh); never set in production
+SO_PATH = os.environ.get("CK_HIP_LIB") or os.path.join(_HERE, "libck_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 CK_HOST, CK_DEVICE = 0, 1

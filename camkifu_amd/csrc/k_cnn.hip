@@ -17,8 +17,20 @@
 
 #include "ck_common.h"
 
-#ifndef UNROLL_CC
-#define UNROLL_CC 16
+#ifndef C3_WM
+#define C3_WM 2
+#endif
+#ifndef C4_WM
+#define C4_WM 2
+#endif
+#ifndef C2_TB
+#define C2_TB 16
+#endif
+#ifndef C2_WM
+#define C2_WM 4
+#endif
+#ifndef C2_RN
+#define C2_RN 1
 #endif
 
 #pragma clang fp contract(off)
@@ -221,119 +233,188 @@ __global__ __launch_bounds__(64 * WAVES_M * cdiv(COUT, 32)) void conv_mfma_f32_k
 // 144 pixels, 90 -> 96 channels: up to 28 % padding and 3-wave workgroups that leave SIMDs
 // idle), so they run on v_mfma_f32_16x16x4_f32: 16-pixel x 16-channel tiles, one wave per
 // 16-channel column owning all R pixel tiles of the patch (6 waves per workgroup).
-//   in : [patch][H][W][CIN] f32          wc : [KH*KW*CINP][COUTP] f32 (CINP = CIN rounded up to 4,
-//   out: POOL ? [patch][OH/2*OW/2][COUT] : [patch][OH*OW][COUT]          zero rows for padding)
-// With POOL the 16 rows of a tile are four 2x2 pooling windows (row 4q+e = window q, corner e):
-// the four accumulator registers of a lane are exactly one window, so max-pooling is in-lane.
+//   in : [patch][H][W][CIN] f32
+//   wc : [channel tile][group of 4 k-steps][lane][4] f32 (pack_mfma16: the B fragment lane (k-slot, column)
+//        needs for k-step 4g+e is element e; K = (kh, kw, cin padded to 4), zero padded)
+//   out: POOL ? [patch][OH/2*OW/2][COUT] : [patch][OH*OW][COUT]
+// With POOL a tile is a 4x4 block of output pixels = four 2x2 pooling windows (tile row 4q+e =
+// window q, corner e): the four accumulator registers of a lane are exactly one window, so
+// max-pooling is in-lane.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int H, int W, int CIN, int KH, int KW, int COUT, int R, bool POOL>
-__global__ __launch_bounds__(64 * cdiv(COUT, 16)) void conv_mfma16_f32_kernel(
+// smallest stride >= n with stride = rem (mod 32)
+__host__ __device__ constexpr int lds_stride(int n, int rem) { return n + ((rem - n % 32) + 32) % 32; }
+
+template <int H, int W, int CIN, int KH, int KW, int COUT, int TB, int YB, int WAVES_M, int RN, bool POOL>
+__global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfma16_f32_kernel(
     const float* __restrict__ in, const float* __restrict__ wc, const float* __restrict__ bias,
     float* __restrict__ out)
 {
 #pragma clang fp contract(off)
     constexpr int OH = H - KH + 1, OW = W - KW + 1, M = OH * OW;
-    constexpr int NT = cdiv(COUT, 16), COUTP = cdiv(COUT, 32) * 32;
+    constexpr int NT = cdiv(COUT, 16), WAVES_N = NT / RN;
     constexpr int CINP = cdiv(CIN, 4) * 4;
-    constexpr int CS = (CINP % 2 == 0) ? CINP + 1 : CINP;
-    constexpr int KS = KH * KW * (CINP / 4);
-    constexpr int NTHREADS = 64 * NT;
-    static_assert(R * 16 >= M, "one wave owns every pixel tile of the patch");
-    static_assert(!POOL || (OW % 2 == 0 && OH % 2 == 0 && M % 16 == 0), "pooling windows must fill the tiles");
-    __shared__ float lds[H * W * CS];
+    // LDS layout [row][col][channel] with pixel stride CS = 2 (mod 32) dwords and row stride RS chosen so
+    // that the 16 pixels x 2 k-slots a half-wave reads in one ds_read_b32 fall on 32 distinct banks:
+    //   plain tiles (16 consecutive output pixels, wrapping rows):  bank = 2*m + k      -> RS = 2*OW (mod 32)
+    //   pooling tiles (4 x 4 output pixels):                        bank = 2*col + 8*row + k -> RS = 8 (mod 32)
+    constexpr int CS = lds_stride(CINP, 2);
+    constexpr int RS = lds_stride(W * CS, POOL ? 8 : (2 * OW) % 32);
+    constexpr int KS = KH * KW * (CINP / 4), SG = cdiv(KS, 4);
+    constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
+    constexpr int R = cdiv(TB, WAVES_M);               // pixel tiles per wave (the last wave row may own R-1)
+    constexpr int RT = POOL ? (OH / 4) * (OW / 4) : cdiv(M, 16);       // tiles per patch
+    static_assert(NT % RN == 0, "channel tiles split evenly over the waves");
+    static_assert(TB * YB >= RT, "the grid owns every pixel tile of the patch");
+    static_assert(R * WAVES_M - TB <= 1, "uneven split handled for one missing tile only");
+    static_assert(!POOL || (OW % 4 == 0 && OH % 4 == 0 && TB % (OW / 4) == 0), "pooling tiles are 4x4 output pixels, whole tile rows per block");
+    // input rows one workgroup can touch
+    constexpr int ROWS_RAW = POOL ? 4 * (TB / (OW / 4)) + KH - 1 : (TB * 16 + OW - 2) / OW + 1 + KH - 1;
+    constexpr int ROWS = ROWS_RAW < H ? ROWS_RAW : H;
+    __shared__ float lds[ROWS * RS];
 
-    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WAVES_N, wm = wave / WAVES_N;
     const int l15 = lane & 15, kq = lane >> 4;
     const int patch = blockIdx.x;
+    const int tile_blk = blockIdx.y * TB;
+    const int oy_min = POOL ? 4 * (tile_blk / (OW / 4)) : (tile_blk * 16) / OW;
+    int row_cnt = H - oy_min;
+    if (row_cnt > ROWS) row_cnt = ROWS;
 
     {
-        const float* g = in + (size_t)patch * H * W * CIN;
-        if constexpr (CIN % 2 == 0) {
+        const float* g = in + ((size_t)patch * H + oy_min) * W * CIN;
+        if constexpr (CIN % 4 == 0) {
+            const float4* g4 = reinterpret_cast<const float4*>(g);
+#pragma unroll 4
+            for (int i = tid; i < row_cnt * W * (CIN / 4); i += NTHREADS) {
+                const int pxl = i / (CIN / 4), c = i % (CIN / 4);
+                const float4 v = g4[i];
+                float* d = &lds[(pxl / W) * RS + (pxl % W) * CS + 4 * c];     // 8-byte aligned (CS, RS even)
+                *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+            }
+        } else if constexpr (CIN % 2 == 0) {
             const float2* g2 = reinterpret_cast<const float2*>(g);
 #pragma unroll 4
-            for (int i = tid; i < H * W * CIN / 2; i += NTHREADS) {
+            for (int i = tid; i < row_cnt * W * (CIN / 2); i += NTHREADS) {
                 const int pxl = i / (CIN / 2), c = i % (CIN / 2);
                 const float2 v = g2[i];
-                lds[pxl * CS + 2 * c] = v.x;
-                lds[pxl * CS + 2 * c + 1] = v.y;
+                *reinterpret_cast<float2*>(&lds[(pxl / W) * RS + (pxl % W) * CS + 2 * c]) = v;
             }
         } else {
-            for (int i = tid; i < H * W * CIN; i += NTHREADS) lds[(i / CIN) * CS + i % CIN] = g[i];
+            for (int i = tid; i < row_cnt * W * CIN; i += NTHREADS) {
+                const int pxl = i / CIN;
+                lds[(pxl / W) * RS + (pxl % W) * CS + i % CIN] = g[i];
+            }
         }
         if constexpr (CINP > CIN)
-            for (int i = tid; i < H * W * (CINP - CIN); i += NTHREADS)
-                lds[(i / (CINP - CIN)) * CS + CIN + i % (CINP - CIN)] = 0.f;
+            for (int i = tid; i < row_cnt * W * (CINP - CIN); i += NTHREADS) {
+                const int pxl = i / (CINP - CIN);
+                lds[(pxl / W) * RS + (pxl % W) * CS + CIN + i % (CINP - CIN)] = 0.f;
+            }
     }
     __syncthreads();
 
+    const int tile0 = tile_blk + wm * R;
     int abase[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
+        int t = tile0 + r;
+        if (t > RT - 1) t = RT - 1;
         int oy, ox;
         if constexpr (POOL) {
-            const int win = 4 * r + (l15 >> 2), sub = l15 & 3;
-            oy = 2 * (win / (OW / 2)) + (sub >> 1);
-            ox = 2 * (win % (OW / 2)) + (sub & 1);
+            // tile t = 4x4 output pixels = 2x2 pooling windows; tile row 4q+e = window q, corner e
+            const int ty = t / (OW / 4), tx = t % (OW / 4), q = l15 >> 2, sub = l15 & 3;
+            oy = 4 * ty + 2 * (q >> 1) + (sub >> 1);
+            ox = 4 * tx + 2 * (q & 1) + (sub & 1);
         } else {
-            int m = r * 16 + l15;
+            int m = t * 16 + l15;
             if (m > M - 1) m = M - 1;
             oy = m / OW; ox = m % OW;
         }
-        abase[r] = (oy * W + ox) * CS + kq;
+        abase[r] = (oy - oy_min) * RS + ox * CS + kq;
     }
-    f32x4 acc[R];
+    f32x4 acc[R][RN];
 #pragma unroll
     for (int r = 0; r < R; r++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) acc[r][e] = 0.f;
+        for (int n = 0; n < RN; n++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[r][n][e] = 0.f;
 
-    constexpr int PF = 12;
-    const float* wp = wc + (size_t)kq * COUTP + wn * 16 + l15;
-    float bq[PF];
+    // real tiles of this wave (wave-uniform): all R, or R-1 for the last wave row of an uneven split
+    int nv = TB - wm * R;
+    nv = nv > R ? R : nv;
+    const float4* wq = reinterpret_cast<const float4*>(wc) + (size_t)(wn * RN) * SG * 64 + lane;
+    auto k_loop = [&](auto nv_tag) {
+        constexpr int NV = decltype(nv_tag)::value;
+        // one dwordx4 load per lane brings the B fragments of four consecutive k-steps (fully coalesced,
+        // 1 KB per wave); the loads run PFG groups ahead of the MFMAs through a register ring with
+        // compile-time indices
+        constexpr int PFG = 3;
+        float4 bq[PFG][RN];
 #pragma unroll
-    for (int u = 0; u < PF; u++) bq[u] = u < KS ? wp[(size_t)(4 * u) * COUTP] : 0.f;
+        for (int u = 0; u < PFG; u++)
 #pragma unroll
-    for (int i = 0; i < KH; i++) {
+            for (int n = 0; n < RN; n++) bq[u][n] = u < SG ? wq[((size_t)n * SG + u) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < KW; j++) {
+        for (int i = 0; i < KH; i++) {
 #pragma unroll
-            for (int cc = 0; cc < CINP / 4; cc++) {
-                const int step = (i * KW + j) * (CINP / 4) + cc;
-                const float b = bq[step % PF];
-                if (step + PF < KS) bq[step % PF] = wp[(size_t)(4 * (step + PF)) * COUTP];
+            for (int j = 0; j < KW; j++) {
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const float a = lds[abase[r] + (i * W + j) * CS + 4 * cc];
-                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[r], 0, 0, 0);
+                for (int cc = 0; cc < CINP / 4; cc++) {
+                    const int step = (i * KW + j) * (CINP / 4) + cc;
+                    const int g = step / 4, e = step % 4;
+                    float b[RN];
+#pragma unroll
+                    for (int n = 0; n < RN; n++) {
+                        const float4 q = bq[g % PFG][n];
+                        b[n] = e == 0 ? q.x : e == 1 ? q.y : e == 2 ? q.z : q.w;
+                        if ((e == 3 || step == KS - 1) && g + PFG < SG) bq[g % PFG][n] = wq[((size_t)n * SG + g + PFG) * 64];
+                    }
+#pragma unroll
+                    for (int r = 0; r < NV; r++) {
+                        const float a = lds[abase[r] + i * RS + j * CS + 4 * cc];
+#pragma unroll
+                        for (int n = 0; n < RN; n++)
+                            acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc[r][n], 0, 0, 0);
+                    }
                 }
             }
         }
-    }
+    };
+    if (nv == R) k_loop(std::integral_constant<int, R>{});
+    else if constexpr (R * WAVES_M > TB) k_loop(std::integral_constant<int, R - 1>{});
 
-    const int co = wn * 16 + l15;
-    const float bv = co < COUT ? bias[co] : 0.f;
-    if constexpr (POOL) {
-        float* o = out + (size_t)patch * (M / 4) * COUT;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            float mx = acc[r][0] > acc[r][1] ? acc[r][0] : acc[r][1];
-            const float m2 = acc[r][2] > acc[r][3] ? acc[r][2] : acc[r][3];
-            mx = mx > m2 ? mx : m2;
-            mx = mx + bv;                     // max commutes with the (monotone) bias add and relu
-            mx = mx > 0.f ? mx : 0.f;
-            if (co < COUT) o[(size_t)(4 * r + kq) * COUT + co] = mx;
-        }
-    } else {
-        float* o = out + (size_t)patch * M * COUT;
+    for (int n = 0; n < RN; n++) {
+        const int co = (wn * RN + n) * 16 + l15;
+        const float bv = co < COUT ? bias[co] : 0.f;
+        if constexpr (POOL) {
+            float* o = out + (size_t)patch * (M / 4) * COUT;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
+            for (int r = 0; r < R; r++) {
+                const int t = tile0 + r;
+                float mx = acc[r][n][0] > acc[r][n][1] ? acc[r][n][0] : acc[r][n][1];
+                const float m2 = acc[r][n][2] > acc[r][n][3] ? acc[r][n][2] : acc[r][n][3];
+                mx = mx > m2 ? mx : m2;
+                mx = mx + bv;                     // max commutes with the (monotone) bias add and relu
+                mx = mx > 0.f ? mx : 0.f;
+                const int py = 2 * (t / (OW / 4)) + (kq >> 1), px = 2 * (t % (OW / 4)) + (kq & 1);
+                if (r < nv && t < RT && co < COUT) o[(size_t)(py * (OW / 2) + px) * COUT + co] = mx;
+            }
+        } else {
+            float* o = out + (size_t)patch * M * COUT;
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int m = r * 16 + 4 * kq + e;
-                float v = acc[r][e] + bv;
-                v = v > 0.f ? v : 0.f;
-                if (m < M && co < COUT) o[(size_t)m * COUT + co] = v;
+            for (int r = 0; r < R; r++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int m = (tile0 + r) * 16 + 4 * kq + e;
+                    float v = acc[r][n][e] + bv;
+                    v = v > 0.f ? v : 0.f;
+                    if (r < nv && m < M && co < COUT) o[(size_t)m * COUT + co] = v;
+                }
             }
         }
     }
@@ -648,6 +729,23 @@ static void flip_pack(const float* k, int KH, int KW, int CIN, int COUT, std::ve
                         k[(((size_t)(KH - 1 - i) * KW + (KW - 1 - j)) * CIN + c) * COUT + o];
 }
 
+// B operand pack of conv_mfma16_f32_kernel: [channel tile of 16][group of 4 k-steps][lane = kslot*16 + col][4]
+// with K = (kh, kw, cin padded to a multiple of 4) and k = 4*step + kslot; flip applied, padding zero
+static void pack_mfma16(const float* k, int KH, int KW, int CIN, int COUT, std::vector<float>& dst)
+{
+    const int CINP = (CIN + 3) / 4 * 4, KS = KH * KW * CINP / 4, SG = (KS + 3) / 4, NT = (COUT + 15) / 16;
+    dst.assign((size_t)NT * SG * 64 * 4, 0.f);
+    for (int nt = 0; nt < NT; nt++)
+        for (int step = 0; step < KS; step++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int kidx = 4 * step + lane / 16, ij = kidx / CINP, c = kidx % CINP, o = nt * 16 + lane % 16;
+                if (c >= CIN || o >= COUT) continue;
+                const int i = ij / KW, j = ij % KW;
+                dst[(((size_t)nt * SG + step / 4) * 64 + lane) * 4 + step % 4] =
+                    k[(((size_t)(KH - 1 - i) * KW + (KW - 1 - j)) * CIN + c) * COUT + o];
+            }
+}
+
 int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
 {
     static const size_t counts[12] = { 5 * 5 * 3 * 32, 32, 5 * 5 * 32 * 32, 32, 3 * 3 * 32 * 90, 90,
@@ -666,9 +764,9 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
     };
     std::vector<float> t;
     flip_pack(host[0].data(), 5, 5, 3, 32, t);  CK_TRY(up(ctx->cnn.c1w, t));
-    flip_pack(host[2].data(), 5, 5, 32, 32, t); CK_TRY(up(ctx->cnn.c2w, t));
-    flip_pack(host[4].data(), 3, 3, 32, 90, t); CK_TRY(up(ctx->cnn.c3w, t));
-    flip_pack(host[6].data(), 3, 3, 90, 90, t, 92); CK_TRY(up(ctx->cnn.c4w, t));
+    pack_mfma16(host[2].data(), 5, 5, 32, 32, t); CK_TRY(up(ctx->cnn.c2w, t));
+    pack_mfma16(host[4].data(), 3, 3, 32, 90, t); CK_TRY(up(ctx->cnn.c3w, t));
+    pack_mfma16(host[6].data(), 3, 3, 90, 90, t); CK_TRY(up(ctx->cnn.c4w, t));
     CK_TRY(up(ctx->cnn.c1b, host[1])); CK_TRY(up(ctx->cnn.c2b, host[3]));
     CK_TRY(up(ctx->cnn.c3b, host[5])); CK_TRY(up(ctx->cnn.c4b, host[7]));
     CK_TRY(up(ctx->cnn.d1w, host[8])); CK_TRY(up(ctx->cnn.d1b, host[9]));
@@ -780,21 +878,23 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         {
             TimeScope ts(ctx, "cnn_conv2");
             // 32 rows: 4 groups of (4 waves x 2 rows), pooled output 16x16x32
-            hipLaunchKernelGGL((conv_mfma_f32_kernel<36, 36, 32, 5, 5, 32, 2, 4, false, true>), dim3(np, 4), dim3(256), 0,
-                               ctx->stream, (const void*)a1, (const float*)W.c2w.p, (const float*)W.c2b.p, p2);
+            // 8x8 pooling tiles of 4x4 pixels: workgroups of whole tile rows, pooled output 16x16x32
+            hipLaunchKernelGGL((conv_mfma16_f32_kernel<36, 36, 32, 5, 5, 32, C2_TB, 64 / C2_TB, C2_WM, C2_RN, true>), dim3(np, 64 / C2_TB),
+                               dim3(64 * C2_WM * (2 / C2_RN)), 0, ctx->stream, (const float*)a1, (const float*)W.c2w.p,
+                               (const float*)W.c2b.p, p2);
         }
         float* a3 = a1;
         {
             TimeScope ts(ctx, "cnn_conv3");
             // 13 pixel tiles x 6 channel tiles of 16
-            hipLaunchKernelGGL((conv_mfma16_f32_kernel<16, 16, 32, 3, 3, 90, 13, false>), dim3(np), dim3(384), 0,
+            hipLaunchKernelGGL((conv_mfma16_f32_kernel<16, 16, 32, 3, 3, 90, 13, 1, C3_WM, 1, false>), dim3(np), dim3(384 * C3_WM), 0,
                                ctx->stream, (const float*)p2, (const float*)W.c3w.p, (const float*)W.c3b.p, a3);
         }
 
         {
             TimeScope ts(ctx, "cnn_conv4");
             // 9 tiles of four pooling windows x 6 channel tiles; pooled 6x6x90 written directly
-            hipLaunchKernelGGL((conv_mfma16_f32_kernel<14, 14, 90, 3, 3, 90, 9, true>), dim3(np), dim3(384), 0,
+            hipLaunchKernelGGL((conv_mfma16_f32_kernel<14, 14, 90, 3, 3, 90, 9, 1, C4_WM, 1, true>), dim3(np), dim3(384 * C4_WM), 0,
                                ctx->stream, (const float*)a3, (const float*)W.c4w.p, (const float*)W.c4b.p, p4);
         }
         CK_HIP(ctx, hipGetLastError());
