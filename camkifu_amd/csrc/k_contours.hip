@@ -151,6 +151,86 @@ __global__ __launch_bounds__(256) void prep_rows4_kernel(const uint8_t* __restri
     }
 }
 
+// Rows of up to 256*NS pixels, fully unrolled: all NS dword loads of the row are in flight at
+// once and the row takes ONE atomic on the frame's edge counter (the loop version above pays a
+// load round trip and an atomic per 256 pixels).
+template <int NS>
+__global__ __launch_bounds__(256) void prep_rows4u_kernel(const uint8_t* __restrict__ edges, int h, int w,
+                                                          uint8_t* __restrict__ ez, int32_t* __restrict__ L,
+                                                          FrameTab* __restrict__ tab, int32_t* __restrict__ elist)
+{
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int f = blockIdx.y;
+    if (y >= h) return;                                  // whole wave leaves together
+    const size_t off = ((size_t)f * h + y) * w;
+    const bool row_inner = y > 0 && y < h - 1;
+    int32_t* E = elist + (size_t)f * h * w;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t v[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int x = 256 * s + 4 * lane;
+        v[s] = 0;
+        if (x < w && row_inner) v[s] = *reinterpret_cast<const uint32_t*>(edges + off + x);
+    }
+    int nib[NS], before[NS];          // before: edge pixels of this row in earlier lanes / steps
+    unsigned long long has[NS];
+    int total = 0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int x = 256 * s + 4 * lane;
+        int nb = ((v[s] & 0xFFu) ? 1 : 0) | ((v[s] & 0xFF00u) ? 2 : 0) | ((v[s] & 0xFF0000u) ? 4 : 0) | ((v[s] & 0xFF000000u) ? 8 : 0);
+        if (x == 0) nb &= ~1;                            // cleared frame: first and last column
+        if (x + 3 == w - 1) nb &= ~8;
+        nib[s] = nb;
+        has[s] = __builtin_amdgcn_ballot_w64(nb != 0);
+        before[s] = total;
+        if (has[s]) {                                    // wave-uniform
+            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(nb & 1), b1 = __builtin_amdgcn_ballot_w64(nb & 2);
+            const unsigned long long b2 = __builtin_amdgcn_ballot_w64(nb & 4), b3 = __builtin_amdgcn_ballot_w64(nb & 8);
+            before[s] += __builtin_popcountll(b0 & lt) + __builtin_popcountll(b1 & lt) +
+                         __builtin_popcountll(b2 & lt) + __builtin_popcountll(b3 & lt);
+            total += __builtin_popcountll(b0) + __builtin_popcountll(b1) + __builtin_popcountll(b2) + __builtin_popcountll(b3);
+        }
+    }
+    int base = 0;
+    if (total) {
+        if (lane == 0) base = atomicAdd(&tab[f].n_edges, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+    }
+    int last_edge = -1;                                  // wave-uniform: last edge column of earlier steps
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int x = 256 * s + 4 * lane;
+        const int nb = nib[s];
+        const int my_last = nb ? x + 31 - __builtin_clz((unsigned)nb) : -1;
+        const unsigned long long below = has[s] & lt;
+        const int src = below ? 63 - __builtin_clzll(below) : 0;
+        int prev_last = __shfl(my_last, src);
+        if (!below) prev_last = last_edge;
+        if (x < w) {
+            *reinterpret_cast<uint32_t*>(ez + off + x) =
+                (nb & 1 ? 1u : 0u) | (nb & 2 ? 0x100u : 0u) | (nb & 4 ? 0x10000u : 0u) | (nb & 8 ? 0x1000000u : 0u);
+            int4 par;
+            int le = prev_last;
+            par.x = (nb & 1) ? y * w + x : y * w + le + 1;
+            if (nb & 1) le = x;
+            par.y = (nb & 2) ? y * w + x + 1 : y * w + le + 1;
+            if (nb & 2) le = x + 1;
+            par.z = (nb & 4) ? y * w + x + 2 : y * w + le + 1;
+            if (nb & 4) le = x + 2;
+            par.w = (nb & 8) ? y * w + x + 3 : y * w + le + 1;
+            *reinterpret_cast<int4*>(L + off + x) = par;
+            int slot = base + before[s];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (nb & (1 << k)) E[slot++] = y * w + x + k;
+        }
+        if (has[s]) last_edge = __shfl(my_last, 63 - __builtin_clzll(has[s]));
+    }
+}
+
 // ---- B. unions: edge pixels (8-connectivity) and background runs (4-connectivity) -------
 // Work items: every edge pixel, plus one item per image row for the run that starts at x = 0.
 // A stretch of columns where this row and the row above are both background starts either at
@@ -508,7 +588,14 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         TimeScope ts(ctx, "ccl");
         CK_HIP(ctx, hipMemsetAsync(d_tab, 0, tab_bytes, ctx->stream));
         // the dword path needs 4-byte aligned rows: w % 4 == 0 and an aligned base pointer
-        if ((w & 3) == 0 && ((uintptr_t)d_edges & 3) == 0)
+        const bool dwords = (w & 3) == 0 && ((uintptr_t)d_edges & 3) == 0;
+        if (dwords && w <= 1024)
+            hipLaunchKernelGGL(prep_rows4u_kernel<4>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
+        else if (dwords && w <= 2048)
+            hipLaunchKernelGGL(prep_rows4u_kernel<8>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
+        else if (dwords && w <= 4096)
+            hipLaunchKernelGGL(prep_rows4u_kernel<16>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
+        else if (dwords)
             hipLaunchKernelGGL(prep_rows4_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
         else
             hipLaunchKernelGGL(prep_rows_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
