@@ -5,13 +5,21 @@
 //
 // The four convolutions and the first dense layer are dense contractions and run on the
 // matrix cores as implicit GEMMs (M = output pixels, N = output channels, K = kh*kw*cin):
-//   fp32 mode: v_mfma_f32_32x32x2_f32 -- exact f32, and because one MFMA is a k-ordered fmaf
-//              chain, accumulating K in (kh, kw, cin) order reproduces the scalar CPU chain.
-// A (activations) is staged in LDS with the per-pixel channel stride padded to an odd number
-// of dwords (conflict-free ds_read_b32 for 32 consecutive pixels); B (weights) streams from
-// L2 and is reused by R register-blocked M tiles per wave.
-// Everything else (pooling, 160->81 dense, softmax, base-3 decode) is byte/float VALU work.
+//   fp32 mode: v_mfma_f32_16x16x4_f32 -- exact f32; K is accumulated in (kh, kw, cin) order like
+//              the scalar CPU chain.  16x16 tiles because (a) 196- and 144-pixel, 90-channel layers
+//              pad far less than in 32x32 tiles and (b) the 16x16x4 form sustains 155 TFLOP/s on
+//              this part against 138 for 32x32x2 (tools/micro/mfma_peak.hip).  f32 MFMA runs on the
+//              vector ALUs (same 157.3 TFLOP/s peak): it does not overlap VALU work of other waves
+//              (tools/micro/coexec.hip), so MFMA-bound and VALU-bound kernels simply add up.
+//   bf16 mode: v_mfma_f32_32x32x16_bf16, fp32 accumulate (conv1 stays f32: K = 75 is tiny).
+// A (activations) is staged in LDS with pixel / row strides chosen so that one ds_read_b32 of a
+// half-wave hits 32 distinct banks; B (weights) streams from L2 as coalesced dwordx4 fragments and
+// is reused by the R register-blocked pixel tiles of a wave.  Wave counts per workgroup are
+// multiples of 4 so every SIMD carries the same number of MFMA chains.
+// Everything else (160->81 dense, softmax, base-3 decode) is byte/float VALU work.
 #include <math.h>
+
+#include <algorithm>
 
 #include <type_traits>
 
@@ -22,6 +30,12 @@
 #endif
 #ifndef C4_WM
 #define C4_WM 2
+#endif
+#ifndef C1_R
+#define C1_R 3
+#endif
+#ifndef C1_GRID
+#define C1_GRID (256 * 3)      // persistent workgroups: three per CU
 #endif
 #ifndef C2_TB
 #define C2_TB 16
@@ -59,180 +73,9 @@ __device__ __forceinline__ float bf2f(uint16_t h)
 __device__ __forceinline__ int region_origin(int i) { return i == 9 ? 340 : 40 * i; }
 
 // ------------------------------------------------------------------------------------------
-// Implicit-GEMM valid convolution + bias + relu (+ optional fused 2x2 max-pool when OW == 32).
-//   in : U8IN ? goban images [frame][380][380][3] u8 (patch gathered on the fly)
-//              : activations [patch][H][W][CIN] f32
-//   wc : [KS*2][COUTP] f32, correlation layout (flip already applied), zero padded
-//   out: [patch][OH*OW or pooled][COUT] f32
-// Work split: blockIdx.x = patch, blockIdx.y = group of WAVES_M*R consecutive M tiles;
-// wave (wm, wn) owns R M-tiles x one 32-wide N tile.
-template <int H, int W, int CIN, int KH, int KW, int COUT, int R, int WAVES_M, bool U8IN, bool POOL, bool OUTBF = false>
-__global__ __launch_bounds__(64 * WAVES_M * cdiv(COUT, 32)) void conv_mfma_f32_kernel(
-    const void* __restrict__ in_, const float* __restrict__ wc, const float* __restrict__ bias,
-    float* __restrict__ out)
-{
-#pragma clang fp contract(off)
-    constexpr int OH = H - KH + 1, OW = W - KW + 1, M = OH * OW;
-    constexpr int NT = cdiv(COUT, 32), COUTP = NT * 32;
-    constexpr int K = KH * KW * CIN, KS = cdiv(K, 2);
-    constexpr int CS = (CIN % 2 == 0) ? CIN + 1 : CIN;            // odd dword stride per pixel
-    constexpr int TILES_WG = WAVES_M * R;
-    constexpr int ROWS = (TILES_WG * 32 + OW - 2) / OW + 1 + KH - 1;   // input rows a WG can touch
-    constexpr int ROWS_C = ROWS < H ? ROWS : H;
-    __shared__ float lds[ROWS_C * W * CS];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / NT, wn = wave % NT;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int patch = blockIdx.x;
-    const int m_wg0 = blockIdx.y * TILES_WG * 32;
-    const int oy_min = m_wg0 / OW;
-    int row_cnt = H - oy_min;
-    if (row_cnt > ROWS_C) row_cnt = ROWS_C;
-
-    // ---- stage the input rows this workgroup needs ---------------------------------------
-    constexpr int NTHREADS = 64 * WAVES_M * NT;
-    if constexpr (U8IN) {
-        const uint8_t* g = (const uint8_t*)in_;
-        const int frame = patch / 100, reg = patch % 100;
-        const int py0 = region_origin(reg / 10), px0 = region_origin(reg % 10);
-        const uint8_t* src = g + ((size_t)frame * 380 + py0) * 380 * 3 + (size_t)px0 * 3;
-        for (int i = tid; i < row_cnt * W * CIN; i += NTHREADS) {
-            const int r = i / (W * CIN), rem = i % (W * CIN);
-            lds[r * W * CS + rem] = (float)src[(size_t)(oy_min + r) * 380 * 3 + rem];   // CS == CIN == 3
-        }
-    } else {
-        const float* g = (const float*)in_ + (size_t)patch * H * W * CIN + (size_t)oy_min * W * CIN;
-        for (int i = tid; i < row_cnt * W * CIN; i += NTHREADS) {
-            const int pxl = i / CIN, c = i % CIN;
-            lds[pxl * CS + c] = g[i];
-        }
-    }
-    __syncthreads();
-
-    // ---- per-lane A base offsets for the R tiles ------------------------------------------
-    int abase[R];
-    const int tile0 = (blockIdx.y * WAVES_M + wm) * R;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        int m = (tile0 + r) * 32 + l31;
-        if (m > M - 1) m = M - 1;                    // padded rows recompute the last pixel
-        const int oy = m / OW, ox = m % OW;
-        abase[r] = ((oy - oy_min) * W + ox) * CS;
-    }
-    f32x16 acc[R];
-#pragma unroll
-    for (int r = 0; r < R; r++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[r][e] = 0.f;
-
-    const float* wcol = wc + wn * 32 + l31;
-    // number of real (non-padding) M tiles of this wave: wave-uniform; the K loop is
-    // instantiated per count so the MFMA stream stays branch-free
-    constexpr int MT = cdiv(M, 32);
-    int nv = MT - tile0;
-    nv = nv > R ? R : nv;
-    auto k_loop = [&](auto nv_tag) {
-        constexpr int NV = decltype(nv_tag)::value;
-        if constexpr (CIN % 2 == 0) {
-            // K = (kh, kw, cin) is walked in fully unrolled order, so the B row index is linear
-            // in the step (k = 2*step + hi) and the weight loads run PF steps ahead of the MFMAs
-            // through a register ring with compile-time indices: no vmcnt(0) drain at a seam
-            constexpr int PF = 12;
-            const float* wp = wcol + (size_t)hi * COUTP;
-            float bq[PF];
-#pragma unroll
-            for (int u = 0; u < PF; u++) bq[u] = u < KS ? wp[(size_t)(2 * u) * COUTP] : 0.f;
-#pragma unroll
-            for (int i = 0; i < KH; i++) {
-#pragma unroll
-                for (int j = 0; j < KW; j++) {
-                    const int aoff = (i * W + j) * CS + hi;
-#pragma unroll
-                    for (int cc = 0; cc < CIN / 2; cc++) {
-                        const int step = (i * KW + j) * (CIN / 2) + cc;
-                        const float b = bq[step % PF];
-                        if (step + PF < KS) bq[step % PF] = wp[(size_t)(2 * (step + PF)) * COUTP];
-#pragma unroll
-                        for (int r = 0; r < NV; r++) {
-                            const float a = lds[abase[r] + aoff + 2 * cc];
-                            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[r], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        } else {
-#pragma unroll 2
-            for (int s = 0; s < KS; s++) {
-                const int k = 2 * s + hi;
-                const int i = k / (KW * CIN), rem = k % (KW * CIN);
-                const int j = rem / CIN, c = rem % CIN;
-                const bool live = k < K;
-                const int aoff = live ? (i * W + j) * CS + c : 0;
-                const float b = wcol[(size_t)k * COUTP];
-#pragma unroll
-                for (int r = 0; r < NV; r++) {
-                    float a = lds[abase[r] + aoff];
-                    a = live ? a : 0.f;
-                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[r], 0, 0, 0);
-                }
-            }
-        }
-    };
-    if (nv >= R) k_loop(std::integral_constant<int, R>{});
-    else if constexpr (R > 1) {
-        if (nv == R - 1) k_loop(std::integral_constant<int, R - 1>{});
-        else if constexpr (R > 2) {
-            if (nv == R - 2) k_loop(std::integral_constant<int, R - 2>{});
-            else if constexpr (R > 3) { if (nv == R - 3) k_loop(std::integral_constant<int, R - 3>{}); }
-        }
-    }
-
-    // ---- epilogue: bias, relu, (pool), store ----------------------------------------------
-    const int co = wn * 32 + l31;
-    const float bv = co < COUT ? bias[co] : 0.f;
-    if constexpr (POOL) {
-        static_assert(!POOL || (OW == 32 && R % 2 == 0), "fused pooling needs one tile per output row");
-        constexpr int PW = OW / 2;
-        float* o = out + (size_t)patch * (OH / 2) * PW * COUT;
-#pragma unroll
-        for (int r = 0; r < R; r += 2) {
-            const int oy = tile0 + r;                      // tile index == output row
-            if (oy >= OH) continue;
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                const int ox = (e & 3) + 8 * (e >> 2) + 4 * hi;       // even
-                float v0 = acc[r][e] + bv, v1 = acc[r][e + 1] + bv;
-                float v2 = acc[r + 1][e] + bv, v3 = acc[r + 1][e + 1] + bv;
-                v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
-                v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
-                float mx = v0 > v1 ? v0 : v1; mx = mx > v2 ? mx : v2; mx = mx > v3 ? mx : v3;
-                if (co < COUT) o[((size_t)(oy / 2) * PW + ox / 2) * COUT + co] = mx;
-            }
-        }
-    } else {
-        float* o = out + (size_t)patch * M * COUT;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int m = (tile0 + r) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                float v = acc[r][e] + bv;
-                v = v > 0.f ? v : 0.f;
-                if (m < M && co < COUT) {
-                    if constexpr (OUTBF) reinterpret_cast<uint16_t*>(out)[((size_t)patch * M + m) * COUT + co] = f2bf(v);
-                    else o[(size_t)m * COUT + co] = v;
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// The 3x3 layers (14x14 and 12x12 outputs, 90 channels) tile badly in 32x32 blocks (196 and
-// 144 pixels, 90 -> 96 channels: up to 28 % padding and 3-wave workgroups that leave SIMDs
-// idle), so they run on v_mfma_f32_16x16x4_f32: 16-pixel x 16-channel tiles, one wave per
-// 16-channel column owning all R pixel tiles of the patch (6 waves per workgroup).
+// conv2..conv4: implicit-GEMM valid convolution + bias + relu (+ fused 2x2 max-pool) on
+// 16-pixel x 16-channel tiles.  blockIdx.x = patch, blockIdx.y = group of TB pixel tiles;
+// wave (wm, wn) owns R = TB / WAVES_M pixel tiles x RN channel tiles.
 //   in : [patch][H][W][CIN] f32
 //   wc : [channel tile][group of 4 k-steps][lane][4] f32 (pack_mfma16: the B fragment lane (k-slot, column)
 //        needs for k-step 4g+e is element e; K = (kh, kw, cin padded to 4), zero padded)
@@ -421,6 +264,125 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
 }
 
 // ------------------------------------------------------------------------------------------
+// conv1: 5x5x3 -> 32 on the raw 40x40 u8 patch (K10 gather fused: the patch is read straight
+// from the goban image), + bias + relu.  K = 75 is walked densely in (kh, kw, cin) order --
+// a kernel row is 15 consecutive floats of the staged [row][col*3 + c] image -- in 19 k-steps of
+// v_mfma_f32_16x16x4_f32 (k = 75 is a zero weight).  The operands are swapped relative to
+// conv_mfma16_f32_kernel (A = weights, B = pixels), so a lane's four accumulators are four
+// consecutive channels of one pixel and the result leaves as 16-byte stores.
+//   work unit = 12 output rows of one patch = 27 pixel tiles, WAVES waves x R tiles
+//   wf : [2 channel tiles][19 steps][64 lanes] f32 (pack_conv1)
+//   out: [patch][36*36][32] f32 (or bf16 when OUTBF)
+template <int R, bool OUTBF>
+__global__ __launch_bounds__(64 * (27 / R)) void conv1_mfma16_kernel(
+    const uint8_t* __restrict__ goban, const float* __restrict__ wf, const float* __restrict__ bias,
+    void* __restrict__ out_, int nunits)
+{
+#pragma clang fp contract(off)
+    constexpr int WAVES = 27 / R, NTHREADS = 64 * WAVES;
+    constexpr int OW = 36, ROWS = 16, RS = 140;           // RS = 12 (mod 32): a tile wrapping to the next row keeps its bank walk
+    static_assert(27 % R == 0, "27 tiles per work unit");
+    constexpr int NPT = cdiv(ROWS * 30, NTHREADS);       // dwords of the next unit each thread keeps in flight
+    __shared__ float lds[ROWS * RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+
+    // work unit = (patch, third of its output rows); persistent workgroups walk the units with
+    // the 16 x 120 input bytes of the NEXT unit already in flight (patch rows are 4-byte aligned in
+    // the goban image) while the current one is on the matrix cores
+    uint32_t raw[NPT];
+    auto fetch = [&](int unit) {
+#pragma unroll
+        for (int q = 0; q < NPT; q++) {
+            const int d = tid + q * NTHREADS;
+            raw[q] = 0u;
+            if (unit < nunits && d < ROWS * 30) {
+                const int patch = unit / 3, by = unit % 3;
+                const int frame = patch / 100, reg = patch % 100;
+                const int py0 = region_origin(reg / 10) + 12 * by, px0 = region_origin(reg % 10);
+                const uint8_t* src = goban + ((size_t)frame * 380 + py0 + d / 30) * 380 * 3 + (size_t)px0 * 3;
+                raw[q] = reinterpret_cast<const uint32_t*>(src)[d % 30];
+            }
+        }
+    };
+    int unit = blockIdx.x;
+    fetch(unit);
+
+    // this lane's weight fragments for all 19 steps and both channel tiles
+    float wq[19][2];
+#pragma unroll
+    for (int s = 0; s < 19; s++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) wq[s][n] = wf[(n * 19 + s) * 64 + lane];
+    float4 bv[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++) bv[n] = *reinterpret_cast<const float4*>(bias + n * 16 + 4 * kq);
+    int abase[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int m = (wave * R + r) * 16 + l15;          // pixel inside the unit's 12 rows
+        abase[r] = (m / OW) * RS + (m % OW) * 3;
+    }
+
+    for (; unit < nunits; unit += gridDim.x) {
+#pragma unroll
+        for (int q = 0; q < NPT; q++) {
+            const int d = tid + q * NTHREADS;
+            if (d < ROWS * 30) {
+                float* o = &lds[(d / 30) * RS + 4 * (d % 30)];
+                o[0] = (float)(raw[q] & 0xFFu); o[1] = (float)((raw[q] >> 8) & 0xFFu);
+                o[2] = (float)((raw[q] >> 16) & 0xFFu); o[3] = (float)(raw[q] >> 24);
+            }
+        }
+        __syncthreads();
+        fetch(unit + gridDim.x);
+
+        f32x4 acc[R][2];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[r][n][e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 19; s++) {
+            int k = 4 * s + kq;
+            k = k > 74 ? 74 : k;                          // the padding slot re-reads the last tap (its weight is zero)
+            const int i0 = (4 * s) / 15;
+            const int i = k >= 15 * (i0 + 1) ? i0 + 1 : i0;
+            const int koff = i * RS + (k - 15 * i);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const float a = lds[abase[r] + koff];
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+                    acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[s][n], a, acc[r][n], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                  // every wave is done reading before the next unit lands
+        const int patch = unit / 3, by = unit % 3;
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const size_t m = (size_t)patch * 1296 + (size_t)by * 432 + (wave * R + r) * 16 + l15;
+                float4 v;
+                v.x = acc[r][n][0] + bv[n].x; v.y = acc[r][n][1] + bv[n].y; v.z = acc[r][n][2] + bv[n].z; v.w = acc[r][n][3] + bv[n].w;
+                v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                if constexpr (OUTBF) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+                    pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out_) + m * 32 + n * 16 + 4 * kq) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out_) + m * 32 + n * 16 + 4 * kq) = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // bf16 mode (CK_CNN_BF16): same implicit GEMM on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
 //   in : [patch][H][W][CINP] bf16, CINP a multiple of 16 (padding channels are zero)
 //   wt : [COUTS][KH*KW*CINP] bf16 -- one contiguous K vector per output channel, so a lane's
@@ -595,24 +557,6 @@ __global__ __launch_bounds__(64) void fc1_mfma_bf16_kernel(const uint16_t* __res
     }
 }
 
-// 2x2 max pool, channels-last
-__global__ void pool2_kernel(const float* __restrict__ in, int H, int W, int C, float* __restrict__ out, size_t total)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int OW = W / 2, OH = H / 2;
-    const int c = (int)(i % C);
-    const int x = (int)((i / C) % OW);
-    const int y = (int)((i / ((size_t)C * OW)) % OH);
-    const size_t p = i / ((size_t)C * OW * OH);
-    const float* b = in + ((p * H + 2 * y) * W + 2 * x) * C + c;
-    float m = b[0];
-    float v = b[C]; m = m > v ? m : v;
-    v = b[(size_t)W * C]; m = m > v ? m : v;
-    v = b[(size_t)W * C + C]; m = m > v ? m : v;
-    out[i] = m;
-}
-
 // dense 3240 -> 160 + relu as an MFMA GEMM over patches: one wave = 32 patches x 32 outputs
 __global__ __launch_bounds__(64) void fc1_mfma_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out,
@@ -713,22 +657,6 @@ __global__ __launch_bounds__(128) void decode_kernel(const float* __restrict__ y
 }
 }  // namespace
 
-// correlation-layout pack: row (i*KW + j)*CINP + c, COUT padded to a multiple of 32; the rows of
-// padding channels (c >= CIN) and the odd tail row stay zero
-static void flip_pack(const float* k, int KH, int KW, int CIN, int COUT, std::vector<float>& dst, int CINP = 0)
-{
-    if (CINP == 0) CINP = CIN;
-    const int NT = (COUT + 31) / 32, COUTP = NT * 32;
-    const int K = KH * KW * CINP, KS2 = ((K + 1) / 2) * 2;
-    dst.assign((size_t)KS2 * COUTP, 0.f);
-    for (int i = 0; i < KH; i++)
-        for (int j = 0; j < KW; j++)
-            for (int c = 0; c < CIN; c++)
-                for (int o = 0; o < COUT; o++)
-                    dst[(size_t)((i * KW + j) * CINP + c) * COUTP + o] =
-                        k[(((size_t)(KH - 1 - i) * KW + (KW - 1 - j)) * CIN + c) * COUT + o];
-}
-
 // B operand pack of conv_mfma16_f32_kernel: [channel tile of 16][group of 4 k-steps][lane = kslot*16 + col][4]
 // with K = (kh, kw, cin padded to a multiple of 4) and k = 4*step + kslot; flip applied, padding zero
 static void pack_mfma16(const float* k, int KH, int KW, int CIN, int COUT, std::vector<float>& dst)
@@ -743,6 +671,21 @@ static void pack_mfma16(const float* k, int KH, int KW, int CIN, int COUT, std::
                 const int i = ij / KW, j = ij % KW;
                 dst[(((size_t)nt * SG + step / 4) * 64 + lane) * 4 + step % 4] =
                     k[(((size_t)(KH - 1 - i) * KW + (KW - 1 - j)) * CIN + c) * COUT + o];
+            }
+}
+
+// A operand pack of conv1_mfma16_kernel: [channel tile][step][lane = kslot*16 + channel], K = 75 dense
+// in (kh, kw, cin) order, k = 4*step + kslot, flip applied, k = 75 zero
+static void pack_conv1(const float* k, std::vector<float>& dst)
+{
+    dst.assign((size_t)2 * 19 * 64, 0.f);
+    for (int n = 0; n < 2; n++)
+        for (int s = 0; s < 19; s++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int kk = 4 * s + lane / 16, o = n * 16 + lane % 16;
+                if (kk >= 75) continue;
+                const int i = kk / 15, j = (kk % 15) / 3, c = kk % 3;
+                dst[((size_t)n * 19 + s) * 64 + lane] = k[(((size_t)(4 - i) * 5 + (4 - j)) * 3 + c) * 32 + o];
             }
 }
 
@@ -763,7 +706,7 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
         return CK_OK;
     };
     std::vector<float> t;
-    flip_pack(host[0].data(), 5, 5, 3, 32, t);  CK_TRY(up(ctx->cnn.c1w, t));
+    pack_conv1(host[0].data(), t);              CK_TRY(up(ctx->cnn.c1w, t));
     pack_mfma16(host[2].data(), 5, 5, 32, 32, t); CK_TRY(up(ctx->cnn.c2w, t));
     pack_mfma16(host[4].data(), 3, 3, 32, 90, t); CK_TRY(up(ctx->cnn.c3w, t));
     pack_mfma16(host[6].data(), 3, 3, 90, 90, t); CK_TRY(up(ctx->cnn.c4w, t));
@@ -829,8 +772,8 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             uint16_t* q4 = q4_all + (size_t)f0 * 100 * 3456;
             {
                 TimeScope ts(ctx, "cnn_conv1");
-                hipLaunchKernelGGL((conv_mfma_f32_kernel<40, 40, 3, 5, 5, 32, 3, 4, true, false, true>), dim3(np, 4), dim3(256), 0,
-                                   ctx->stream, (const void*)gob, (const float*)W.c1w.p, (const float*)W.c1b.p, (float*)b1);
+                hipLaunchKernelGGL((conv1_mfma16_kernel<C1_R, true>), dim3(std::min(np * 3, C1_GRID)), dim3(64 * (27 / C1_R)), 0,
+                                   ctx->stream, gob, (const float*)W.c1w.p, (const float*)W.c1b.p, (void*)b1, np * 3);
             }
             {
                 TimeScope ts(ctx, "cnn_conv2");
@@ -871,9 +814,8 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         float* p4 = p4_all + (size_t)f0 * 100 * 3240;
         {
             TimeScope ts(ctx, "cnn_conv1");
-            // 41 M tiles: 4 groups of (4 waves x 3 tiles)
-            hipLaunchKernelGGL((conv_mfma_f32_kernel<40, 40, 3, 5, 5, 32, 3, 4, true, false>), dim3(np, 4), dim3(256), 0,
-                               ctx->stream, (const void*)gob, (const float*)W.c1w.p, (const float*)W.c1b.p, a1);
+            hipLaunchKernelGGL((conv1_mfma16_kernel<C1_R, false>), dim3(std::min(np * 3, C1_GRID)), dim3(64 * (27 / C1_R)), 0,
+                               ctx->stream, gob, (const float*)W.c1w.p, (const float*)W.c1b.p, (void*)a1, np * 3);
         }
         {
             TimeScope ts(ctx, "cnn_conv2");
