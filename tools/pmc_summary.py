@@ -12,8 +12,8 @@ import sys
 STAGE = [("median15_kernel", "median", None), ("canny_nms_kernel", "canny_nms", None),
          ("prep_rows", "ccl_prep_rows", None), ("hough_vote_kernel", "hough_vote", None),
          ("warp_kernel", "warp", None),
-         ("conv_mfma_f32_kernel<40, 40, 3", "cnn_conv1", 128), ("conv_mfma_f32_kernel<36, 36, 32", "cnn_conv2", 128),
-         ("conv_mfma_f32_kernel<16, 16, 32", "cnn_conv3", 128), ("conv_mfma_f32_kernel<14, 14, 90", "cnn_conv4", 128)]
+         ("conv1_mfma16_kernel", "cnn_conv1", 128), ("conv_mfma16_f32_kernel<36, 36, 32", "cnn_conv2", 128),
+         ("conv_mfma16_f32_kernel<16, 16, 32", "cnn_conv3", 128), ("conv_mfma16_f32_kernel<14, 14, 90", "cnn_conv4", 128)]
 
 
 def load(d, counter):
