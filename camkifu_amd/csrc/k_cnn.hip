@@ -557,36 +557,75 @@ __global__ __launch_bounds__(64) void fc1_mfma_bf16_kernel(const uint16_t* __res
     }
 }
 
-// dense 3240 -> 160 + relu as an MFMA GEMM over patches: one wave = 32 patches x 32 outputs
-__global__ __launch_bounds__(64) void fc1_mfma_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, float* __restrict__ out,
-                                                          int npatch)
+// dense 3240 -> 160 + relu as an MFMA GEMM over patches (v_mfma_f32_16x16x4_f32, K ascending).
+// Workgroup = 64 patches x all 160 outputs: wave w owns patches 16w..16w+15 and the ten 16-output
+// tiles.  The activations are staged through LDS in chunks of 120 values per patch (coalesced
+// float4 loads, pixel stride 130 dwords = 2 mod 32: conflict-free fragment reads); the weights
+// stream from L2 as packed dwordx2 fragments ([tile][pair of k-steps][lane][2], pack_fc1) through
+// a 3-deep register ring.  Operands are swapped (A = weights, B = activations) so a lane ends up
+// with four consecutive outputs of one patch: 16-byte stores.
+__global__ __launch_bounds__(256) void fc1_mfma16_kernel(const float* __restrict__ x, const float* __restrict__ wq_,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int npatch)
 {
 #pragma clang fp contract(off)
-    constexpr int KIN = 3240, NOUT = 160;
-    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
-    const int p0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-    int p = p0 + l31;
-    if (p > npatch - 1) p = npatch - 1;
-    const float* xa = x + (size_t)p * KIN + hi;
-    const float* wb = w + (size_t)hi * NOUT + n0 + l31;
-    f32x16 acc;
+    constexpr int KIN = 3240, NOUT = 160, NT = 10, KC = 120, NCHUNK = KIN / KC, GC = KC / 8, CSR = 130;
+    constexpr int SG2 = KIN / 8;                   // pairs of k-steps
+    constexpr int PF = 3;
+    static_assert(GC % PF == 0, "ring slots stay aligned across chunks");
+    __shared__ float lds[64 * CSR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int p0 = blockIdx.x * 64;
+    const float2* wq = reinterpret_cast<const float2*>(wq_) + lane;
+    f32x4 acc[NT];
 #pragma unroll
-    for (int e = 0; e < 16; e++) acc[e] = 0.f;
-#pragma unroll 4
-    for (int s = 0; s < KIN / 2; s++) {
-        const float a = xa[2 * s];
-        const float b = wb[(size_t)(2 * s) * NOUT];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[n][e] = 0.f;
+    float2 bq[PF][NT];
+#pragma unroll
+    for (int u = 0; u < PF; u++)
+#pragma unroll
+        for (int n = 0; n < NT; n++) bq[u][n] = wq[((size_t)n * SG2 + u) * 64];
+    const int abase = (wave * 16 + l15) * CSR + kq;
+    for (int ch = 0; ch < NCHUNK; ch++) {
+        __syncthreads();                           // previous chunk fully consumed
+        for (int i = tid; i < 64 * (KC / 4); i += 256) {
+            const int row = i / (KC / 4), c4 = i % (KC / 4);
+            int p = p0 + row;
+            p = p > npatch - 1 ? npatch - 1 : p;
+            const float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * KIN + ch * KC + 4 * c4);
+            float* d = &lds[row * CSR + 4 * c4];
+            *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+            *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int gl = 0; gl < GC; gl++) {
+            const int g = ch * GC + gl;            // global pair index
+            float2 b[NT];
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                b[n] = bq[gl % PF][n];
+                if (g + PF < SG2) bq[gl % PF][n] = wq[((size_t)n * SG2 + g + PF) * 64];
+            }
+            const float a0 = lds[abase + 8 * gl], a1 = lds[abase + 8 * gl + 4];
+#pragma unroll
+            for (int n = 0; n < NT; n++) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[n].x, a0, acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; n++) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[n].y, a1, acc[n], 0, 0, 0);
+        }
     }
-    const int co = n0 + l31;
-    const float bv = bias[co];
+    const int p = p0 + wave * 16 + l15;
+    if (p < npatch) {
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const int pp = p0 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-        float v = acc[e] + bv;
-        v = v > 0.f ? v : 0.f;
-        if (pp < npatch) out[(size_t)pp * NOUT + co] = v;
+        for (int n = 0; n < NT; n++) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + n * 16 + 4 * kq);
+            float4 v;
+            v.x = acc[n][0] + bv.x; v.y = acc[n][1] + bv.y; v.z = acc[n][2] + bv.z; v.w = acc[n][3] + bv.w;
+            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+            *reinterpret_cast<float4*>(out + (size_t)p * NOUT + n * 16 + 4 * kq) = v;
+        }
     }
 }
 
@@ -689,6 +728,19 @@ static void pack_conv1(const float* k, std::vector<float>& dst)
             }
 }
 
+// A operand pack of fc1_mfma16_kernel: [output tile of 16][pair of k-steps][lane = kslot*16 + output][2],
+// k = 4*step + kslot ascending
+static void pack_fc1(const float* w, std::vector<float>& dst)
+{
+    const int KIN = 3240, NOUT = 160, SG2 = KIN / 8;
+    dst.assign((size_t)(NOUT / 16) * SG2 * 64 * 2, 0.f);
+    for (int nt = 0; nt < NOUT / 16; nt++)
+        for (int step = 0; step < KIN / 4; step++)
+            for (int lane = 0; lane < 64; lane++)
+                dst[(((size_t)nt * SG2 + step / 2) * 64 + lane) * 2 + step % 2] =
+                    w[(size_t)(4 * step + lane / 16) * NOUT + nt * 16 + lane % 16];
+}
+
 int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
 {
     static const size_t counts[12] = { 5 * 5 * 3 * 32, 32, 5 * 5 * 32 * 32, 32, 3 * 3 * 32 * 90, 90,
@@ -712,7 +764,8 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
     pack_mfma16(host[6].data(), 3, 3, 90, 90, t); CK_TRY(up(ctx->cnn.c4w, t));
     CK_TRY(up(ctx->cnn.c1b, host[1])); CK_TRY(up(ctx->cnn.c2b, host[3]));
     CK_TRY(up(ctx->cnn.c3b, host[5])); CK_TRY(up(ctx->cnn.c4b, host[7]));
-    CK_TRY(up(ctx->cnn.d1w, host[8])); CK_TRY(up(ctx->cnn.d1b, host[9]));
+    pack_fc1(host[8].data(), t);               CK_TRY(up(ctx->cnn.d1w, t));
+    CK_TRY(up(ctx->cnn.d1b, host[9]));
     CK_TRY(up(ctx->cnn.d2w, host[10])); CK_TRY(up(ctx->cnn.d2b, host[11]));
     // bf16 packs: [cout padded][kh*kw*cin padded], flip applied, padding rows / channels zero
     auto pack_bf = [&](const float* k, int KH, int KW, int CIN, int CINP, int COUT, int COUTS, DevBuf& dst) -> int {
@@ -844,7 +897,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
     {
         TimeScope ts(ctx, "cnn_tail");
         const int np = nframes * 100;
-        hipLaunchKernelGGL(fc1_mfma_f32_kernel, dim3((np + 31) / 32, 5), dim3(64), 0, ctx->stream,
+        hipLaunchKernelGGL(fc1_mfma16_kernel, dim3((np + 63) / 64), dim3(256), 0, ctx->stream,
                            (const float*)p4_all, (const float*)W.d1w.p, (const float*)W.d1b.p, h1, np);
         hipLaunchKernelGGL(fc2_softmax_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float*)h1,
                            (const float*)W.d2w.p, (const float*)W.d2b.p, d_y, np);
