@@ -22,7 +22,7 @@ EXPORTS = [
     "ck_ctx_create", "ck_ctx_destroy", "ck_last_error", "ck_backend", "ck_version", "ck_stream",
     "ck_timing_enable", "ck_timing_reset", "ck_timing_get",
     "ck_median15", "ck_canny", "ck_board_edges", "ck_board_lines", "ck_board_detect",
-    "ck_get_perspective_transform", "ck_warp_perspective",
+    "ck_i420_to_bgr", "ck_get_perspective_transform", "ck_warp_perspective",
     "ck_mog2_create", "ck_mog2_apply", "ck_mog2_destroy",
     "ck_cnn_set_weights", "ck_cnn_set_mode", "ck_cnn_predict", "ck_stones_detect",
 ]
@@ -216,6 +216,26 @@ class Context:
         return [dict(status=int(r["status"]), n_contours=int(r["n_contours"]), n_lines=int(r["n_lines"]),
                      biggest_area=float(r["biggest_area"]), lines=lines[f, :min(int(r["n_lines"]), cap)].copy())
                 for f, r in enumerate(res)]
+
+    # ---- frame source ------------------------------------------------------------------------
+    def i420_to_bgr(self, i420, h, w, to_device=None):
+        """planar YUV 4:2:0 frames (n, h*w*3/2) or one flat frame -> BGR (n, h, w, 3) / (h, w, 3).
+        `to_device`: a torch device to leave the BGR frames in HBM even when the I420 bytes come from
+        host memory (the fast-file path uploads 1.5 B/px and converts on the GPU)."""
+        fsz = h * w * 3 // 2
+        single = len(i420.shape) == 1
+        n = 1 if single else int(i420.shape[0])
+        assert int(i420.shape[-1]) == fsz, (tuple(i420.shape), fsz)
+        p, sp, keep = _in(i420)
+        oshape = (h, w, 3) if single else (n, h, w, 3)
+        if to_device is not None and sp == CK_HOST:
+            import torch
+            out = torch.empty(oshape, dtype=torch.uint8, device=to_device)
+            op, osp = C.c_void_p(out.data_ptr()), CK_DEVICE
+        else:
+            out, op, osp = self._out(i420, oshape, np.uint8)
+        self._chk(lib().ck_i420_to_bgr(self._h, p, n, int(h), int(w), sp, op, osp))
+        return out
 
     # ---- K8 ---------------------------------------------------------------------------------
     def warp_perspective(self, bgr, M, dsize=380):

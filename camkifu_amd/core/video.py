@@ -4,6 +4,7 @@ ready_to_read, full_speed, total_f_processed, bindings, metadata, _show, _window
 Display goes to the manager's image queue when there is one and is otherwise dropped: HighGUI
 is out of scope."""
 import collections
+import threading
 import time
 import traceback
 
@@ -103,3 +104,17 @@ class VidProcessor:
             except Exception:
                 self.ignored_show[name] += 1
         self.metadata.clear()
+
+
+class VisionThread(threading.Thread):
+    """Daemon-thread wrapper of a VidProcessor (core/video.py:335-355): run() is the processor's
+    execute(); every other attribute is delegated to the processor."""
+
+    def __init__(self, processor):
+        super().__init__(name=processor.__class__.__name__)
+        self.daemon = True
+        self.processor = processor
+        self.run = processor.execute
+
+    def __getattr__(self, item):
+        return getattr(self.processor, item)

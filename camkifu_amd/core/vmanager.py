@@ -1,40 +1,15 @@
-"""Vision managers: finder registry/reflection and a sequential headless driver (mirror of the
-reference's core/vmanager.py:16-198 `VManagerBase` and test/objects/vmanager_test.py `VManagerSeq`).
-Video decoding is out of scope: frames come from an in-memory array or a
-.npy file through ArrayCapture, which plays the role of CaptureReaderBase."""
+"""Vision managers: finder registry/reflection (core/vmanager.py:16-198 `VManagerBase`), the
+multi-threaded `VManager` with lock-step file reading (core/vmanager.py:201-458) and the sequential
+headless driver of the reference's tests (test/objects/vmanager_test.py `VManagerSeq`).
+Frames come from core/capture.py: an in-memory array, a .npy file or an uncompressed .y4m file."""
 import importlib
+import os
 import threading
-
-import numpy as np
+import time
 
 from .. import cvconf
-
-
-class ArrayCapture:
-    """Frame source over an (n, h, w, 3) uint8 array (or a path to one saved with np.save).
-    read() hands each consumer a private copy, like CaptureReader.read_file does."""
-
-    def __init__(self, frames):
-        if isinstance(frames, str):
-            frames = np.load(frames, mmap_mode="r")
-        self.frames = frames
-        self.pos = 0
-
-    def read(self, caller=None):
-        if self.pos >= len(self.frames):
-            return False, None
-        frame = np.array(self.frames[self.pos], copy=True)
-        self.pos += 1
-        return True, frame
-
-    def progress(self):
-        return self.pos / max(1, len(self.frames))
-
-    def seek(self, ratio):
-        self.pos = int(ratio * len(self.frames))
-
-    def release(self):
-        pass
+from .capture import ArrayCapture, CaptureReader, CaptureReaderBase, open_capture     # noqa: F401  (ArrayCapture re-exported)
+from .video import VisionThread
 
 
 class VManagerBase(threading.Thread):
@@ -59,9 +34,19 @@ class VManagerBase(threading.Thread):
         self.current_video = self.controller.video
         if self.capt is not None:
             self.capt.release()
-        self.capt = ArrayCapture(self.controller.video)
-        self.full_speed = True
-        self.capt.seek(self.controller.bounds[0])
+        self.capt = self._get_capture()
+        if self.capt is not None:
+            # arrays and files are read as fast as the finders go; only a live camera is rate limited
+            self.full_speed = True
+            self.capt.seek(self.controller.bounds[0])
+
+    def _get_capture(self):
+        """the capture for controller.video; a file path gets the frame-skipping reader (file_fps)"""
+        cap = open_capture(self.controller.video)
+        if not cap.isOpened():
+            print("Could not open video: {}".format(getattr(cap, "error", self.controller.video)))
+            return None
+        return CaptureReaderBase(cap, self)
 
     def error_raised(self, processor, error):
         print("{} terminating due to {} in {}.".format(type(self).__name__, type(error).__name__,
@@ -115,6 +100,89 @@ class VManagerBase(threading.Thread):
         if chosen is None:
             return None
         return getattr(importlib.import_module(chosen[0]), chosen[1])
+
+
+class VManager(VManagerBase):
+    """Multi-threaded manager (core/vmanager.py:201-458, headless part): one daemon thread per finder;
+    when the input is a file both finders receive the same frames in lock step (CaptureReader)."""
+
+    def __init__(self, controller, imqueue=None, bf=None, sf=None, active=True):
+        super().__init__(controller, imqueue=imqueue, bf=bf, sf=sf)
+        self.daemon = True
+        self.processes = []
+        self._interrupt_flag = False
+        self.active = active
+        self.hasrun = False
+        self.error = None
+
+    def _get_capture(self):
+        cap = open_capture(self.controller.video)
+        if not cap.isOpened():
+            print("Could not open video: {}".format(getattr(cap, "error", self.controller.video)))
+            return None
+        return CaptureReader(cap, self)
+
+    def next(self):
+        for proc in self.processes:
+            proc.next()
+
+    def run(self):
+        self.init_capt()
+        while not self._interrupt_flag:
+            if self.active:
+                self.check_video()
+                if self.capt is not None:
+                    self.check_bf()
+                    self.check_sf()
+            time.sleep(0.02)
+            self.hasrun = True
+
+    def interrupt(self):
+        self.stop_processing()
+        self._interrupt_flag = True
+
+    def stop_processing(self):
+        for proc in list(self.processes):
+            proc.interrupt()
+        try:
+            self.capt.unsync_threads(True)        # release threads a CaptureReader keeps sleeping
+        except AttributeError:
+            pass
+
+    def check_video(self):
+        if self.current_video is not self.controller.video and self.current_video != self.controller.video:
+            self.stop_processing()
+            self.init_capt()
+            self.board_finder = None
+            self.stones_finder = None
+            self.controller.pipe("video_changed")
+
+    def check_bf(self):
+        if self.board_finder is None and self.bf_class is not None:
+            self.board_finder = self.bf_class(self)
+            self._spawn(self.board_finder)
+
+    def check_sf(self):
+        if self.stones_finder is None and self.sf_class is not None:
+            self.stones_finder = self.sf_class(self)
+            self._spawn(self.stones_finder)
+
+    def is_processing(self):
+        return len(self.processes).__bool__()
+
+    def confirm_stop(self, process):
+        for vt in list(self.processes):
+            if vt.processor is process:
+                self.processes.remove(vt)
+
+    def _spawn(self, process):
+        vt = VisionThread(process)
+        self.processes.append(vt)
+        try:
+            self.capt.unsync_threads(False)       # processes wait for each other again when reading frames
+        except AttributeError:
+            pass
+        vt.start()
 
 
 class VManagerSeq(VManagerBase):

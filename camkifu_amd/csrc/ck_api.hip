@@ -302,6 +302,21 @@ static int upload_minv(ck_ctx* ctx, const double* M, int m_count, int n, const d
     return CK_OK;
 }
 
+int ck_i420_to_bgr(ck_ctx* ctx, const uint8_t* i420, int n, int h, int w, int in_space, uint8_t* bgr, int out_space)
+{
+    CK_TRY(check_img(ctx, i420, n, h, w));
+    if (!bgr) return ck_fail(ctx, CK_ERR_ARG, "bgr is NULL");
+    if ((h & 1) || (w & 1)) return ck_fail(ctx, CK_ERR_ARG, "I420 needs even dimensions, got %dx%d", w, h);
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, i420, (size_t)n * h * w * 3 / 2, in_space, ctx->in_stage2, &d_in));
+    const size_t obytes = (size_t)n * h * w * 3;
+    uint8_t* d_out = bgr;
+    if (out_space == CK_HOST) { CK_TRY(ck_ensure(ctx, ctx->out_stage, obytes)); d_out = (uint8_t*)ctx->out_stage.p; }
+    CK_TRY(k_i420_to_bgr(ctx, (const uint8_t*)d_in, n, h, w, d_out));
+    if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, bgr, d_out, obytes, CK_HOST));
+    return finish(ctx);
+}
+
 int ck_warp_perspective(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
                         const double* M, int m_count, int dsize, uint8_t* out, int out_space)
 {

@@ -119,6 +119,7 @@ int k_interleaved_to_planar(ck_ctx* ctx, const uint8_t* d_in, int n, int h, int 
 // canny: planar 3-channel input -> map (0/1/2) -> edges (0/255); labels = scratch n*h*w int32
 int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, int low, int high,
                    uint8_t* d_map, int32_t* d_labels, uint8_t* d_edges, uint8_t* d_map_out);
+int k_i420_to_bgr(ck_ctx* ctx, const uint8_t* d_i420, int n, int h, int w, uint8_t* d_bgr);
 int k_warp(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, const double* d_minv, int m_count,
            int dsize, uint8_t* d_out);
 int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int hough_thresh,

@@ -248,6 +248,32 @@ class FastFilePipeline:
         full = gather_records(rec, n_total, self.rank, self.world, self.device)
         return self.fold(full, mtx is not None)
 
+    def process_y4m(self, capture, batch=256, file_fps=None, torch_device=None):
+        """Fast processing of a video file (README "Fast video file processing"; frame selection as
+        CaptureReaderBase.skip, core/vmanager.py:511-525).  `capture` is a core.capture.Y4MCapture: the
+        frames to analyse are dealt to the ranks batch by batch (frame k of a batch -> rank k mod world),
+        each rank uploads ITS frames as I420 (1.5 B/px through a reused pinned buffer) and converts them
+        to BGR in HBM (ck_i420_to_bgr), then the batch goes through process_batch.
+        Returns the concatenated per-frame move lists."""
+        import torch
+        from .core.capture import file_frame_indices
+        idx = file_frame_indices(len(capture), capture.fps, file_fps)
+        dev = torch_device if torch_device is not None else torch.device("cuda", getattr(self.ctx, "device", 0))
+        pinned, emitted = None, []
+        for b0 in range(0, len(idx), batch):
+            chunk = idx[b0:b0 + batch]
+            mine = [chunk[k] for k in shard_indices(len(chunk), self.rank, self.world)]
+            if pinned is None:
+                cap_rows = len(shard_indices(batch, 0, self.world))
+                pinned = torch.empty((cap_rows, capture.fsize), dtype=torch.uint8).pin_memory()
+            raw = capture.read_raw_batch(mine, out=pinned.numpy())
+            if len(mine):
+                frames = self.ctx.i420_to_bgr(raw, capture.h, capture.w, to_device=dev)
+            else:
+                frames = torch.empty((0, capture.h, capture.w, 3), dtype=torch.uint8, device=dev)
+            emitted.extend(self.process_batch(frames, len(chunk)))
+        return emitted
+
     def fold(self, full, have_mtx=True):
         """ordered replay of the temporal logic on the gathered records of one batch"""
         u = unpack_records(full)

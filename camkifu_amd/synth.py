@@ -145,3 +145,20 @@ def cnn_weights(seed=SEED, as_torch=False, device="cpu"):
     if as_torch:
         return {k: torch.from_numpy(v).to(device) for k, v in Wt.items()}
     return Wt
+
+
+def bgr_to_i420(frame):
+    """(h, w, 3) uint8 BGR -> flat I420 (h*w*3/2 bytes), BT.601 studio range, chroma averaged over
+    2x2 blocks: how a synthetic clip is stored in a .y4m file (camkifu_amd.core.capture.write_y4m)."""
+    f = np.asarray(frame).astype(np.int32)
+    h, w = f.shape[:2]
+    assert h % 2 == 0 and w % 2 == 0
+    b, g, r = f[..., 0], f[..., 1], f[..., 2]
+    y = ((66 * r + 129 * g + 25 * b + 128) >> 8) + 16
+    u = ((-38 * r - 74 * g + 112 * b + 128) >> 8) + 128
+    v = ((112 * r - 94 * g - 18 * b + 128) >> 8) + 128
+
+    def sub(c):
+        return (c.reshape(h // 2, 2, w // 2, 2).sum(axis=(1, 3)) + 2) >> 2
+    out = np.concatenate([y.reshape(-1), sub(u).reshape(-1), sub(v).reshape(-1)])
+    return np.clip(out, 0, 255).astype(np.uint8)

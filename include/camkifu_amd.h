@@ -88,6 +88,14 @@ int ck_board_lines(ck_ctx* ctx, const uint8_t* edges, int n, int h, int w, int i
 int ck_board_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
                     int hough_thresh, float* lines, int cap, ck_board_result* res);
 
+/* ---- frame source: what cv2.VideoCapture.read() hands every consumer   core/vmanager.py:506-509, 584
+ * (the reference decodes to BGR on the CPU).  A file reader that holds planar YUV 4:2:0 frames
+ * (I420: Y h*w, U, V (h/2)*(w/2) each; e.g. a .y4m file) uploads 1.5 B/px and converts in HBM:
+ * BT.601 studio range, the 20-bit fixed-point arithmetic of cv2.cvtColor(COLOR_YUV2BGR_I420).
+ * i420: n frames of h*w*3/2 bytes; bgr: n x h x w x 3.  h and w must be even. */
+int ck_i420_to_bgr(ck_ctx* ctx, const uint8_t* i420, int n, int h, int w, int in_space,
+                   uint8_t* bgr, int out_space);
+
 /* ---- K7  cv2.getPerspectiveTransform(src4, dst4)            board/boardfinder.py:43-45
  * host only; src/dst 4x2 float32, M 3x3 float64 row-major. */
 int ck_get_perspective_transform(const float* src4, const float* dst4, double* M9);

@@ -128,6 +128,10 @@ void ora_decode_all(const float* y /*100x81*/, uint8_t* labels, double* conf);
 /* threads the OpenMP-parallel routines (median rows, CNN patches) will use */
 int ora_num_threads(void);
 
+/* frame source: I420 (planar Y, U, V; h and w even) -> interleaved BGR, BT.601 studio range,
+ * fixed point as cv2.cvtColor(COLOR_YUV2BGR_I420) (core/vmanager.py:506-509 hands consumers BGR). */
+void ora_i420_to_bgr(const uint8_t* i420, int h, int w, uint8_t* bgr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -169,6 +169,15 @@ def warp_perspective(img, M, dsize=(380, 380)):
     return out
 
 
+def i420_to_bgr(i420, h, w):
+    """one frame: flat I420 buffer of h*w*3/2 bytes -> (h, w, 3) BGR"""
+    buf = np.ascontiguousarray(i420, np.uint8).reshape(-1)
+    assert buf.size == h * w * 3 // 2 and h % 2 == 0 and w % 2 == 0
+    out = np.empty((h, w, 3), np.uint8)
+    lib().ora_i420_to_bgr(_vp(buf), h, w, _vp(out))
+    return out
+
+
 class MOG2:
     def __init__(self, h, w, cn=3):
         self.h, self.w, self.cn = h, w, cn

@@ -380,3 +380,57 @@ def test_detectiontest_harness_on_gpu():
                           "--frames", "70"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "[synthetic-640x480: 100.0% in" in out.stdout, out.stdout[-500:]
+
+
+# ---------------------------------------------------------------- frame source
+@pytest.mark.parametrize("h,w", [(1080, 1920), (480, 642), (2, 2), (46, 68)])
+def test_i420_to_bgr_parity(ck, ora, h, w):
+    """ck_i420_to_bgr == oracle, bit for bit: dword path (w % 4 == 0), 2-pixel path, tiny frames,
+    host and device buffers"""
+    import torch
+    rng = np.random.default_rng(h * 7 + w)
+    n = 3
+    raw = rng.integers(0, 256, (n, h * w * 3 // 2), dtype=np.uint8)
+    raw[0, :h * w] = rng.choice(np.array([0, 15, 16, 17, 234, 235, 236, 255], np.uint8), h * w)     # range edges
+    ref = np.stack([ora.i420_to_bgr(raw[k], h, w) for k in range(n)])
+    assert np.array_equal(ck.i420_to_bgr(raw, h, w), ref)                                   # host -> host
+    dev = ck.i420_to_bgr(raw, h, w, to_device=torch.device("cuda:0"))                       # host -> HBM
+    assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), ref)
+    dev2 = ck.i420_to_bgr(torch.from_numpy(raw).cuda(), h, w)                               # HBM -> HBM
+    assert dev2.is_cuda and np.array_equal(dev2.cpu().numpy(), ref)
+    assert np.array_equal(ck.i420_to_bgr(raw[1], h, w), ref[1])                             # one flat frame
+    from camkifu_amd import capi
+    with pytest.raises(capi.CkError):
+        ck.i420_to_bgr(np.zeros(3 * 5 * 3 // 2, np.uint8), 3, 5)                            # odd dimensions
+
+
+def test_y4m_file_through_the_pipeline(ck, ora, synth, tmp_path):
+    """a synthetic clip stored as .y4m, read with the reference's file_fps skipping, uploaded as I420,
+    converted on the GPU and folded == the same frames decoded by the oracle and pushed as BGR"""
+    from camkifu_amd import pipeline
+    from camkifu_amd.controller import ControllerHeadless
+    from camkifu_amd.core import capture as cap
+    rng = np.random.default_rng(5)
+    corners = synth.random_corners(480, 640, rng)
+    stones = synth.random_stones(rng, density=0.3)
+    bgr = [synth.render(480, 640, stones, corners, seed=900 + f).numpy() for f in range(8)]
+    # 30 fps file, default file_fps = 5 -> frames 6, 13, 20, ...: 100 frames give 14 analysed ones
+    path = str(tmp_path / "game.y4m")
+    cap.write_y4m(path, (synth.bgr_to_i420(bgr[f % 8]) for f in range(100)), 480, 640)
+    from camkifu_amd.stone.nn_manager import NNManager
+    ck.cnn_set_weights(NNManager.init_net())          # the trained fixture: labels mean something
+    c = cap.Y4MCapture(path)
+    idx = cap.file_frame_indices(len(c), c.fps)
+    assert idx == list(range(6, 100, 7))
+    ctrl = ControllerHeadless()
+    pipe = pipeline.FastFilePipeline(480, 640, ctrl, ctx=ck)
+    pipe.process_y4m(c, batch=7)
+    # same frames, decoded on the CPU, fed as BGR
+    ctrl2 = ControllerHeadless()
+    pipe2 = pipeline.FastFilePipeline(480, 640, ctrl2, ctx=ck)
+    dec = np.stack([ora.i420_to_bgr(np.asarray(c.read_raw_batch([i])[0]), 480, 640) for i in idx])
+    for b0 in range(0, len(idx), 7):
+        pipe2.process_batch(dec[b0:b0 + 7], len(dec[b0:b0 + 7]))
+    assert pipe.board.mtx is not None and np.array_equal(pipe.board.mtx, pipe2.board.mtx)
+    assert ctrl.kifu.to_sgf() == ctrl2.kifu.to_sgf() and pipe.frames_done == len(idx)
+    assert len(ctrl.kifu.moves) > 0
