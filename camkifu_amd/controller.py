@@ -1,14 +1,19 @@
 """Headless controller: the sink the finders talk to (same `pipe` instruction names and board
 queries as the reference's vgui/ControllerV and test/objects/ControllerVDev: "append",
 "delete", "bulk", "auto_save"; is_empty_blocking, locate, get_stones).  Instructions run
-synchronously on the caller's thread; there are no Go rules (no captures) -- SURVEY.md 8f rank 4."""
+synchronously on the caller's thread.  With rules=True every appended stone goes through the
+rule engine (captures are taken off the goban, suicide / ko / occupied raise StateError), as the
+reference's controller does through Golib; the default keeps the goban a plain mirror of what the
+finders report."""
 import numpy as np
 
-from .golib_shim import gsize, E, Kifu
+from .golib_shim import gsize, E, Kifu, Rule
 
 
 class ControllerHeadless:
-    def __init__(self, video=None, bounds=(0, 1), autosave_path=None):
+    def __init__(self, video=None, bounds=(0, 1), autosave_path=None, rules=False):
+        self.rules = Rule() if rules else None
+        self.last_captured = []            # (color, x, y) taken by the most recent append
         self.video = video
         self.bounds = bounds
         self.kifu = Kifu()
@@ -27,6 +32,11 @@ class ControllerHeadless:
     def _append(self, move):
         if self.board[move.x][move.y] is not None:
             raise ValueError("occupied: %s" % move)
+        self.last_captured = []
+        if self.rules is not None:
+            self.last_captured = self.rules.put(move)          # raises StateError when illegal
+            for _, cx, cy in self.last_captured:
+                self.board[cx][cy] = None                      # prisoners leave the goban, not the record
         self.board[move.x][move.y] = move
         self.kifu.append(move)
 
@@ -35,6 +45,8 @@ class ControllerHeadless:
         if mv is not None:
             self.board[x][y] = None
             self.kifu.pop_at(x, y)
+            if self.rules is not None:
+                self.rules.remove(x, y)
         return mv
 
     def _bulk(self, moves):

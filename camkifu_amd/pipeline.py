@@ -158,6 +158,9 @@ class StonesFold:
     def __init__(self, controller):
         self.controller = controller
         self.cur = None                        # cached goban as uint8 (19,19): 0 E, 1 B, 2 W
+        # prisoners the rule engine took off the goban but the camera may still show: (r, c) -> label.
+        # They are not suggested again until the intersection has been seen empty or recoloured.
+        self.prisoners = {}
 
     def resync(self):
         """re-read the goban from the controller (once per batch: somebody else may edit it)"""
@@ -171,6 +174,12 @@ class StonesFold:
         if self.cur is None:
             self.resync()
         change = (labels != 0) & (conf > self.MIN_CONFIDENCE) & (labels != self.cur)
+        if self.prisoners:
+            for (r, c), lab in list(self.prisoners.items()):
+                if labels[r, c] == lab:
+                    change[r, c] = False                     # still lying on the board: not a new stone
+                else:
+                    del self.prisoners[(r, c)]               # taken away (or replaced): watch over
         if not change.any():
             return []
         moves = []
@@ -181,7 +190,15 @@ class StonesFold:
                 moves.append(Move(NP_TYPE, (E, r, c)))       # clear first, then recolour
             moves.append(Move(NP_TYPE, (color, r, c)))
             self.cur[r, c] = labels[r, c]
-        self.controller.pipe("bulk", moves)
+        if getattr(self.controller, "rules", None) is None:
+            self.controller.pipe("bulk", moves)
+        else:
+            # one instruction per stone so the prisoners of each can be taken off the cached goban
+            for mv in moves:
+                self.controller.pipe("bulk", [mv])
+                for col, cx, cy in (self.controller.last_captured if mv.color != E else ()):
+                    self.prisoners[(cy, cx)] = 1 if col == B else 2
+                    self.cur[cy, cx] = 0
         self.controller.pipe("auto_save")
         return moves
 

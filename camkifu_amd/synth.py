@@ -162,3 +162,38 @@ def bgr_to_i420(frame):
         return (c.reshape(h // 2, 2, w // 2, 2).sum(axis=(1, 3)) + 2) >> 2
     out = np.concatenate([y.reshape(-1), sub(u).reshape(-1), sub(v).reshape(-1)])
     return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def random_game(n_moves, rng, side=9, cool=0):
+    """A legal game of `n_moves` alternating random moves played under the rules of Go (captures,
+    no suicide, no ko retake) inside a side x side corner, so that groups do get captured.
+    `cool`: nobody plays on a point for that many moves after a stone was captured there (players
+    need the time to take the prisoners off the board).
+    -> (moves [(color, r, c)], positions [n_moves] uint8 (19,19) AFTER each move, captured [per move list])"""
+    from .golib_shim import B, W, Move, NP_TYPE, Rule, StateError, gsize
+    rule = Rule()
+    moves, positions, captured = [], [], []
+    color = B
+    while len(moves) < n_moves:
+        hot = {(r, c) for caps in captured[len(captured) - cool:] for _, r, c in caps} if cool else set()
+        for _ in range(200):
+            r, c = int(rng.integers(0, side)), int(rng.integers(0, side))
+            if (r, c) in hot:
+                continue
+            try:
+                caps = rule.put(Move(NP_TYPE, (color, r, c)))
+                break
+            except StateError:
+                continue
+        else:
+            break                                            # no legal move found: stop early
+        moves.append((color, r, c))
+        captured.append([(col, y, x) for col, x, y in caps])    # numpy (r, c)
+        pos = np.zeros((gsize, gsize), np.uint8)
+        for x in range(gsize):
+            for y in range(gsize):
+                if rule.stones[x][y] != 'E':
+                    pos[y, x] = 1 if rule.stones[x][y] == B else 2
+        positions.append(pos)
+        color = W if color == B else B
+    return moves, positions, captured
