@@ -145,12 +145,19 @@ def main():
         return (pool_b.submit(ctx_b.board_detect, frames, -1, pipeline.LMAX, True),   # K1..K6, lines on the host
                 pool_s.submit(ctx.stones_detect, frames, M))                       # K8, K10..K12, labels in HBM
 
+    host_s = [0.0, 0.0, 0.0]        # pack, gather, fold: host seconds spent per phase (diagnostic)
+
     def finish_host(board, labels, conf):
         """pack the fixed-size per-frame records, one all-gather (RCCL over xGMI), ordered fold"""
+        t_a = time.perf_counter()
         rec = pipeline.pack_records_raw(board[0], board[1], labels.cpu().numpy(), conf.cpu().numpy())
+        t_b = time.perf_counter()
         full = pipeline.gather_records(rec, world * F, rank, world, cdev) if world > 1 else rec
+        t_c = time.perf_counter()
         pipe.stones = pipeline.StonesFold(ControllerHeadless())     # every step replays the same game from scratch
         pipe.fold(full)
+        t_d = time.perf_counter()
+        host_s[0] += t_b - t_a; host_s[1] += t_c - t_b; host_s[2] += t_d - t_c
 
     def run_steps(k):
         """k steps, two batches in flight: the host part of batch i (contour pruning inside board_detect,
@@ -179,6 +186,7 @@ def main():
     if args.warmup:
         run_steps(args.warmup)
     sync()
+    host_s[:] = [0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     board, labels = run_steps(args.steps)
     sync()
@@ -260,6 +268,10 @@ def main():
             "stages": stages,
             "stage_timing": "HIP events per context stream over %d serial steps after the timed region; the timed "
                             "region overlaps the board and stones paths on two streams" % prof_steps,
+            "host_ms_per_step": {"pack_records": round(1e3 * host_s[0] / args.steps, 3),
+                                 "gather": round(1e3 * host_s[1] / args.steps, 3),
+                                 "ordered_fold": round(1e3 * host_s[2] / args.steps, 3),
+                                 "note": "rank 0; overlapped with the GPU work of the next batches"},
             "lines_found_frame0": int(board[0]["n_lines"][0]),
             "board_found_by_fold": pipe.board.mtx is not None,
             "moves_recorded_by_fold": len(pipe.stones.controller.kifu.moves),

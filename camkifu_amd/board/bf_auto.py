@@ -8,6 +8,7 @@ reference's Python then consumes: the contour count, the biggest minAreaRect are
 (rho, theta) list in OpenCV's order.  The temporal logic (4-frame line accumulation,
 intersection grouping, cluster merging, corner update) is the reference's and stays on the host.
 """
+import bisect
 import math
 import time
 
@@ -68,11 +69,16 @@ class BoardFinderAuto(BoardFinder):
 
     def group_intersections(self, shape):
         """pairwise intersections of sufficiently non-parallel accumulated lines, greedily grouped
-        (x-only proximity test -- reference quirk, bf_auto.py:161)"""
+        (x-only proximity test -- reference quirk, bf_auto.py:161: the squared "distance" is
+        (dx)^2 + (dx)^2).  Same groups in the same order as the reference's loops; the membership test
+        `any(2 dx^2 < thresh for p1 in g)` is answered from the sorted x values of the group (the
+        nearest x decides), which keeps the every-4th-frame cost flat when hundreds of near-duplicate
+        intersections pile up while the board is not found."""
         length_ref = min(shape[0], shape[1])
         margin = -length_ref / 15
         thresh = (length_ref / 80) ** 2
         ordered = sorted(self.lines_accu, key=lambda s: s.theta)
+        xs_of = {id(g): sorted(p[0] for p in g) for g in self.groups_accu}
         for s1 in ordered:
             for s2 in reversed(ordered):
                 if not (math.pi / 3 < s1.line_angle(s2)):
@@ -80,12 +86,25 @@ class BoardFinderAuto(BoardFinder):
                 p0 = s1.intersection(s2)
                 if not imgutil.within_margin(p0, (0, 0, shape[1], shape[0]), margin):
                     continue
+                x = p0[0]
                 for g in self.groups_accu:
-                    if any((p0[0] - p1[0]) ** 2 + (p0[0] - p1[0]) ** 2 < thresh for p1 in g):
+                    xs = xs_of[id(g)]
+                    k = bisect.bisect_left(xs, x)
+                    near = False
+                    if k < len(xs):
+                        d = xs[k] - x
+                        near = d * d + d * d < thresh
+                    if not near and k > 0:
+                        d = x - xs[k - 1]
+                        near = d * d + d * d < thresh
+                    if near:
                         g.append(p0)
+                        xs.insert(k, x)
                         break
                 else:
-                    self.groups_accu.append([p0])
+                    g = [p0]
+                    self.groups_accu.append(g)
+                    xs_of[id(g)] = [x]
 
     def updt_corners(self, length_ref):
         found = False

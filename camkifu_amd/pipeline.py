@@ -296,14 +296,18 @@ class FastFilePipeline:
         u = unpack_records(full)
         n = len(full)
         self.stones.resync()
-        for f in range(n):
+        f = 0
+        while f < n:
             if self.board.hold > 0:                    # hold-off after a hit: nothing to look at
-                self.board.hold -= 1
-                self.board.finder.total_f_processed += 1
+                skip = min(self.board.hold, n - f)
+                self.board.hold -= skip
+                self.board.finder.total_f_processed += skip
+                f += skip
                 continue
             k = int(u["n_lines"][f])
             self.board.step(dict(status=int(u["status"][f]), n_contours=int(u["n_contours"][f]), n_lines=k,
                                  biggest_area=float(u["biggest_area"][f]), lines=u["lines"][f, :k]))
+            f += 1
         emitted = self.stones.step_batch(u["labels"], u["conf"]) if have_mtx else [[] for _ in range(n)]
         self.frames_done += n
         return emitted

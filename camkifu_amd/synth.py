@@ -15,7 +15,7 @@ GSIZE = 19
 E, B, W = 0, 1, 2
 
 
-def random_corners(h, w, rng, jitter=0.05, fill=0.84, slant=0.06):
+def random_corners(h, w, rng, jitter=0.05, fill=0.84, slant=0.06, whole_degrees=True):
     """Four board corners (outer wood edge), clockwise from top-left, as float32 (4,2) (x,y).
     The quad covers well over a third of the frame (area gate, bf_auto.py:82).  Both vertical
     sides are slanted by at least `slant`/2 of the board side: the reference groups line
@@ -31,7 +31,33 @@ def random_corners(h, w, rng, jitter=0.05, fill=0.84, slant=0.06):
         mid = 0.5 * (base[top, 0] + base[bot, 0])
         half = rng.uniform(0.5, 1.0) * slant * side * 0.5
         base[top, 0], base[bot, 0] = mid + sgn * half, mid - sgn * half
+    if whole_degrees:
+        base = _snap_sides(base)
     return base.astype(np.float32)
+
+
+def _snap_sides(quad):
+    """Turn every side about its midpoint onto the nearest whole degree.  cv2.HoughLines votes in
+    1-degree x 1-pixel bins with a threshold of min(h, w) / 5 (bf_auto.py:128): a ~900 px board edge
+    lying between two angle bins smears its votes over 5-8 rho bins and no bin reaches the
+    threshold, so at 1080p the reference's finder only ever locks on when the edges sit close to
+    whole degrees -- which is how this synthetic camera is placed."""
+    lines = []
+    for i in range(4):
+        p, q = quad[i], quad[(i + 1) % 4]
+        mid = 0.5 * (p + q)
+        ang = np.degrees(np.arctan2(q[1] - p[1], q[0] - p[0]))
+        snapped = np.round(ang)
+        if i in (1, 3) and abs(abs(snapped) - 90.0) < 2.0:       # keep the vertical sides slanted by >= 2 degrees
+            snapped = np.sign(snapped) * (90.0 + (2.0 if abs(ang) >= 90.0 else -2.0))
+        d = np.array([np.cos(np.radians(snapped)), np.sin(np.radians(snapped))])
+        lines.append((mid, d))
+    out = np.empty((4, 2), np.float64)
+    for i in range(4):
+        (m0, d0), (m1, d1) = lines[i - 1], lines[i]               # corner i = side (i-1) meets side i
+        t = np.linalg.solve(np.array([d0, -d1]).T, m1 - m0)
+        out[i] = m0 + t[0] * d0
+    return out
 
 
 def random_stones(rng, density=0.3, keep_first_line_empty=True):

@@ -91,3 +91,46 @@ def test_posgrid_and_getrect():
     for k, v in GOLD["sf_getrect"].items():
         r, c = map(int, k.split(","))
         assert list(sf.getrect(r, c)) == v
+
+
+def test_group_intersections_matches_the_plain_double_loop():
+    """the bisect membership test in BoardFinderAuto.group_intersections is a pure speed-up: same
+    groups, same order as the reference's any(...) formulation (bf_auto.py:143-172)"""
+    import math
+    import random
+    from camkifu_amd.board.bf_auto import BoardFinderAuto
+    from camkifu_amd.core import imgutil
+
+    class _VM:
+        imqueue = None
+
+    def plain(lines, shape):
+        length_ref = min(shape[0], shape[1])
+        margin, thresh = -length_ref / 15, (length_ref / 80) ** 2
+        groups = []
+        ordered = sorted(lines, key=lambda s: s.theta)
+        for s1 in ordered:
+            for s2 in reversed(ordered):
+                if not (math.pi / 3 < s1.line_angle(s2)):
+                    break
+                p0 = s1.intersection(s2)
+                if not imgutil.within_margin(p0, (0, 0, shape[1], shape[0]), margin):
+                    continue
+                for g in groups:
+                    if any((p0[0] - p1[0]) ** 2 + (p0[0] - p1[0]) ** 2 < thresh for p1 in g):
+                        g.append(p0)
+                        break
+                else:
+                    groups.append([p0])
+        return groups
+    rng = random.Random(5)
+    for trial in range(200):
+        shape = (480, 640, 3)
+        lines = []
+        for _ in range(rng.randint(2, 24)):
+            theta = rng.choice([0.03, 0.05, 1.55, 1.6, 1.58, 3.1, 0.8]) + rng.uniform(-0.02, 0.02)
+            lines.append(imgutil.segment_from_hough((rng.uniform(-300, 600), theta), shape[:2]))
+        bf = BoardFinderAuto(_VM(), ctx=False)
+        bf.lines_accu = list(lines)
+        bf.group_intersections(shape)
+        assert bf.groups_accu == plain(lines, shape), trial
