@@ -48,6 +48,9 @@ def cpu_baseline(h, w, frames, corners, weights, nframes):
                        % (nframes, w, h))
 
 
+LANES_DEFAULT = 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,6 +64,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--lanes", type=int, default=LANES_DEFAULT,
+                    help="pairs of (board, stones) contexts per GPU; the batch is split between them so more "
+                         "kernels are in flight and drain / host gaps of one lane are filled by the others")
     args = ap.parse_args()
 
     import numpy as np
@@ -89,6 +95,7 @@ def main():
     # context (= HIP stream + scratch), so the host-side gaps of one path are filled by the other
     ctx_b = capi.Context(local_rank)
     ctx = capi.Context(local_rank)
+    lanes = [(ctx_b, ctx)] + [(capi.Context(local_rank), capi.Context(local_rank)) for _ in range(args.lanes - 1)]
     H, W, F = args.height, args.width, args.frames
 
     # ---- synthetic video shard of this rank, rendered straight into HBM --------------------
@@ -129,8 +136,9 @@ def main():
     from camkifu_amd.stone.nn_manager import NNManager, GOLDEN_WEIGHTS
     weights = NNManager.init_net()               # trained fixture when present, else seeded He-normal
     torch.cuda.synchronize()
-    ctx.cnn_set_weights({k: torch.from_numpy(v).to(dev) for k, v in weights.items()})
-    ctx.cnn_set_mode(capi.CK_CNN_BF16 if args.cnn == "bf16" else capi.CK_CNN_FP32)
+    for _, c in lanes:
+        c.cnn_set_weights({k: torch.from_numpy(v).to(dev) for k, v in weights.items()})
+        c.cnn_set_mode(capi.CK_CNN_BF16 if args.cnn == "bf16" else capi.CK_CNN_FP32)
     dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
     M = capi.get_perspective_transform(corners, dst)
     from camkifu_amd import pipeline
@@ -138,12 +146,28 @@ def main():
     pipe = pipeline.FastFilePipeline(H, W, ControllerHeadless(), ctx=ctx, ctx_board=ctx_b, rank=rank, world=world,
                                      device=cdev)
     # one host thread per context (a context is single-threaded by contract), each with its own stream
-    pool_b, pool_s = ThreadPoolExecutor(1), ThreadPoolExecutor(1)
+    pools = [(ThreadPoolExecutor(1), ThreadPoolExecutor(1)) for _ in lanes]
+    cuts = [round(i * F / len(lanes)) for i in range(len(lanes) + 1)]
+    slices = [frames[cuts[i]:cuts[i + 1]] for i in range(len(lanes))]
+
+    class _Both:
+        """the per-lane futures of one step, joined: board = (records, lines), stones = (labels, conf)"""
+        def __init__(self, futs):
+            self.futs = futs
+
+        def board(self):
+            parts = [fb.result() for fb, _ in self.futs]
+            return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]))
+
+        def stones(self):
+            parts = [fs.result() for _, fs in self.futs]
+            return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
 
     def launch():
-        """GPU part of one step, on two host threads / two HIP streams"""
-        return (pool_b.submit(ctx_b.board_detect, frames, -1, pipeline.LMAX, True),   # K1..K6, lines on the host
-                pool_s.submit(ctx.stones_detect, frames, M))                       # K8, K10..K12, labels in HBM
+        """GPU part of one step: per lane, the board path and the stones path on two host threads / HIP streams"""
+        return _Both([(pb.submit(cb.board_detect, fr, -1, pipeline.LMAX, True),        # K1..K6, lines on the host
+                       ps.submit(cs.stones_detect, fr, M))                             # K8, K10..K12, labels in HBM
+                      for (pb, ps), (cb, cs), fr in zip(pools, lanes, slices)])
 
     host_s = [0.0, 0.0, 0.0]        # pack, gather, fold: host seconds spent per phase (diagnostic)
 
@@ -166,8 +190,8 @@ def main():
         inflight = [launch() for _ in range(min(DEPTH, k))]
         for i in range(k):
             futs = inflight.pop(0)
-            board = futs[0].result()
-            labels, conf = futs[1].result()
+            board = futs.board()
+            labels, conf = futs.stones()
             if i + DEPTH < k:
                 inflight.append(launch())
             finish_host(board, labels, conf)
@@ -262,7 +286,8 @@ def main():
             "dtype": "u8" if args.cnn == "fp32" else "u8+bf16", "data": "synthetic",
             "config": {"workload": "%dx%d synthetic video, %d-frame batch per GPU, board detect (K1-K6) + "
                                    "stones detect (K8,K10-K12), cnn %s" % (W, H, F, args.cnn),
-                       "frames_per_gpu": F, "height": H, "width": W, "parallelism": "frames sharded x%d" % world},
+                       "frames_per_gpu": F, "height": H, "width": W, "parallelism": "frames sharded x%d" % world,
+                       "lanes_per_gpu": len(lanes)},
             "roofline": roof,
             "filter_pass": filt,
             "stages": stages,
