@@ -91,6 +91,10 @@ def _in(a, dtype=np.uint8):
     if _is_torch(a):
         assert a.is_contiguous()
         if a.is_cuda:
+            # the library works on its own HIP stream: whatever torch still has queued that produces
+            # this tensor must have finished before the pointer is handed over
+            import torch
+            torch.cuda.current_stream(a.device).synchronize()
             return C.c_void_p(a.data_ptr()), CK_DEVICE, a
         a = a.numpy()
     a = np.ascontiguousarray(a, dtype)

@@ -434,3 +434,59 @@ def test_y4m_file_through_the_pipeline(ck, ora, synth, tmp_path):
     assert pipe.board.mtx is not None and np.array_equal(pipe.board.mtx, pipe2.board.mtx)
     assert ctrl.kifu.to_sgf() == ctrl2.kifu.to_sgf() and pipe.frames_done == len(idx)
     assert len(ctrl.kifu.moves) > 0
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE config 3)
+def test_full_size_batch_properties(ck, ora, synth):
+    """1080p, a 64-frame batch resident in HBM -- too big for the oracle, so the checks are the
+    size-independent ones: a frame gives the same result alone and inside a batch (any position),
+    results do not depend on the run (atomics only ever build sets), permuting the batch permutes the
+    results, every edge pixel is an NMS survivor, and three frames spot-checked against the oracle."""
+    import torch
+    from camkifu_amd.stone.nn_manager import NNManager
+    n, H, W = 64, 1080, 1920
+    rng = np.random.default_rng(77)
+    corners = synth.random_corners(H, W, rng)
+    dev = torch.device("cuda:0")
+    frames = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+    for i in range(n):
+        stones = synth.random_stones(np.random.default_rng(1000 + i % 9), density=0.05 * (i % 9))
+        frames[i] = synth.render(H, W, stones, corners, seed=5000 + i, device=dev)
+    ck.cnn_set_weights(NNManager.init_net())
+    dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
+    M = ora.get_perspective_transform(corners, dst)
+
+    rec, lines = ck.board_detect(frames, raw=True)
+    labels, conf = ck.stones_detect(frames, M)
+    labels, conf = labels.cpu().numpy(), conf.cpu().numpy()
+    assert (rec["status"] == 0).all() and (rec["n_lines"] >= 3).all()
+    # determinism
+    rec2, lines2 = ck.board_detect(frames, raw=True)
+    assert np.array_equal(rec, rec2) and np.array_equal(lines, lines2)
+    # alone == in batch, for frames at both ends, a chunk boundary of the classifier and the middle
+    for i in (0, 17, 31, 32, 63):
+        r1, l1 = ck.board_detect(frames[i:i + 1], raw=True)
+        assert np.array_equal(r1[0], rec[i]) and np.array_equal(l1[0], lines[i]), i
+        la, ca = ck.stones_detect(frames[i:i + 1], M)
+        assert np.array_equal(la.cpu().numpy()[0], labels[i]) and np.array_equal(ca.cpu().numpy()[0], conf[i]), i
+    # permutation equivariance
+    perm = torch.from_numpy(np.random.default_rng(3).permutation(n)).to(dev)
+    recp, linesp = ck.board_detect(frames[perm].contiguous(), raw=True)
+    p = perm.cpu().numpy()
+    assert np.array_equal(recp, rec[p]) and np.array_equal(linesp, lines[p])
+    # edges are a subset of the NMS survivors; strong survivors are edges
+    sub = frames[:4]
+    med = ck.median15(sub)
+    edges, nms = ck.canny(med, want_map=True)
+    edges, nms = edges.cpu().numpy(), nms.cpu().numpy()
+    assert not (edges.astype(bool) & (nms == 1)).any() and edges[nms == 2].all()
+    # oracle spot checks (three frames, seconds each)
+    for i in (0, 40, 63):
+        fr = frames[i].cpu().numpy()
+        e = ora.canny(ora.median(fr, 15), 25, 75)
+        res = ora.board_lines(e)
+        k = int(rec["n_lines"][i])
+        assert res["status"] == k and np.array_equal(res["lines"][:k], lines[i, :k])
+        gob = ora.warp_perspective(fr, M)
+        l2, c2 = ora.decode_all(ora.cnn_predict_regions(NNManager.init_net(), gob))
+        assert np.array_equal(labels[i], l2)
