@@ -48,7 +48,7 @@ def cpu_baseline(h, w, frames, corners, weights, nframes):
                        % (nframes, w, h))
 
 
-LANES_DEFAULT = 1
+LANES_DEFAULT = 2
 
 
 def main():
