@@ -13,8 +13,12 @@ from ..golib_shim import gsize, E, B, W
 
 colors = {E: 0, B: 1, W: 2}
 rcolors = {0: E, 1: B, 2: W}
-GOLDEN_WEIGHTS = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
-                              "tests", "golden", "cnn_weights.npz")
+# The trained model file (reference: KERAS_MODEL_FILE = cvconf.train_dir + "/model/keras.h5",
+# stone/nn_manager.py:22).  The author's file cannot be fetched here; the repository ships a classifier
+# trained on the synthetic renderer (tools/train_cnn.py) in the same Keras-1 HDF5 layout.
+KERAS_MODEL_FILE = os.environ.get("CAMKIFU_KERAS_MODEL") or os.path.join(
+    os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "keras.h5")
+GOLDEN_WEIGHTS = KERAS_MODEL_FILE
 
 
 class NNManager:
@@ -41,10 +45,20 @@ class NNManager:
 
     @staticmethod
     def init_net(download=False):
-        """weights in Keras-1 'tf' layout: the trained fixture when present, else seeded He-normal"""
-        if os.path.isfile(GOLDEN_WEIGHTS):
-            z = np.load(GOLDEN_WEIGHTS)
-            return {k: np.ascontiguousarray(z[k], np.float32) for k in capi.WEIGHT_ORDER}
+        """weights in Keras-1 'tf' layout: the model file when present (stone/nn_manager.py:65-73 loads it
+        with keras.models.load_model; here stone/keras1.py + h5lite read it), else create_net():
+        seeded He-normal"""
+        if os.path.isfile(KERAS_MODEL_FILE):
+            return NNManager.load_model(KERAS_MODEL_FILE)
+        return NNManager.create_net()
+
+    @staticmethod
+    def load_model(path):
+        from . import keras1
+        return keras1.load_model(path)
+
+    @staticmethod
+    def create_net():
         from .. import synth
         return synth.cnn_weights()
 

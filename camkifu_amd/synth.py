@@ -156,7 +156,7 @@ def video(nframes, h, w, seed=SEED, device="cpu", new_stone_every=5, noise=3.0):
 def cnn_weights(seed=SEED, as_torch=False, device="cpu"):
     """He-normal synthetic weights in Keras-1 'tf' layout; conv1 is scaled by 1/128 because the
     reference feeds raw 0..255 pixels (nn_cache.py:47-51) and random weights have no reason to
-    compensate for it.  Replaced by trained weights when tests/golden/cnn_weights.npz exists."""
+    compensate for it.  Replaced by the trained model when tests/golden/keras.h5 exists (NNManager.init_net)."""
     from .capi import WEIGHT_SHAPES, WEIGHT_ORDER
     rng = np.random.default_rng(seed)
     Wt = {}
