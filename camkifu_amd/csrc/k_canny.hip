@@ -47,34 +47,51 @@ __global__ __launch_bounds__(256) void canny_nms_kernel(const uint8_t* __restric
     const uint8_t (*px)[LH][LWD * 4] = reinterpret_cast<const uint8_t (*)[LH][LWD * 4]>(pxw);
 
     const int TG22 = 13573;   // (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
-    for (int i = tid; i < MH * MW; i += 256) {
-        const int r = i / MW, col = i % MW;
-        const int y = oy - 1 + r, x = ox - 1 + col;
-        int32_t packed = 0;                       // outside the image the magnitude is 0
-        if (y >= 0 && y < h && x >= 0 && x < w) {
-            // Sobel taps use replicate border relative to the IMAGE: clamp, then index the tile
-            const int r0 = (y - 1 < 0 ? 0 : y - 1) - (oy - 2), r1 = y - (oy - 2), r2 = (y + 1 > h - 1 ? h - 1 : y + 1) - (oy - 2);
-            const int c0 = (x - 1 < 0 ? 0 : x - 1) - (ox - 4), c1 = x - (ox - 4), c2 = (x + 1 > w - 1 ? w - 1 : x + 1) - (ox - 4);
-            int best = -1, bdx = 0, bdy = 0;
+    // Gradient tile (MH x MW, 1-px halo around the output tile).  One thread = one column x 6 rows, walked
+    // top to bottom with the separable Sobel kept in registers: per pixel row the horizontal difference
+    // r - l and the horizontal smooth l + 2c + r of each channel; dx = d[-1] + 2 d[0] + d[+1],
+    // dy = s[+1] - s[-1].  Rows outside the image are already replicated in the pixel tile (clamped row
+    // loads); columns are replicated by clamping the two side taps.
+    if (tid < 3 * MW) {
+        const int col = tid % MW, seg = tid / MW;
+        const int x = ox - 1 + col;
+        const bool xin = x >= 0 && x < w;
+        const int cl = (x - 1 < 0 ? 0 : x - 1) - (ox - 4), cc = x - (ox - 4), cr = (x + 1 > w - 1 ? w - 1 : x + 1) - (ox - 4);
+        constexpr int RSEG = MH / 3;                   // 6 gradient rows per thread
+        int hd[3][3], hs[3][3];                        // [row slot][channel]
+#pragma unroll
+        for (int k = 0; k < RSEG + 2; k++) {
+            const int pr = seg * RSEG + k;             // pixel-tile row
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const int a00 = px[c][r0][c0], a01 = px[c][r0][c1], a02 = px[c][r0][c2];
-                const int a10 = px[c][r1][c0], a12 = px[c][r1][c2];
-                const int a20 = px[c][r2][c0], a21 = px[c][r2][c1], a22 = px[c][r2][c2];
-                const int dx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
-                const int dy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
-                const int m = abs(dx) + abs(dy);
-                if (m > best) { best = m; bdx = dx; bdy = dy; }
+                const int l = xin ? px[c][pr][cl] : 0, m = xin ? px[c][pr][cc] : 0, r = xin ? px[c][pr][cr] : 0;
+                hd[k % 3][c] = r - l;
+                hs[k % 3][c] = l + 2 * m + r;
             }
-            const int ax = abs(bdx), ay = abs(bdy) << 15;
-            const int tg22x = ax * TG22;
-            int sector;
-            if (ay < tg22x) sector = 0;
-            else if (ay > tg22x + (ax << 16)) sector = 1;
-            else sector = ((bdx ^ bdy) < 0) ? 3 : 2;
-            packed = best | (sector << 16);
+            if (k >= 2) {
+                const int gr = seg * RSEG + k - 2;     // gradient-tile row
+                const int y = oy - 1 + gr;
+                int best = -1, bdx = 0, bdy = 0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const int dx = hd[(k - 2) % 3][c] + 2 * hd[(k - 1) % 3][c] + hd[k % 3][c];
+                    const int dy = hs[k % 3][c] - hs[(k - 2) % 3][c];
+                    const int m = abs(dx) + abs(dy);
+                    if (m > best) { best = m; bdx = dx; bdy = dy; }
+                }
+                int32_t packed = 0;                    // outside the image the magnitude is 0
+                if (xin && y >= 0 && y < h) {
+                    const int ax = abs(bdx), ay = abs(bdy) << 15;
+                    const int tg22x = ax * TG22;
+                    int sector;
+                    if (ay < tg22x) sector = 0;
+                    else if (ay > tg22x + (ax << 16)) sector = 1;
+                    else sector = ((bdx ^ bdy) < 0) ? 3 : 2;
+                    packed = best | (sector << 16);
+                }
+                mg[gr][col] = packed;
+            }
         }
-        mg[r][col] = packed;
     }
     __syncthreads();
 
