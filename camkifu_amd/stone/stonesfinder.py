@@ -4,13 +4,13 @@ stone/stonesfinder.py:95-176, 250-349, 412-450, 950-981).
 _doframe = K8 warpPerspective(frame, board_finder.mtx, (380, 380)) -> K9 MOG2 background model
 -> _learn -> _find(goban_img); both image stages run on the GPU through the C-ABI.  Results go
 to the controller through suggest / remove / bulk_update in numpy (row, col) coordinates.
-Line-based emptiness checks, grid learning and the deletion watch are "next" rows."""
+Line-based emptiness checks and grid learning are "next" rows."""
 import queue
 
 import numpy as np
 
 from .. import capi, cvconf
-from ..core.exceptions import DeletedError
+from ..core.exceptions import CorrectionWarning, DeletedError
 from ..core.video import VidProcessor
 from ..golib_shim import gsize, E, B, W, Move, NP_TYPE
 
@@ -31,7 +31,9 @@ class StonesFinder(VidProcessor):
             video = getattr(self.vmanager, "current_video", None)
             is_img = isinstance(video, str) and video.lower().endswith((".png", ".jpg"))
             self.bg_init_frames = 0 if is_img else 50
+        # (quite primal) "learning" attributes, see _learn()
         self.corrections = queue.Queue(correc_size)
+        self.saved_bg = np.zeros(self.canonical_shape + (3,), dtype=np.float32)
         self.deleted = {}
         self.nb_del_samples = 50
 
@@ -61,20 +63,50 @@ class StonesFinder(VidProcessor):
             self._fg = self.ctx.mog2_apply(self.bg_model, self.goban_img, learning)          # K9
 
     def _learn(self):
-        """user corrections: drained but not learnt from yet (deletion watch is a next row)"""
+        """User corrections (stonesfinder.py:178-222).  A deletion (or a moved stone) puts the emptied
+        intersection under watch: its pixels are averaged over nb_del_samples calm frames into
+        saved_bg, and _check_dels refuses new suggestions there until the zone looks different."""
+        unprocessed = []
         try:
             while True:
                 err, exp = self.corrections.get_nowait()
-                if err is not None and exp is None:
-                    self.deleted[(err.y, err.x)] = self.nb_del_samples
+                if exp is None:
+                    self.deleted[(err.y, err.x)] = self.nb_del_samples      # Move.x / Move.y are image coordinates
+                elif err is not None and (err.x, err.y) != (exp.x, exp.y):
+                    self.deleted[(err.y, err.x)] = self.nb_del_samples      # a stone has been moved
+                else:
+                    unprocessed.append((err, exp))                          # a missed stone: left to subclasses
         except queue.Empty:
             pass
+        for (r, c), nb_left in self.deleted.items():
+            if nb_left:
+                fg = self.get_foreground()
+                x0, y0, x1, y1 = self.getrect(r, c)
+                # reference quirk kept: the comparison sits INSIDE the sum (count of pixels below the
+                # bound), so the zone is sampled unless every pixel of it is foreground
+                if fg is None or np.sum(fg[x0:x1, y0:y1] < 0.1 * (x1 - x0) * (y1 - y0)):
+                    self.saved_bg[x0:x1, y0:y1] += self.goban_img[x0:x1, y0:y1] / self.nb_del_samples
+                    self.deleted[(r, c)] = nb_left - 1
+        if 0 < len(unprocessed):
+            raise CorrectionWarning(unprocessed, message="Unhandled corrections")
 
     def get_foreground(self):
         return self._fg
 
     def _check_dels(self, r, c):
-        if (r, c) in self.deleted:
+        """stonesfinder.py:223-245: has this intersection been deleted by the user recently?"""
+        try:
+            nb_samples_left = self.deleted[(r, c)]
+        except KeyError:
+            return
+        if 0 == nb_samples_left:                       # only check when sampling has completed
+            x0, y0, x1, y1 = self.getrect(r, c)
+            diff = self.saved_bg[x0:x1, y0:y1] - self.goban_img[x0:x1, y0:y1]
+            if np.sum(np.absolute(diff)) / (diff.shape[0] * diff.shape[1]) < 40:
+                raise DeletedError(((r, c),), "The zone has not changed enough since last deletion.")
+            print("previously user-deleted location: {} now unlocked".format((r, c)))
+            del self.deleted[(r, c)]
+        else:
             raise DeletedError(((r, c),), "The zone has been marked as deleted too recently.")
 
     # ---- result sink ---------------------------------------------------------------------------
