@@ -17,6 +17,17 @@
 //
 // HBM traffic: each input byte is read ~(64*78)/(48*64) = 1.6x (L2 absorbs the halo),
 // output written once, planar [n][3][h][pitch] so the next stage reads dwords.
+//
+// The kernel is VALU-issue bound (every instruction below costs one 4-cycle wave64 slot, v_mad_u64_u32
+// two: tools/micro/valu_rates.hip), so its time is (#box filters per tile) x (376 instructions).
+// Costed against the distinct-prefix counts of real median images (1080p board scenes, ~20.6 box
+// filters per 48x64 tile, lower bound ~12.7 from the distinct medians):
+//   * tile shapes 48x16 .. 48x128 and full-wave rows 240x8 .. 240x32: 48x48 / 48x64 are the minimum
+//     (smaller tiles pay the 14-row / 14-column halo, larger ones hold more distinct medians);
+//   * 8 pixels per lane (112-wide tiles, better lane use, fewer DPP shifts): the tile then holds
+//     ~23-25 prefixes and the registers drop the occupancy -- a wash;
+//   * skipping thresholds outside the tile's input value range, or a sampled-range + linear scan:
+//     no gain on board scenes (the input range of a tile is wide; flat tiles are already cheap).
 #include "ck_common.h"
 
 namespace {
