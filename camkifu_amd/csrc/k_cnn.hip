@@ -383,37 +383,47 @@ __global__ __launch_bounds__(64 * (27 / R)) void conv1_mfma16_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16 mode (CK_CNN_BF16): same implicit GEMM on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
-//   in : [patch][H][W][CINP] bf16, CINP a multiple of 16 (padding channels are zero)
-//   wt : [COUTS][KH*KW*CINP] bf16 -- one contiguous K vector per output channel, so a lane's
-//        B fragment (8 consecutive k of one column) is a single 16-byte load
-//   out: [patch][pixels][COUTS] bf16 (channels >= COUT written as zero)
-// LDS pixel stride is CINP + 8 elements: 16-byte fragments of 16 consecutive pixels land on
-// disjoint 4-bank groups (conflict-free ds_read_b128).
+// bf16 mode (CK_CNN_BF16): the same implicit GEMM on v_mfma_f32_16x16x32_bf16 (fp32 accumulate).
+// Same work split, tiling, in-lane pooling and wave balance as conv_mfma16_f32_kernel; one k-step is
+// 32 input channels of one kernel tap (a lane's fragment = 8 consecutive channels = one ds_read_b128).
+//   in : [patch][H][W][CINP] bf16, CINP a multiple of 32 (padding channels are zero)
+//   wt : [16-channel tile][k-step][lane][8] bf16 (pack_mfma16_bf16): a wave's B operand is one coalesced 1 KB load
+//   out: [patch][pixels or pooled][COUTS] bf16 (channels >= COUT written as zero)
+// LDS pixel stride is CINP + 8 elements (16-byte fragments of 8 consecutive pixels land on disjoint bank
+// groups); the row stride keeps that walk going across a tile's row wrap / its second pixel row.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int H, int W, int CINP, int KH, int KW, int COUT, int COUTS, int R, int WAVES_M, bool POOL>
-__global__ __launch_bounds__(64 * WAVES_M * (COUTS / 32)) void conv_mfma_bf16_kernel(
+__host__ __device__ constexpr int lds_stride_b(int n, int rem, int mod) { return n + ((rem - n % mod) + mod) % mod; }
+
+template <int H, int W, int CINP, int KH, int KW, int COUT, int COUTS, int TB, int YB, int WAVES_M, bool POOL>
+__global__ __launch_bounds__(64 * WAVES_M * (COUTS / 16)) void conv_mfma16_bf16_kernel(
     const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt, const float* __restrict__ bias,
     uint16_t* __restrict__ out)
 {
     constexpr int OH = H - KH + 1, OW = W - KW + 1, M = OH * OW;
-    constexpr int NT = COUTS / 32, KP = KH * KW * CINP;
-    constexpr int CP = CINP + 8;
-    constexpr int TILES_WG = WAVES_M * R;
-    constexpr int ROWS = (TILES_WG * 32 + OW - 2) / OW + 1 + KH - 1;
-    constexpr int ROWS_C = ROWS < H ? ROWS : H;
-    __shared__ __attribute__((aligned(16))) uint16_t lds[ROWS_C * W * CP];
+    constexpr int NT = COUTS / 16;
+    static_assert(CINP % 32 == 0 && COUTS % 16 == 0, "channels padded to the MFMA shape");
+    constexpr int CS = CINP + 8;                                   // elements; 2*CS = 80 (mod 128) bytes
+    // row stride in elements: bytes = 64 (mod 128) for 4x4 pooling tiles, = 80*OW (mod 128) for plain tiles
+    constexpr int RS = lds_stride_b(W * CS, POOL ? 32 : (40 * OW) % 64, 64);
+    constexpr int KS = KH * KW * (CINP / 32);
+    constexpr int NTHREADS = 64 * WAVES_M * NT;
+    constexpr int R = cdiv(TB, WAVES_M);
+    constexpr int RT = POOL ? (OH / 4) * (OW / 4) : cdiv(M, 16);
+    static_assert(TB * YB >= RT && R * WAVES_M - TB <= 1, "tile split");
+    static_assert(!POOL || (OW % 4 == 0 && OH % 4 == 0 && TB % (OW / 4) == 0), "pooling tiles are 4x4 output pixels");
+    constexpr int ROWS_RAW = POOL ? 4 * (TB / (OW / 4)) + KH - 1 : (TB * 16 + OW - 2) / OW + 1 + KH - 1;
+    constexpr int ROWS = ROWS_RAW < H ? ROWS_RAW : H;
+    __shared__ __attribute__((aligned(16))) uint16_t lds[ROWS * RS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / NT, wn = wave % NT;
-    const int l31 = lane & 31, hi = lane >> 5;
+    const int wn = wave % NT, wm = wave / NT;
+    const int l15 = lane & 15, kq = lane >> 4;
     const int patch = blockIdx.x;
-    const int m_wg0 = blockIdx.y * TILES_WG * 32;
-    const int oy_min = m_wg0 / OW;
+    const int tile_blk = blockIdx.y * TB;
+    const int oy_min = POOL ? 4 * (tile_blk / (OW / 4)) : (tile_blk * 16) / OW;
     int row_cnt = H - oy_min;
-    if (row_cnt > ROWS_C) row_cnt = ROWS_C;
-    constexpr int NTHREADS = 64 * WAVES_M * NT;
+    if (row_cnt > ROWS) row_cnt = ROWS;
     {
         constexpr int CH8 = CINP / 8;
         const uint4* g = reinterpret_cast<const uint4*>(in + ((size_t)patch * H + oy_min) * W * CINP);
@@ -421,109 +431,93 @@ __global__ __launch_bounds__(64 * WAVES_M * (COUTS / 32)) void conv_mfma_bf16_ke
 #pragma unroll 4
         for (int i = tid; i < total; i += NTHREADS) {
             const int pxl = i / CH8, ch = i % CH8;
-            *reinterpret_cast<uint4*>(&lds[pxl * CP + ch * 8]) = g[i];
+            *reinterpret_cast<uint4*>(&lds[(pxl / W) * RS + (pxl % W) * CS + ch * 8]) = g[i];
         }
     }
     __syncthreads();
 
+    const int tile0 = tile_blk + wm * R;
     int abase[R];
-    const int tile0 = (blockIdx.y * WAVES_M + wm) * R;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        int m = (tile0 + r) * 32 + l31;
-        if (m > M - 1) m = M - 1;
-        const int oy = m / OW, ox = m % OW;
-        abase[r] = ((oy - oy_min) * W + ox) * CP + 8 * hi;
+        int t = tile0 + r;
+        if (t > RT - 1) t = RT - 1;
+        int oy, ox;
+        if constexpr (POOL) {
+            const int ty = t / (OW / 4), tx = t % (OW / 4), q = l15 >> 2, sub = l15 & 3;
+            oy = 4 * ty + 2 * (q >> 1) + (sub >> 1);
+            ox = 4 * tx + 2 * (q & 1) + (sub & 1);
+        } else {
+            int m = t * 16 + l15;
+            if (m > M - 1) m = M - 1;
+            oy = m / OW; ox = m % OW;
+        }
+        abase[r] = (oy - oy_min) * RS + ox * CS + 8 * kq;
     }
-    f32x16 acc[R];
+    f32x4 acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[r][e] = 0.f;
+        for (int e = 0; e < 4; e++) acc[r][e] = 0.f;
 
-    constexpr int MT = cdiv(M, 32);
-    int nv = MT - tile0;
+    int nv = TB - wm * R;
     nv = nv > R ? R : nv;
-    const uint16_t* wrow0 = wt + (size_t)(wn * 32 + l31) * KP + 8 * hi;
+    const uint4* wq = reinterpret_cast<const uint4*>(wt) + (size_t)wn * KS * 64 + lane;
     auto k_loop = [&](auto nv_tag) {
         constexpr int NV = decltype(nv_tag)::value;
+        constexpr int PF = 4;
+        uint4 bq[PF];
+#pragma unroll
+        for (int u = 0; u < PF; u++) bq[u] = u < KS ? wq[(size_t)u * 64] : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < KH; i++) {
 #pragma unroll
             for (int j = 0; j < KW; j++) {
 #pragma unroll
-                for (int c16 = 0; c16 < CINP / 16; c16++) {
-                    const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wrow0 + (i * KW + j) * CINP + c16 * 16));
+                for (int cc = 0; cc < CINP / 32; cc++) {
+                    const int step = (i * KW + j) * (CINP / 32) + cc;
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, bq[step % PF]);
+                    if (step + PF < KS) bq[step % PF] = wq[(size_t)(step + PF) * 64];
 #pragma unroll
                     for (int r = 0; r < NV; r++) {
-                        const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&lds[abase[r] + (i * W + j) * CP + c16 * 16]));
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r], 0, 0, 0);
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&lds[abase[r] + i * RS + j * CS + 32 * cc]));
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[r], 0, 0, 0);
                     }
                 }
             }
         }
     };
-    if (nv >= R) k_loop(std::integral_constant<int, R>{});
-    else if constexpr (R > 1) {
-        if (nv == R - 1) k_loop(std::integral_constant<int, R - 1>{});
-        else if constexpr (R > 2) {
-            if (nv == R - 2) k_loop(std::integral_constant<int, R - 2>{});
-            else if constexpr (R > 3) { if (nv == R - 3) k_loop(std::integral_constant<int, R - 3>{}); }
-        }
-    }
+    if (nv == R) k_loop(std::integral_constant<int, R>{});
+    else if constexpr (R * WAVES_M > TB) k_loop(std::integral_constant<int, R - 1>{});
 
-    const int co = wn * 32 + l31;
+    const int co = wn * 16 + l15;
     const float bv = co < COUT ? bias[co] : 0.f;
     if constexpr (POOL) {
-        static_assert(!POOL || (OW == 32 && R % 2 == 0), "fused pooling needs one tile per output row");
-        constexpr int PW = OW / 2;
-        uint16_t* o = out + (size_t)patch * (OH / 2) * PW * COUTS;
+        uint16_t* o = out + (size_t)patch * (M / 4) * COUTS;
 #pragma unroll
-        for (int r = 0; r < R; r += 2) {
-            const int oy = tile0 + r;
-            if (oy >= OH) continue;
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                const int ox = (e & 3) + 8 * (e >> 2) + 4 * hi;
-                float v0 = acc[r][e] + bv, v1 = acc[r][e + 1] + bv;
-                float v2 = acc[r + 1][e] + bv, v3 = acc[r + 1][e + 1] + bv;
-                float mx = v0 > v1 ? v0 : v1; mx = mx > v2 ? mx : v2; mx = mx > v3 ? mx : v3;
-                mx = mx > 0.f ? mx : 0.f;
-                o[((size_t)(oy / 2) * PW + ox / 2) * COUTS + co] = co < COUT ? f2bf(mx) : (uint16_t)0;
-            }
+        for (int r = 0; r < R; r++) {
+            const int t = tile0 + r;
+            float mx = acc[r][0] > acc[r][1] ? acc[r][0] : acc[r][1];
+            const float m2 = acc[r][2] > acc[r][3] ? acc[r][2] : acc[r][3];
+            mx = mx > m2 ? mx : m2;
+            mx = mx + bv;
+            mx = mx > 0.f ? mx : 0.f;
+            const int py = 2 * (t / (OW / 4)) + (kq >> 1), px = 2 * (t % (OW / 4)) + (kq & 1);
+            if (r < nv && t < RT) o[(size_t)(py * (OW / 2) + px) * COUTS + co] = co < COUT ? f2bf(mx) : (uint16_t)0;
         }
     } else {
         uint16_t* o = out + (size_t)patch * M * COUTS;
 #pragma unroll
         for (int r = 0; r < R; r++) {
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int m = (tile0 + r) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            for (int e = 0; e < 4; e++) {
+                const int m = (tile0 + r) * 16 + 4 * kq + e;
                 float v = acc[r][e] + bv;
                 v = v > 0.f ? v : 0.f;
-                if (m < M) o[(size_t)m * COUTS + co] = co < COUT ? f2bf(v) : (uint16_t)0;
+                if (r < nv && m < M) o[(size_t)m * COUTS + co] = co < COUT ? f2bf(v) : (uint16_t)0;
             }
         }
     }
-}
-
-// 2x2 max pool on bf16, channels-last
-__global__ void pool2_bf16_kernel(const uint16_t* __restrict__ in, int H, int W, int C, uint16_t* __restrict__ out, size_t total)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int OW = W / 2, OH = H / 2;
-    const int c = (int)(i % C);
-    const int x = (int)((i / C) % OW);
-    const int y = (int)((i / ((size_t)C * OW)) % OH);
-    const size_t p = i / ((size_t)C * OW * OH);
-    const uint16_t* b = in + ((p * H + 2 * y) * W + 2 * x) * C + c;
-    // non-negative bf16 values order like their bit patterns
-    uint16_t m = b[0];
-    uint16_t v = b[C]; m = m > v ? m : v;
-    v = b[(size_t)W * C]; m = m > v ? m : v;
-    v = b[(size_t)W * C + C]; m = m > v ? m : v;
-    out[i] = m;
 }
 
 // dense 3456(=36 px x 96 padded channels) -> 160 + relu, bf16 operands: one wave = 32 patches x 32 outputs
@@ -767,15 +761,23 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
     pack_fc1(host[8].data(), t);               CK_TRY(up(ctx->cnn.d1w, t));
     CK_TRY(up(ctx->cnn.d1b, host[9]));
     CK_TRY(up(ctx->cnn.d2w, host[10])); CK_TRY(up(ctx->cnn.d2b, host[11]));
-    // bf16 packs: [cout padded][kh*kw*cin padded], flip applied, padding rows / channels zero
+    // bf16 packs in MFMA fragment order: [16-channel tile][k-step][lane = kslot*16 + channel][8 consecutive cin],
+    // k-step = 32 input channels of one kernel tap; flip applied, padding channels zero
     auto pack_bf = [&](const float* k, int KH, int KW, int CIN, int CINP, int COUT, int COUTS, DevBuf& dst) -> int {
-        std::vector<uint16_t> v((size_t)COUTS * KH * KW * CINP, 0);
-        for (int o = 0; o < COUT; o++)
+        const int KS = KH * KW * (CINP / 32), NT = COUTS / 16;
+        std::vector<uint16_t> v((size_t)NT * KS * 64 * 8, 0);
+        for (int nt = 0; nt < NT; nt++)
             for (int i = 0; i < KH; i++)
                 for (int j = 0; j < KW; j++)
-                    for (int c = 0; c < CIN; c++)
-                        v[(size_t)o * KH * KW * CINP + (i * KW + j) * CINP + c] =
-                            f2bf(k[(((size_t)(KH - 1 - i) * KW + (KW - 1 - j)) * CIN + c) * COUT + o]);
+                    for (int cc = 0; cc < CINP / 32; cc++)
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int e = 0; e < 8; e++) {
+                                const int c = 32 * cc + 8 * (lane / 16) + e, o = nt * 16 + lane % 16;
+                                if (c >= CIN || o >= COUT) continue;
+                                const int step = (i * KW + j) * (CINP / 32) + cc;
+                                v[(((size_t)nt * KS + step) * 64 + lane) * 8 + e] =
+                                    f2bf(k[(((size_t)(KH - 1 - i) * KW + (KW - 1 - j)) * CIN + c) * COUT + o]);
+                            }
         CK_TRY(ck_ensure(ctx, dst, v.size() * 2));
         CK_HIP(ctx, hipMemcpy(dst.p, v.data(), v.size() * 2, hipMemcpyHostToDevice));
         return CK_OK;
@@ -830,23 +832,20 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             }
             {
                 TimeScope ts(ctx, "cnn_conv2");
-                hipLaunchKernelGGL((conv_mfma_bf16_kernel<36, 36, 32, 5, 5, 32, 32, 2, 4, true>), dim3(np, 4), dim3(256), 0,
+                hipLaunchKernelGGL((conv_mfma16_bf16_kernel<36, 36, 32, 5, 5, 32, 32, 16, 4, 4, true>), dim3(np, 4), dim3(512), 0,
                                    ctx->stream, (const uint16_t*)b1, (const uint16_t*)W.c2w_bf.p, (const float*)W.c2b.p, b2);
             }
             uint16_t* b3 = b1;
             {
                 TimeScope ts(ctx, "cnn_conv3");
-                hipLaunchKernelGGL((conv_mfma_bf16_kernel<16, 16, 32, 3, 3, 90, 96, 4, 2, false>), dim3(np, 1), dim3(384), 0,
+                hipLaunchKernelGGL((conv_mfma16_bf16_kernel<16, 16, 32, 3, 3, 90, 96, 13, 1, 2, false>), dim3(np), dim3(768), 0,
                                    ctx->stream, (const uint16_t*)b2, (const uint16_t*)W.c3w_bf.p, (const float*)W.c3b.p, b3);
             }
-            uint16_t* b4 = b2;
             {
                 TimeScope ts(ctx, "cnn_conv4");
-                hipLaunchKernelGGL((conv_mfma_bf16_kernel<14, 14, 96, 3, 3, 90, 96, 3, 2, false>), dim3(np, 1), dim3(384), 0,
-                                   ctx->stream, (const uint16_t*)b3, (const uint16_t*)W.c4w_bf.p, (const float*)W.c4b.p, b4);
-                const size_t total = (size_t)np * 6 * 6 * 96;
-                hipLaunchKernelGGL(pool2_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                                   (const uint16_t*)b4, 12, 12, 96, q4, total);
+                // pooled 6x6x96 written directly
+                hipLaunchKernelGGL((conv_mfma16_bf16_kernel<14, 14, 96, 3, 3, 90, 96, 9, 1, 2, true>), dim3(np), dim3(768), 0,
+                                   ctx->stream, (const uint16_t*)b3, (const uint16_t*)W.c4w_bf.p, (const float*)W.c4b.p, q4);
             }
             CK_HIP(ctx, hipGetLastError());
         }
