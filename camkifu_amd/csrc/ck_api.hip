@@ -122,7 +122,7 @@ void ck_ctx_destroy(ck_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = { &ctx->in_stage, &ctx->in_stage2, &ctx->planes, &ctx->edges, &ctx->map, &ctx->labels,
-                       &ctx->labels2, &ctx->ghost, &ctx->misc, &ctx->comp, &ctx->lists, &ctx->pts, &ctx->accum, &ctx->peaks,
+                       &ctx->labels2, &ctx->ghost, &ctx->misc, &ctx->bflag, &ctx->comp, &ctx->lists, &ctx->pts, &ctx->accum, &ctx->peaks,
                        &ctx->goban, &ctx->act0, &ctx->act1, &ctx->act2, &ctx->ybuf, &ctx->lblbuf, &ctx->confbuf,
                        &ctx->out_stage, &ctx->mats,
                        &ctx->cnn.c1w, &ctx->cnn.c1b, &ctx->cnn.c2w, &ctx->cnn.c2b, &ctx->cnn.c3w, &ctx->cnn.c3b,
@@ -224,7 +224,8 @@ int ck_canny(ck_ctx* ctx, const uint8_t* img3, int n, int h, int w, int in_space
     return finish(ctx);
 }
 
-static int board_edges_dev(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, uint8_t* d_edges)
+static int board_edges_dev(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, uint8_t* d_edges,
+                           int* d_border_flag = nullptr)
 {
     const size_t npx = (size_t)n * h * w;
     const int pitch = ck_pitch(w);
@@ -233,7 +234,7 @@ static int board_edges_dev(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int 
     CK_TRY(ck_ensure(ctx, ctx->labels, npx * 4));
     CK_TRY(k_median15_planar(ctx, d_bgr, n, h, w, (uint8_t*)ctx->planes.p, pitch));
     CK_TRY(k_canny_planar(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, 25, 75,
-                          (uint8_t*)ctx->map.p, (int32_t*)ctx->labels.p, d_edges, nullptr));
+                          (uint8_t*)ctx->map.p, (int32_t*)ctx->labels.p, d_edges, nullptr, d_border_flag));
     return CK_OK;
 }
 
@@ -282,9 +283,13 @@ int ck_board_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in
     const void* d_in;
     CK_TRY(ck_to_device(ctx, bgr, npx * 3, in_space, ctx->in_stage, &d_in));
     CK_TRY(ck_ensure(ctx, ctx->edges, npx));
-    CK_TRY(board_edges_dev(ctx, (const uint8_t*)d_in, n, h, w, (uint8_t*)ctx->edges.p));
+    CK_TRY(ck_ensure(ctx, ctx->bflag, (size_t)n * 4));
+    // K2 leaves its hysteresis labels in ctx->labels, which is also K3's parent image: K3 keeps the edge
+    // components Canny already built (frames with an edge on the image frame are relabelled from scratch)
+    CK_TRY(board_edges_dev(ctx, (const uint8_t*)d_in, n, h, w, (uint8_t*)ctx->edges.p, (int*)ctx->bflag.p));
     if (hough_thresh < 0) hough_thresh = (int)((h < w ? h : w) / 5.0);
-    CK_TRY(k_board_lines(ctx, (const uint8_t*)ctx->edges.p, n, h, w, hough_thresh, lines, cap, res, nullptr));
+    CK_TRY(k_board_lines(ctx, (const uint8_t*)ctx->edges.p, n, h, w, hough_thresh, lines, cap, res, nullptr,
+                         (const int*)ctx->bflag.p));
     return finish(ctx);
 }
 

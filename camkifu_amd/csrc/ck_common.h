@@ -58,6 +58,7 @@ struct ck_ctx {
     DevBuf labels2;
     DevBuf ghost;        // n*h*w
     DevBuf misc;         // small per-frame counters
+    DevBuf bflag;        // per frame: did Canny put an edge pixel on the image frame? (K2 -> K3 label reuse)
     DevBuf comp;         // per-frame component tables
     DevBuf lists;        // per-frame edge / border pixel lists
     DevBuf pts;          // compacted border points
@@ -117,13 +118,15 @@ int k_median15_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, ui
 int k_planar_to_interleaved(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, uint8_t* d_out);
 int k_interleaved_to_planar(ck_ctx* ctx, const uint8_t* d_in, int n, int h, int w, int pitch, uint8_t* d_planes);
 // canny: planar 3-channel input -> map (0/1/2) -> edges (0/255); labels = scratch n*h*w int32
+// d_border_flag (nullable, n ints): set to 1 for frames that have an edge pixel on the image frame
 int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, int low, int high,
-                   uint8_t* d_map, int32_t* d_labels, uint8_t* d_edges, uint8_t* d_map_out);
+                   uint8_t* d_map, int32_t* d_labels, uint8_t* d_edges, uint8_t* d_map_out, int* d_border_flag = nullptr);
 int k_i420_to_bgr(ck_ctx* ctx, const uint8_t* d_i420, int n, int h, int w, uint8_t* d_bgr);
 int k_warp(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, const double* d_minv, int m_count,
            int dsize, uint8_t* d_out);
 int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int hough_thresh,
-                  float* lines, int cap, ck_board_result* res, uint8_t* d_ghost_out);
+                  float* lines, int cap, ck_board_result* res, uint8_t* d_ghost_out,
+                  const int* d_canny_border_flag = nullptr);
 int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int n, float* d_y, uint8_t* d_labels, double* d_conf);
 int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space);
 int k_mog2_apply(ck_ctx* ctx, Mog2State& st, const uint8_t* d_img, double lr, uint8_t* d_fg);

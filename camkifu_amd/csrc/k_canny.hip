@@ -195,9 +195,11 @@ __global__ __launch_bounds__(256) void canny_flatten_mark_kernel(const uint8_t* 
     }
 }
 
+// border_flag (nullable): frames with an edge pixel on the image frame are flagged -- K3 clears the frame
+// before labelling, so only the others may reuse these component roots as they are
 __global__ __launch_bounds__(256) void canny_final_kernel(int h, int w, const int32_t* __restrict__ labels,
                                                           uint8_t* __restrict__ edges, const int32_t* __restrict__ cand,
-                                                          const int* __restrict__ cand_count)
+                                                          const int* __restrict__ cand_count, int* __restrict__ border_flag)
 {
     const int f = blockIdx.y;
     const int n = cand_count[f];
@@ -206,14 +208,19 @@ __global__ __launch_bounds__(256) void canny_final_kernel(int h, int w, const in
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += LIST_BLOCKS * 256) {
         const int p = C[i];
         const int root = labels[off + p];
-        if (root != p) edges[off + p] = edges[off + root];
+        const uint8_t e = edges[off + root];           // root entries were written by the previous kernel
+        if (root != p) edges[off + p] = e;
+        if (border_flag && e) {
+            const int y = p / w, x = p - y * w;
+            if (x == 0 || y == 0 || x == w - 1 || y == h - 1) border_flag[f] = 1;
+        }
     }
 }
 
 }  // namespace
 
 int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, int low, int high,
-                   uint8_t* d_map, int32_t* d_labels, uint8_t* d_edges, uint8_t* d_map_out)
+                   uint8_t* d_map, int32_t* d_labels, uint8_t* d_edges, uint8_t* d_map_out, int* d_border_flag)
 {
     if (low > high) { int t = low; low = high; high = t; }
     const size_t npx = (size_t)n * h * w;
@@ -233,13 +240,14 @@ int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, in
     {
         TimeScope ts(ctx, "canny_hyst");
         CK_HIP(ctx, hipMemsetAsync(d_edges, 0, npx, ctx->stream));
+        if (d_border_flag) CK_HIP(ctx, hipMemsetAsync(d_border_flag, 0, (size_t)n * 4, ctx->stream));
         dim3 grid(LIST_BLOCKS, n);
         hipLaunchKernelGGL(canny_link_kernel, grid, dim3(256), 0, ctx->stream, (const uint8_t*)d_map, h, w, d_labels,
                            (const int32_t*)d_cand, (const int*)d_count);
         hipLaunchKernelGGL(canny_flatten_mark_kernel, grid, dim3(256), 0, ctx->stream, (const uint8_t*)d_map, h, w,
                            d_labels, d_edges, (const int32_t*)d_cand, (const int*)d_count);
         hipLaunchKernelGGL(canny_final_kernel, grid, dim3(256), 0, ctx->stream, h, w, (const int32_t*)d_labels, d_edges,
-                           (const int32_t*)d_cand, (const int*)d_count);
+                           (const int32_t*)d_cand, (const int*)d_count, d_border_flag);
         CK_HIP(ctx, hipGetLastError());
     }
     return CK_OK;

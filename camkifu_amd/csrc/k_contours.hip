@@ -157,12 +157,17 @@ __global__ __launch_bounds__(256) void prep_rows4_kernel(const uint8_t* __restri
 template <int NS>
 __global__ __launch_bounds__(256) void prep_rows4u_kernel(const uint8_t* __restrict__ edges, int h, int w,
                                                           uint8_t* __restrict__ ez, int32_t* __restrict__ L,
-                                                          FrameTab* __restrict__ tab, int32_t* __restrict__ elist)
+                                                          FrameTab* __restrict__ tab, int32_t* __restrict__ elist,
+                                                          const int* __restrict__ canny_border_flag)
 {
     const int lane = threadIdx.x & 63;
     const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int f = blockIdx.y;
     if (y >= h) return;                                  // whole wave leaves together
+    // L still holds Canny's hysteresis labels: every edge pixel already points at the first pixel of its
+    // 8-connected component.  Unless an edge touched the image frame (cleared below, which may split a
+    // component) those parents are exactly what the edge unions would rebuild, so they are kept.
+    const bool keep_edge_parents = canny_border_flag != nullptr && canny_border_flag[f] == 0;
     const size_t off = ((size_t)f * h + y) * w;
     const bool row_inner = y > 0 && y < h - 1;
     int32_t* E = elist + (size_t)f * h * w;
@@ -221,6 +226,13 @@ __global__ __launch_bounds__(256) void prep_rows4u_kernel(const uint8_t* __restr
             par.z = (nb & 4) ? y * w + x + 2 : y * w + le + 1;
             if (nb & 4) le = x + 2;
             par.w = (nb & 8) ? y * w + x + 3 : y * w + le + 1;
+            if (keep_edge_parents && nb) {
+                const int4 old = *reinterpret_cast<const int4*>(L + off + x);
+                if (nb & 1) par.x = old.x;
+                if (nb & 2) par.y = old.y;
+                if (nb & 4) par.z = old.z;
+                if (nb & 8) par.w = old.w;
+            }
             *reinterpret_cast<int4*>(L + off + x) = par;
             int slot = base + before[s];
 #pragma unroll
@@ -237,9 +249,11 @@ __global__ __launch_bounds__(256) void prep_rows4u_kernel(const uint8_t* __restr
 // x = 0 or right after an edge pixel of one of the two rows: one union per stretch.
 __global__ __launch_bounds__(256) void link_list_kernel(const uint8_t* __restrict__ ez, int h, int w,
                                                         int32_t* __restrict__ labels, const FrameTab* __restrict__ tab,
-                                                        const int32_t* __restrict__ elist)
+                                                        const int32_t* __restrict__ elist,
+                                                        const int* __restrict__ canny_border_flag)
 {
     const int f = blockIdx.y;
+    const bool edges_linked = canny_border_flag != nullptr && canny_border_flag[f] == 0;   // parents kept from Canny
     const int ne = tab[f].n_edges;
     const uint8_t* e = ez + (size_t)f * h * w;
     int32_t* L = labels + (size_t)f * h * w;
@@ -247,11 +261,13 @@ __global__ __launch_bounds__(256) void link_list_kernel(const uint8_t* __restric
     for (int i = blockIdx.x * 256 + threadIdx.x; i < ne + h - 1; i += LIST_BLOCKS * 256) {
         if (i < ne) {
             const int p = E[i];                        // 1 <= x <= w-2, 1 <= y <= h-2
-            if (e[p - 1]) uf_union(L, p, p - 1);
-            if (e[p - w]) uf_union(L, p, p - w);
-            else {
-                if (e[p - w - 1]) uf_union(L, p, p - w - 1);
-                if (e[p - w + 1]) uf_union(L, p, p - w + 1);
+            if (!edges_linked) {
+                if (e[p - 1]) uf_union(L, p, p - 1);
+                if (e[p - w]) uf_union(L, p, p - w);
+                else {
+                    if (e[p - w - 1]) uf_union(L, p, p - w - 1);
+                    if (e[p - w + 1]) uf_union(L, p, p - w + 1);
+                }
             }
             const int q1 = p + 1, q2 = p + w + 1;      // background stretches opening right of p
             if (!e[q1] && !e[q1 - w]) uf_union(L, q1, q1 - w);
@@ -544,7 +560,7 @@ struct Comp {
 }  // namespace
 
 int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int hough_thresh,
-                  float* lines, int cap, ck_board_result* res, uint8_t* d_ghost_out)
+                  float* lines, int cap, ck_board_result* res, uint8_t* d_ghost_out, const int* d_canny_border_flag)
 {
     static const bool prof = getenv("CK_PROFILE_HOST") != nullptr;   // debugging aid: host-side lap times on stderr
     auto t_start = std::chrono::steady_clock::now();
@@ -589,18 +605,20 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         CK_HIP(ctx, hipMemsetAsync(d_tab, 0, tab_bytes, ctx->stream));
         // the dword path needs 4-byte aligned rows: w % 4 == 0 and an aligned base pointer
         const bool dwords = (w & 3) == 0 && ((uintptr_t)d_edges & 3) == 0;
+        // reuse of Canny's component roots (ck_board_detect only) needs the row kernel that preserves them
+        const int* kflag = (dwords && w <= 4096) ? d_canny_border_flag : nullptr;
         if (dwords && w <= 1024)
-            hipLaunchKernelGGL(prep_rows4u_kernel<4>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
+            hipLaunchKernelGGL(prep_rows4u_kernel<4>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist, kflag);
         else if (dwords && w <= 2048)
-            hipLaunchKernelGGL(prep_rows4u_kernel<8>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
+            hipLaunchKernelGGL(prep_rows4u_kernel<8>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist, kflag);
         else if (dwords && w <= 4096)
-            hipLaunchKernelGGL(prep_rows4u_kernel<16>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
+            hipLaunchKernelGGL(prep_rows4u_kernel<16>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist, kflag);
         else if (dwords)
             hipLaunchKernelGGL(prep_rows4_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
         else
             hipLaunchKernelGGL(prep_rows_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
         hipLaunchKernelGGL(link_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
-                           (const FrameTab*)d_tab, (const int32_t*)elist);
+                           (const FrameTab*)d_tab, (const int32_t*)elist, kflag);
         hipLaunchKernelGGL(flatten_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
                            (const FrameTab*)d_tab, (const int32_t*)elist);
         hipLaunchKernelGGL(roots_list_kernel, lgrid, lblock, 0, ctx->stream, h, w, (const int32_t*)L, compid, d_tab, maxc,

@@ -490,3 +490,33 @@ def test_full_size_batch_properties(ck, ora, synth):
         gob = ora.warp_perspective(fr, M)
         l2, c2 = ora.decode_all(ora.cnn_predict_regions(NNManager.init_net(), gob))
         assert np.array_equal(labels[i], l2)
+
+
+def test_board_detect_when_edges_touch_the_frame(ck, ora, synth):
+    """K3 reuses K2's hysteresis components unless an edge pixel lies on the image frame (K3 clears the
+    frame, which can split a component): both cases in one batch, against the oracle chain"""
+    rng = np.random.default_rng(21)
+    frames = []
+    for k in range(4):
+        fr = synth.scene(240, 320, seed=60 + k)["frame"].numpy().copy()
+        if k % 2:
+            # bright bars running off the image on three sides, and a loop hanging on the top border
+            fr[100:108, :] = 250
+            fr[:, 40:46] = 5
+            fr[0:30, 200:204] = 255
+            fr[26:30, 200:260] = 255
+            fr[0:30, 256:260] = 255
+        frames.append(fr)
+    frames = np.stack(frames)
+    out = ck.board_detect(frames)
+    touched = []
+    for k in range(4):
+        e = ora.canny(ora.median(frames[k], 15), 25, 75)
+        touched.append(bool(e[0].any() or e[-1].any() or e[:, 0].any() or e[:, -1].any()))
+        ref = ora.board_lines(e)
+        assert out[k]["n_contours"] == ref["n_contours"], k
+        kk = max(ref["status"], 0)
+        assert out[k]["n_lines"] == kk and np.array_equal(out[k]["lines"][:kk], ref["lines"][:kk]), k
+        if ref["status"] != -1:
+            assert out[k]["biggest_area"] == pytest.approx(ref["biggest_area"], rel=0, abs=0), k
+    assert any(touched) and not all(touched)
