@@ -520,3 +520,43 @@ def test_board_detect_when_edges_touch_the_frame(ck, ora, synth):
         if ref["status"] != -1:
             assert out[k]["biggest_area"] == pytest.approx(ref["biggest_area"], rel=0, abs=0), k
     assert any(touched) and not all(touched)
+
+
+def test_contexts_are_independent_across_threads(ck, synth):
+    """one ck_ctx per finder thread (SURVEY 8b 'Threading'): four contexts hammered from four threads give
+    exactly what one context gives sequentially -- no shared mutable state in the library"""
+    import threading
+    from camkifu_amd import capi
+    from camkifu_amd.stone.nn_manager import NNManager
+    W = NNManager.init_net()
+    frames = np.stack([synth.scene(240, 320, seed=200 + k)["frame"].numpy() for k in range(6)])
+    dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
+    M = capi.get_perspective_transform(synth.scene(240, 320, seed=200)["corners"], dst)
+    ck.cnn_set_weights(W)
+    ref_rec, ref_lines = ck.board_detect(frames, raw=True)
+    ref_lab, ref_conf = ck.stones_detect(frames, M)
+    results, errors = {}, []
+
+    def work(tid):
+        try:
+            c = capi.Context(0)
+            c.cnn_set_weights(W)
+            for rep in range(3):
+                rec, lines = c.board_detect(frames, raw=True)
+                lab, conf = c.stones_detect(frames, M)
+                hd = c.mog2_create(380, 380)
+                c.mog2_apply(hd, np.zeros((380, 380, 3), np.uint8), 0.01)
+                c.mog2_destroy(hd)
+            results[tid] = (rec, lines, lab, conf)
+            c.close()
+        except Exception as exc:      # noqa: BLE001
+            errors.append(exc)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errors and len(results) == 4
+    for rec, lines, lab, conf in results.values():
+        assert np.array_equal(rec, ref_rec) and np.array_equal(lines, ref_lines)
+        assert np.array_equal(lab, ref_lab) and np.array_equal(conf, ref_conf)
