@@ -15,7 +15,11 @@
 // A (activations) is staged in LDS with pixel / row strides chosen so that one ds_read_b32 of a
 // half-wave hits 32 distinct banks; B (weights) streams from L2 as coalesced dwordx4 fragments and
 // is reused by the R register-blocked pixel tiles of a wave.  Wave counts per workgroup are
-// multiples of 4 so every SIMD carries the same number of MFMA chains.
+// multiples of 4 so every SIMD carries the same number of MFMA chains.  Tried and dropped: persistent
+// workgroups with the next unit's rows prefetched into registers (the two workgroups of a CU then run
+// in lock step and lose the staging / compute overlap that independent workgroups have: conv2 +5 %),
+// explicit software pipelining of the LDS reads (no change with 4 waves per SIMD), two patches per
+// workgroup for the odd tile counts of conv3 / conv4 (+4 %).
 // Everything else (160->81 dense, softmax, base-3 decode) is byte/float VALU work.
 #include <math.h>
 
