@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--lanes", type=int, default=LANES_DEFAULT,
                     help="pairs of (board, stones) contexts per GPU; the batch is split between them so more "
                          "kernels are in flight and drain / host gaps of one lane are filled by the others")
@@ -283,7 +283,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8" if args.cnn == "fp32" else "u8+bf16", "data": "synthetic",
+            "dtype": "u8+f32" if args.cnn == "fp32" else "u8+bf16", "data": "synthetic",
             "config": {"workload": "%dx%d synthetic video, %d-frame batch per GPU, board detect (K1-K6) + "
                                    "stones detect (K8,K10-K12), cnn %s" % (W, H, F, args.cnn),
                        "frames_per_gpu": F, "height": H, "width": W, "parallelism": "frames sharded x%d" % world,
