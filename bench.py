@@ -59,7 +59,9 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per batch per GPU")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--cnn", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--cnn", choices=["fp32", "bf16", "f16x2"], default="fp32",
+                    help="fp32: k-ordered f32 MFMA chain (exact, default); f16x2: f32-accurate split-fp16 operands on the "
+                         "fp16 matrix pipe; bf16: bf16 operands (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -138,7 +140,7 @@ def main():
     torch.cuda.synchronize()
     for _, c in lanes:
         c.cnn_set_weights({k: torch.from_numpy(v).to(dev) for k, v in weights.items()})
-        c.cnn_set_mode(capi.CK_CNN_BF16 if args.cnn == "bf16" else capi.CK_CNN_FP32)
+        c.cnn_set_mode({"fp32": capi.CK_CNN_FP32, "bf16": capi.CK_CNN_BF16, "f16x2": capi.CK_CNN_F16X2}[args.cnn])
     dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
     M = capi.get_perspective_transform(corners, dst)
     from camkifu_amd import pipeline
@@ -258,8 +260,9 @@ def main():
             per_launch_frames = prof_steps * F / stages[dom]["launches"]
             avg_s = stages[dom]["ms_total"] / stages[dom]["launches"] * 1e-3
             if dom in MACS:
-                peak = MFMA_BF16_PEAK_TF if args.cnn == "bf16" else MFMA_F32_PEAK_TF
-                ach = 2.0 * MACS[dom] * per_launch_frames / avg_s / 1e12
+                # f16x2 executes three fp16 MFMAs per f32-equivalent MAC block: priced against the fp16 peak
+                peak = MFMA_F32_PEAK_TF if args.cnn == "fp32" else MFMA_BF16_PEAK_TF
+                ach = (3.0 if args.cnn == "f16x2" else 1.0) * 2.0 * MACS[dom] * per_launch_frames / avg_s / 1e12
                 roof = dict(kernel=dom, bound="mfma", achieved=round(ach, 3), peak=peak, unit="TFLOP/s",
                             frac=round(ach / peak, 5), traffic=traffic_of(dom, per_launch_frames))
             else:
@@ -283,7 +286,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8+f32" if args.cnn == "fp32" else "u8+bf16", "data": "synthetic",
+            "dtype": {"fp32": "u8+f32", "bf16": "u8+bf16", "f16x2": "u8+f16x2(f32 accumulate)"}[args.cnn], "data": "synthetic",
             "config": {"workload": "%dx%d synthetic video, %d-frame batch per GPU, board detect (K1-K6) + "
                                    "stones detect (K8,K10-K12), cnn %s" % (W, H, F, args.cnn),
                        "frames_per_gpu": F, "height": H, "width": W, "parallelism": "frames sharded x%d" % world,

@@ -127,7 +127,8 @@ void ck_ctx_destroy(ck_ctx* ctx)
                        &ctx->out_stage, &ctx->mats,
                        &ctx->cnn.c1w, &ctx->cnn.c1b, &ctx->cnn.c2w, &ctx->cnn.c2b, &ctx->cnn.c3w, &ctx->cnn.c3b,
                        &ctx->cnn.c4w, &ctx->cnn.c4b, &ctx->cnn.d1w, &ctx->cnn.d1b, &ctx->cnn.d2w, &ctx->cnn.d2b,
-                       &ctx->cnn.c2w_bf, &ctx->cnn.c3w_bf, &ctx->cnn.c4w_bf, &ctx->cnn.d1w_bf };
+                       &ctx->cnn.c2w_bf, &ctx->cnn.c3w_bf, &ctx->cnn.c4w_bf, &ctx->cnn.d1w_bf,
+                       &ctx->cnn.c2w_h2, &ctx->cnn.c3w_h2, &ctx->cnn.c4w_h2 };
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto& m : ctx->mog2) {
         DevBuf* mb[] = { &m.weight, &m.variance, &m.mean, &m.nmodes };
@@ -351,7 +352,7 @@ int ck_cnn_set_weights(ck_ctx* ctx, const float* const weights[12], int space)
 int ck_cnn_set_mode(ck_ctx* ctx, int mode)
 {
     if (!ctx) return CK_ERR_ARG;
-    if (mode != CK_CNN_FP32 && mode != CK_CNN_BF16) return ck_fail(ctx, CK_ERR_ARG, "unknown cnn mode %d", mode);
+    if (mode != CK_CNN_FP32 && mode != CK_CNN_BF16 && mode != CK_CNN_F16X2) return ck_fail(ctx, CK_ERR_ARG, "unknown cnn mode %d", mode);
     ctx->cnn_mode = mode;
     return CK_OK;
 }

@@ -37,6 +37,8 @@ struct CnnWeights {
     DevBuf c1w, c1b, c2w, c2b, c3w, c3b, c4w, c4b, d1w, d1b, d2w, d2b;
     // bf16 packs for the MFMA path
     DevBuf c2w_bf, c3w_bf, c4w_bf, d1w_bf;
+    // hi / lo fp16 planes for the split-precision mode
+    DevBuf c2w_h2, c3w_h2, c4w_h2;
 };
 
 struct ck_ctx {

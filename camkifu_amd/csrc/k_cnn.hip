@@ -35,6 +35,13 @@
 #ifndef C4_WM
 #define C4_WM 2
 #endif
+#ifndef H2C2_TB
+#define H2C2_TB 16
+#endif
+#ifndef H2C2_WM
+#define H2C2_WM 8
+#endif
+constexpr float H2_WSCALE = 256.f;      // split-precision mode: weights are stored x 2^8 (their lo halves stay normal fp16)
 #ifndef C1_R
 #define C1_R 3
 #endif
@@ -524,6 +531,191 @@ __global__ __launch_bounds__(64 * WAVES_M * (COUTS / 16)) void conv_mfma16_bf16_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Split-precision mode (CK_CNN_F16X2): f32-accurate convolutions on the fp16 matrix pipe.
+// Every f32 operand x is carried as two halves, hi = fp16(x) and lo = fp16(x - hi) (22 mantissa bits
+// together); a product is the three MFMAs lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x32_f16 with f32
+// accumulation (the lo*lo term is below 2^-22 of the product).  Three fp16 MFMAs of 16 cycles replace
+// eight f32 MFMAs of 32 cycles per 16x16x32 block: the ceiling moves from 155 to ~830 TFLOP/s-equivalent.
+// Weights are pre-scaled by 2^8 so that their lo halves stay normal fp16 numbers (undone on the accumulator,
+// exact).  Results agree with the f32 kernels to ~1e-6 (tests), not bit for bit: the k-ordered f32 chain
+// is what CK_CNN_FP32 keeps.
+//   in : [patch][H][W][CIN] f32       wt : [16-channel tile][k-step][hi|lo][lane][8] fp16 (pack_mfma16_h2)
+//   out: as conv_mfma16_f32_kernel
+// LDS: per pixel [hi CINP][lo CINP][8 pad] halves (pixel stride = 16 mod 128 bytes), row stride chosen as in
+// the bf16 kernel; one k-step = 32 channels of one kernel tap.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_h2(float x, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+template <int H, int W, int CIN, int KH, int KW, int COUT, int TB, int YB, int WAVES_M, int RN, bool POOL>
+__global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfma16_h2_kernel(
+    const float* __restrict__ in, const uint16_t* __restrict__ wt, const float* __restrict__ bias,
+    float* __restrict__ out, float wscale_inv)
+{
+#pragma clang fp contract(off)
+    constexpr int OH = H - KH + 1, OW = W - KW + 1, M = OH * OW;
+    constexpr int NT = cdiv(COUT, 16), WAVES_N = NT / RN;
+    constexpr int CINP = cdiv(CIN, 32) * 32;
+    constexpr int PS = 2 * CINP + 8;                               // halves per pixel
+    constexpr int RS = lds_stride_b(W * PS, POOL ? 32 : (8 * OW) % 64, 64);     // halves per row
+    constexpr int KS = KH * KW * (CINP / 32);
+    constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
+    constexpr int R = cdiv(TB, WAVES_M);
+    constexpr int RT = POOL ? (OH / 4) * (OW / 4) : cdiv(M, 16);
+    static_assert(NT % RN == 0 && TB * YB >= RT && R * WAVES_M - TB <= 1, "tile split");
+    static_assert(!POOL || (OW % 4 == 0 && OH % 4 == 0 && TB % (OW / 4) == 0), "pooling tiles are 4x4 output pixels");
+    static_assert(CIN % 2 == 0, "channel pairs");
+    constexpr int ROWS_RAW = POOL ? 4 * (TB / (OW / 4)) + KH - 1 : (TB * 16 + OW - 2) / OW + 1 + KH - 1;
+    constexpr int ROWS = ROWS_RAW < H ? ROWS_RAW : H;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[ROWS * RS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int patch = blockIdx.x;
+    const int tile_blk = blockIdx.y * TB;
+    const int oy_min = POOL ? 4 * (tile_blk / (OW / 4)) : (tile_blk * 16) / OW;
+    int row_cnt = H - oy_min;
+    if (row_cnt > ROWS) row_cnt = ROWS;
+    {
+        const float2* g = reinterpret_cast<const float2*>(in + ((size_t)patch * H + oy_min) * W * CIN);
+#pragma unroll 4
+        for (int i = tid; i < row_cnt * W * (CIN / 2); i += NTHREADS) {
+            const int pxl = i / (CIN / 2), c = i % (CIN / 2);
+            const float2 v = g[i];
+            _Float16 h0, l0, h1, l1;
+            split_h2(v.x, h0, l0);
+            split_h2(v.y, h1, l1);
+            _Float16* d = &lds[(pxl / W) * RS + (pxl % W) * PS + 2 * c];
+            typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<h2v*>(d) = h2v{h0, h1};
+            *reinterpret_cast<h2v*>(d + CINP) = h2v{l0, l1};
+        }
+        if constexpr (CINP > CIN)
+            for (int i = tid; i < row_cnt * W * (CINP - CIN); i += NTHREADS) {
+                const int pxl = i / (CINP - CIN), c = CIN + i % (CINP - CIN);
+                _Float16* d = &lds[(pxl / W) * RS + (pxl % W) * PS + c];
+                d[0] = (_Float16)0.f;
+                d[CINP] = (_Float16)0.f;
+            }
+    }
+    __syncthreads();
+
+    const int tile0 = tile_blk + wm * R;
+    int abase[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int t = tile0 + r;
+        if (t > RT - 1) t = RT - 1;
+        int oy, ox;
+        if constexpr (POOL) {
+            const int ty = t / (OW / 4), tx = t % (OW / 4), q = l15 >> 2, sub = l15 & 3;
+            oy = 4 * ty + 2 * (q >> 1) + (sub >> 1);
+            ox = 4 * tx + 2 * (q & 1) + (sub & 1);
+        } else {
+            int m = t * 16 + l15;
+            if (m > M - 1) m = M - 1;
+            oy = m / OW; ox = m % OW;
+        }
+        abase[r] = (oy - oy_min) * RS + ox * PS + 8 * kq;
+    }
+    f32x4 acc[R][RN];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int n = 0; n < RN; n++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[r][n][e] = 0.f;
+
+    int nv = TB - wm * R;
+    nv = nv > R ? R : nv;
+    // B fragments: [tile][step][plane][lane] uint4
+    const uint4* wq = reinterpret_cast<const uint4*>(wt) + (size_t)(wn * RN) * KS * 128 + lane;
+    auto k_loop = [&](auto nv_tag) {
+        constexpr int NV = decltype(nv_tag)::value;
+        constexpr int PF = 2;
+        uint4 bq[PF][RN][2];
+#pragma unroll
+        for (int u = 0; u < PF; u++)
+#pragma unroll
+            for (int n = 0; n < RN; n++)
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++)
+                    bq[u][n][pl] = u < KS ? wq[((size_t)n * KS + u) * 128 + pl * 64] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < KH; i++) {
+#pragma unroll
+            for (int j = 0; j < KW; j++) {
+#pragma unroll
+                for (int cc = 0; cc < CINP / 32; cc++) {
+                    const int step = (i * KW + j) * (CINP / 32) + cc;
+                    h8 bh[RN], bl[RN];
+#pragma unroll
+                    for (int n = 0; n < RN; n++) {
+                        bh[n] = __builtin_bit_cast(h8, bq[step % PF][n][0]);
+                        bl[n] = __builtin_bit_cast(h8, bq[step % PF][n][1]);
+                        if (step + PF < KS) {
+                            bq[step % PF][n][0] = wq[((size_t)n * KS + step + PF) * 128];
+                            bq[step % PF][n][1] = wq[((size_t)n * KS + step + PF) * 128 + 64];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < NV; r++) {
+                        const _Float16* ap = &lds[abase[r] + i * RS + j * PS + 32 * cc];
+                        const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(ap));
+                        const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(ap + CINP));
+#pragma unroll
+                        for (int n = 0; n < RN; n++) {
+                            acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[n], acc[r][n], 0, 0, 0);
+                            acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[n], acc[r][n], 0, 0, 0);
+                            acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[n], acc[r][n], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    if (nv == R) k_loop(std::integral_constant<int, R>{});
+    else if constexpr (R * WAVES_M > TB) k_loop(std::integral_constant<int, R - 1>{});
+
+#pragma unroll
+    for (int n = 0; n < RN; n++) {
+        const int co = (wn * RN + n) * 16 + l15;
+        const float bv = co < COUT ? bias[co] : 0.f;
+        if constexpr (POOL) {
+            float* o = out + (size_t)patch * (M / 4) * COUT;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int t = tile0 + r;
+                float mx = acc[r][n][0] > acc[r][n][1] ? acc[r][n][0] : acc[r][n][1];
+                const float m2 = acc[r][n][2] > acc[r][n][3] ? acc[r][n][2] : acc[r][n][3];
+                mx = mx > m2 ? mx : m2;
+                mx = mx * wscale_inv + bv;            // the weight scale is a power of two: exact
+                mx = mx > 0.f ? mx : 0.f;
+                const int py = 2 * (t / (OW / 4)) + (kq >> 1), px = 2 * (t % (OW / 4)) + (kq & 1);
+                if (r < nv && t < RT && co < COUT) o[(size_t)(py * (OW / 2) + px) * COUT + co] = mx;
+            }
+        } else {
+            float* o = out + (size_t)patch * M * COUT;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int m = (tile0 + r) * 16 + 4 * kq + e;
+                    float v = acc[r][n][e] * wscale_inv + bv;
+                    v = v > 0.f ? v : 0.f;
+                    if (r < nv && m < M && co < COUT) o[(size_t)m * COUT + co] = v;
+                }
+            }
+        }
+    }
+}
+
 // dense 3456(=36 px x 96 padded channels) -> 160 + relu, bf16 operands: one wave = 32 patches x 32 outputs
 __global__ __launch_bounds__(64) void fc1_mfma_bf16_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                            const float* __restrict__ bias, float* __restrict__ out, int npatch)
@@ -789,6 +981,34 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
     CK_TRY(pack_bf(host[2].data(), 5, 5, 32, 32, 32, 32, ctx->cnn.c2w_bf));
     CK_TRY(pack_bf(host[4].data(), 3, 3, 32, 32, 90, 96, ctx->cnn.c3w_bf));
     CK_TRY(pack_bf(host[6].data(), 3, 3, 90, 96, 90, 96, ctx->cnn.c4w_bf));
+    // split-precision packs: weights x 2^8 as hi / lo fp16 planes in MFMA fragment order
+    // [16-channel tile][k-step][plane][lane = kslot*16 + channel][8 consecutive cin], flip applied
+    auto pack_h2 = [&](const float* k, int KH, int KW, int CIN, int COUT, DevBuf& dst) -> int {
+        const int CINP = (CIN + 31) / 32 * 32, KS = KH * KW * (CINP / 32), NT = (COUT + 15) / 16;
+        std::vector<uint16_t> v((size_t)NT * KS * 2 * 64 * 8, 0);
+        for (int nt = 0; nt < NT; nt++)
+            for (int i = 0; i < KH; i++)
+                for (int j = 0; j < KW; j++)
+                    for (int cc = 0; cc < CINP / 32; cc++)
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int e = 0; e < 8; e++) {
+                                const int c = 32 * cc + 8 * (lane / 16) + e, o = nt * 16 + lane % 16;
+                                if (c >= CIN || o >= COUT) continue;
+                                const int step = (i * KW + j) * (CINP / 32) + cc;
+                                const float wv = k[(((size_t)(KH - 1 - i) * KW + (KW - 1 - j)) * CIN + c) * COUT + o] * H2_WSCALE;
+                                const _Float16 hi = (_Float16)wv;
+                                const _Float16 lo = (_Float16)(wv - (float)hi);
+                                const size_t base = (((size_t)nt * KS + step) * 2) * 64 * 8 + (size_t)lane * 8 + e;
+                                memcpy(&v[base], &hi, 2);
+                                memcpy(&v[base + 64 * 8], &lo, 2);
+                            }
+        CK_TRY(ck_ensure(ctx, dst, v.size() * 2));
+        CK_HIP(ctx, hipMemcpy(dst.p, v.data(), v.size() * 2, hipMemcpyHostToDevice));
+        return CK_OK;
+    };
+    CK_TRY(pack_h2(host[2].data(), 5, 5, 32, 32, ctx->cnn.c2w_h2));
+    CK_TRY(pack_h2(host[4].data(), 3, 3, 32, 90, ctx->cnn.c3w_h2));
+    CK_TRY(pack_h2(host[6].data(), 3, 3, 90, 90, ctx->cnn.c4w_h2));
     {
         std::vector<uint16_t> v((size_t)160 * 3456, 0);
         for (int o = 0; o < 160; o++)
@@ -863,6 +1083,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         CK_HIP(ctx, hipGetLastError());
         return CK_OK;
     }
+    const bool h2 = ctx->cnn_mode == CK_CNN_F16X2;
     for (int f0 = 0; f0 < nframes; f0 += CHUNK) {
         const int nf = nframes - f0 < CHUNK ? nframes - f0 : CHUNK;
         const int np = nf * 100;
@@ -877,6 +1098,10 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             TimeScope ts(ctx, "cnn_conv2");
             // 32 rows: 4 groups of (4 waves x 2 rows), pooled output 16x16x32
             // 8x8 pooling tiles of 4x4 pixels: workgroups of whole tile rows, pooled output 16x16x32
+            if (h2)
+                hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, H2C2_TB, 64 / H2C2_TB, H2C2_WM, 2, true>), dim3(np, 64 / H2C2_TB), dim3(64 * H2C2_WM), 0, ctx->stream,
+                                   (const float*)a1, (const uint16_t*)W.c2w_h2.p, (const float*)W.c2b.p, p2, 1.f / H2_WSCALE);
+            else
             hipLaunchKernelGGL((conv_mfma16_f32_kernel<36, 36, 32, 5, 5, 32, C2_TB, 64 / C2_TB, C2_WM, C2_RN, true>), dim3(np, 64 / C2_TB),
                                dim3(64 * C2_WM * (2 / C2_RN)), 0, ctx->stream, (const float*)a1, (const float*)W.c2w.p,
                                (const float*)W.c2b.p, p2);
@@ -885,6 +1110,10 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         {
             TimeScope ts(ctx, "cnn_conv3");
             // 13 pixel tiles x 6 channel tiles of 16
+            if (h2)
+                hipLaunchKernelGGL((conv_mfma16_h2_kernel<16, 16, 32, 3, 3, 90, 13, 1, 2, 3, false>), dim3(np), dim3(256), 0, ctx->stream,
+                                   (const float*)p2, (const uint16_t*)W.c3w_h2.p, (const float*)W.c3b.p, a3, 1.f / H2_WSCALE);
+            else
             hipLaunchKernelGGL((conv_mfma16_f32_kernel<16, 16, 32, 3, 3, 90, 13, 1, C3_WM, 1, false>), dim3(np), dim3(384 * C3_WM), 0,
                                ctx->stream, (const float*)p2, (const float*)W.c3w.p, (const float*)W.c3b.p, a3);
         }
@@ -892,6 +1121,10 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         {
             TimeScope ts(ctx, "cnn_conv4");
             // 9 tiles of four pooling windows x 6 channel tiles; pooled 6x6x90 written directly
+            if (h2)
+                hipLaunchKernelGGL((conv_mfma16_h2_kernel<14, 14, 90, 3, 3, 90, 9, 1, 2, 3, true>), dim3(np), dim3(256), 0, ctx->stream,
+                                   (const float*)a3, (const uint16_t*)W.c4w_h2.p, (const float*)W.c4b.p, p4, 1.f / H2_WSCALE);
+            else
             hipLaunchKernelGGL((conv_mfma16_f32_kernel<14, 14, 90, 3, 3, 90, 9, 1, C4_WM, 1, true>), dim3(np), dim3(384 * C4_WM), 0,
                                ctx->stream, (const float*)a3, (const float*)W.c4w.p, (const float*)W.c4b.p, p4);
         }

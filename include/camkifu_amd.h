@@ -30,7 +30,7 @@ extern "C" {
 enum { CK_OK = 0, CK_ERR_ARG = 1, CK_ERR_HIP = 2, CK_ERR_CAPACITY = 3, CK_ERR_STATE = 4 };
 enum { CK_HOST = 0, CK_DEVICE = 1 };
 enum { CK_BACKEND_HIP = 1 };
-enum { CK_CNN_FP32 = 0, CK_CNN_BF16 = 1 };
+enum { CK_CNN_FP32 = 0, CK_CNN_BF16 = 1, CK_CNN_F16X2 = 2 };
 
 /* per-frame status of the board path, mirrors the early exits of
  * BoardFinderAuto._detect (board/bf_auto.py:76-82) */
@@ -120,7 +120,8 @@ int ck_mog2_destroy(ck_ctx* ctx, int handle);
  * (conv kernels are applied as true convolutions, as Keras-1 on Theano does).
  * `space` may be CK_DEVICE: e.g. data_ptr() of PyTorch-ROCm tensors. */
 int ck_cnn_set_weights(ck_ctx* ctx, const float* const weights[12], int space);
-int ck_cnn_set_mode(ck_ctx* ctx, int mode);      /* CK_CNN_FP32 (default) | CK_CNN_BF16 */
+int ck_cnn_set_mode(ck_ctx* ctx, int mode);      /* CK_CNN_FP32 (default: k-ordered f32 chain) | CK_CNN_BF16 |
+                                                    CK_CNN_F16X2 (f32-accurate: split fp16 operands, f32 accumulate) */
 /* goban: n x 380 x 380 x 3.  Any of y (n*100*81 softmax), labels (n*361, 0=E 1=B 2=W),
  * conf (n*361 doubles, max(y)/sum(y)) may be NULL. */
 int ck_cnn_predict(ck_ctx* ctx, const uint8_t* goban, int n, int in_space,

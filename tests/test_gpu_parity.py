@@ -560,3 +560,32 @@ def test_contexts_are_independent_across_threads(ck, synth):
     for rec, lines, lab, conf in results.values():
         assert np.array_equal(rec, ref_rec) and np.array_equal(lines, ref_lines)
         assert np.array_equal(lab, ref_lab) and np.array_equal(conf, ref_conf)
+
+
+def test_cnn_split_fp16_mode_is_f32_accurate(ck, ora, synth):
+    """CK_CNN_F16X2: every f32 operand as hi + lo fp16, three fp16 MFMAs per product, f32 accumulate.  Not the
+    k-ordered f32 chain, but the same numbers to ~1e-6: softmax within 1e-5 of the f32 mode (and within the
+    1e-4 bar of the oracle), labels and confidences' argmax identical"""
+    from camkifu_amd import capi
+    from camkifu_amd.stone.nn_manager import NNManager
+    dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
+    rng = np.random.default_rng(31)
+    for W in (NNManager.init_net(), synth.cnn_weights()):
+        ck.cnn_set_weights(W)
+        gobans = []
+        for seed in range(5):
+            sc = synth.scene(480, 640, seed=70 + seed, density=0.1 + 0.1 * seed)
+            gobans.append(ora.warp_perspective(sc["frame"].numpy(), ora.get_perspective_transform(sc["corners"], dst)))
+        gobans.append(rng.integers(0, 256, (380, 380, 3), dtype=np.uint8))
+        gobans = np.stack(gobans)
+        y32, l32, c32 = ck.cnn_predict(gobans)
+        ck.cnn_set_mode(capi.CK_CNN_F16X2)
+        try:
+            y, lab, conf = ck.cnn_predict(gobans)
+        finally:
+            ck.cnn_set_mode(capi.CK_CNN_FP32)
+        assert np.abs(y - y32).max() <= 1e-5, np.abs(y - y32).max()
+        assert np.array_equal(lab, l32)
+        assert np.abs(conf - c32).max() <= 1e-5
+        y_ora = ora.cnn_predict_regions(W, gobans[0])
+        assert np.abs(y[0] - y_ora).max() <= 1e-4
