@@ -716,6 +716,116 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
     }
 }
 
+// conv1 in split-precision mode.  The u8 pixels are exact in fp16, so only the weights are split and a product
+// is two MFMAs (x*lo + x*hi).  K = 75 is laid out as 6 kernel rows x 16 slots (slot = kw*3 + cin, slot 15 and
+// row 5 are zero weights): three k-steps of 32; a lane's fragment is 8 consecutive halves of one input row of
+// the staged fp16 tile (unaligned, read as 8 ds_read_u16 -- there are only nine fragments per wave and unit).
+// Same persistent unit walk, operand swap and 16-byte stores as conv1_mfma16_kernel.
+//   wf : [2 channel tiles][3 steps][hi|lo][64 lanes][8] fp16 (pack_conv1_h2), weights x 2^8
+template <int R>
+__global__ __launch_bounds__(64 * (27 / R)) void conv1_h2_kernel(
+    const uint8_t* __restrict__ goban, const uint16_t* __restrict__ wf, const float* __restrict__ bias,
+    float* __restrict__ out, int nunits, float wscale_inv)
+{
+#pragma clang fp contract(off)
+    constexpr int WAVES = 27 / R, NTHREADS = 64 * WAVES;
+    constexpr int OW = 36, ROWS = 16, RS = 128;           // halves per staged row: 120 used, 8 zero
+    constexpr int NPT = cdiv(ROWS * 30, NTHREADS);
+    __shared__ _Float16 lds[(ROWS + 1) * RS];            // one extra all-zero row for kernel row 5
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+
+    uint32_t raw[NPT];
+    auto fetch = [&](int unit) {
+#pragma unroll
+        for (int q = 0; q < NPT; q++) {
+            const int d = tid + q * NTHREADS;
+            raw[q] = 0u;
+            if (unit < nunits && d < ROWS * 30) {
+                const int patch = unit / 3, by = unit % 3;
+                const int frame = patch / 100, reg = patch % 100;
+                const int py0 = region_origin(reg / 10) + 12 * by, px0 = region_origin(reg % 10);
+                const uint8_t* src = goban + ((size_t)frame * 380 + py0 + d / 30) * 380 * 3 + (size_t)px0 * 3;
+                raw[q] = reinterpret_cast<const uint32_t*>(src)[d % 30];
+            }
+        }
+    };
+    int unit = blockIdx.x;
+    fetch(unit);
+    for (int i = tid; i < ROWS * 8 + RS; i += NTHREADS) {                      // zero the padding columns and the extra row
+        if (i < ROWS * 8) lds[(i / 8) * RS + 120 + i % 8] = (_Float16)0.f;
+        else lds[ROWS * RS + i - ROWS * 8] = (_Float16)0.f;
+    }
+    h8 wq[3][2][2];
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++)
+                wq[s][n][pl] = __builtin_bit_cast(h8, reinterpret_cast<const uint4*>(wf)[((n * 3 + s) * 2 + pl) * 64 + lane]);
+    float4 bv[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++) bv[n] = *reinterpret_cast<const float4*>(bias + n * 16 + 4 * kq);
+    int abase[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int m = (wave * R + r) * 16 + l15;
+        abase[r] = (m / OW + (kq >> 1)) * RS + (m % OW) * 3 + 8 * (kq & 1);
+    }
+
+    for (; unit < nunits; unit += gridDim.x) {
+#pragma unroll
+        for (int q = 0; q < NPT; q++) {
+            const int d = tid + q * NTHREADS;
+            if (d < ROWS * 30) {
+                _Float16* o = &lds[(d / 30) * RS + 4 * (d % 30)];
+                o[0] = (_Float16)(float)(raw[q] & 0xFFu); o[1] = (_Float16)(float)((raw[q] >> 8) & 0xFFu);
+                o[2] = (_Float16)(float)((raw[q] >> 16) & 0xFFu); o[3] = (_Float16)(float)(raw[q] >> 24);
+            }
+        }
+        __syncthreads();
+        fetch(unit + gridDim.x);
+
+        f32x4 acc[R][2];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[r][n][e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const _Float16* ap = &lds[abase[r] + 2 * s * RS];
+                h8 a;
+#pragma unroll
+                for (int e = 0; e < 8; e++) a[e] = ap[e];
+#pragma unroll
+                for (int n = 0; n < 2; n++) {
+                    acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[s][n][1], a, acc[r][n], 0, 0, 0);
+                    acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[s][n][0], a, acc[r][n], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        const int patch = unit / 3, by = unit % 3;
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const size_t m = (size_t)patch * 1296 + (size_t)by * 432 + (wave * R + r) * 16 + l15;
+                float4 v;
+                v.x = acc[r][n][0] * wscale_inv + bv[n].x; v.y = acc[r][n][1] * wscale_inv + bv[n].y;
+                v.z = acc[r][n][2] * wscale_inv + bv[n].z; v.w = acc[r][n][3] * wscale_inv + bv[n].w;
+                v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                *reinterpret_cast<float4*>(out + m * 32 + n * 16 + 4 * kq) = v;
+            }
+        }
+    }
+}
+
 // dense 3456(=36 px x 96 padded channels) -> 160 + relu, bf16 operands: one wave = 32 patches x 32 outputs
 __global__ __launch_bounds__(64) void fc1_mfma_bf16_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                            const float* __restrict__ bias, float* __restrict__ out, int npatch)
@@ -1006,6 +1116,25 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
         CK_HIP(ctx, hipMemcpy(dst.p, v.data(), v.size() * 2, hipMemcpyHostToDevice));
         return CK_OK;
     };
+    {   // conv1: [channel tile][step][plane][lane][8]; k = (kernel row 2*step + kslot/2, slot 8*(kslot%2) + e), slot = kw*3 + cin
+        std::vector<uint16_t> v((size_t)2 * 3 * 2 * 64 * 8, 0);
+        for (int nt = 0; nt < 2; nt++)
+            for (int st = 0; st < 3; st++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int e = 0; e < 8; e++) {
+                        const int kqq = lane / 16, i = 2 * st + (kqq >> 1), slot = 8 * (kqq & 1) + e, o = nt * 16 + lane % 16;
+                        if (i > 4 || slot > 14) continue;
+                        const int j = slot / 3, c = slot % 3;
+                        const float wv = host[0][(((size_t)(4 - i) * 5 + (4 - j)) * 3 + c) * 32 + o] * H2_WSCALE;
+                        const _Float16 hi = (_Float16)wv;
+                        const _Float16 lo = (_Float16)(wv - (float)hi);
+                        const size_t base = (((size_t)nt * 3 + st) * 2) * 64 * 8 + (size_t)lane * 8 + e;
+                        memcpy(&v[base], &hi, 2);
+                        memcpy(&v[base + 64 * 8], &lo, 2);
+                    }
+        CK_TRY(ck_ensure(ctx, ctx->cnn.c1w_h2, v.size() * 2));
+        CK_HIP(ctx, hipMemcpy(ctx->cnn.c1w_h2.p, v.data(), v.size() * 2, hipMemcpyHostToDevice));
+    }
     CK_TRY(pack_h2(host[2].data(), 5, 5, 32, 32, ctx->cnn.c2w_h2));
     CK_TRY(pack_h2(host[4].data(), 3, 3, 32, 90, ctx->cnn.c3w_h2));
     CK_TRY(pack_h2(host[6].data(), 3, 3, 90, 90, ctx->cnn.c4w_h2));
@@ -1091,6 +1220,10 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         float* p4 = p4_all + (size_t)f0 * 100 * 3240;
         {
             TimeScope ts(ctx, "cnn_conv1");
+            if (h2)
+                hipLaunchKernelGGL((conv1_h2_kernel<C1_R>), dim3(std::min(np * 3, C1_GRID)), dim3(64 * (27 / C1_R)), 0, ctx->stream, gob,
+                                   (const uint16_t*)W.c1w_h2.p, (const float*)W.c1b.p, a1, np * 3, 1.f / H2_WSCALE);
+            else
             hipLaunchKernelGGL((conv1_mfma16_kernel<C1_R, false>), dim3(std::min(np * 3, C1_GRID)), dim3(64 * (27 / C1_R)), 0,
                                ctx->stream, gob, (const float*)W.c1w.p, (const float*)W.c1b.p, (void*)a1, np * 3);
         }
