@@ -59,9 +59,9 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per batch per GPU")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--cnn", choices=["fp32", "bf16", "f16x2"], default="fp32",
-                    help="fp32: k-ordered f32 MFMA chain (exact, default); f16x2: f32-accurate split-fp16 operands on the "
-                         "fp16 matrix pipe; bf16: bf16 operands (BASELINE config 5)")
+    ap.add_argument("--cnn", choices=["fp32", "bf16", "f16x2"], default="f16x2",
+                    help="f16x2 (default): f32-accurate split-fp16 operands on the fp16 matrix pipe; fp32: k-ordered f32 "
+                         "MFMA chain; bf16: bf16 operands (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -253,32 +253,46 @@ def main():
         def traffic_of(stage, frames_per_launch):
             t = pmc.get(stage)
             return None if not t else int(t["hbm_bytes_per_frame"] * frames_per_launch)
+        def valu_frac(stage):
+            """VALU issue-slot utilisation: wave-level VALU instructions (PMC SQ_INSTS_VALU, profiles/) x 4 cycles per
+            wave64 instruction on a SIMD16 / (1024 SIMDs x 2.4 GHz x kernel time)"""
+            t = pmc.get(stage)
+            if not t or "valu_wave_insts_per_frame" not in t:
+                return None
+            return round(t["valu_wave_insts_per_frame"] * 4.0 / (1024 * 2.4e9 * stages[stage]["us_per_frame"] * 1e-6), 4)
+
+        def roof_of(stage):
+            per_launch_frames = prof_steps * F / stages[stage]["launches"]
+            avg_s = stages[stage]["ms_total"] / stages[stage]["launches"] * 1e-3
+            if stage in MACS:
+                # f16x2 executes three fp16 MFMAs per f32-equivalent MAC block: priced against the fp16 peak
+                f32_kernel = args.cnn == "fp32" or (args.cnn == "bf16" and stage == "cnn_conv1")     # bf16 mode keeps conv1 in f32
+                peak = MFMA_F32_PEAK_TF if f32_kernel else MFMA_BF16_PEAK_TF
+                mults = 1.0
+                if args.cnn == "f16x2":
+                    mults = 2.0 if stage == "cnn_conv1" else 3.0       # fp16 MFMAs executed per f32-equivalent product
+                ach = mults * 2.0 * MACS[stage] * per_launch_frames / avg_s / 1e12
+                return dict(kernel=stage, bound="mfma", achieved=round(ach, 3), peak=peak, unit="TFLOP/s",
+                            frac=round(ach / peak, 5), traffic=traffic_of(stage, per_launch_frames))
+            bytes_per_frame = {"median": 2 * 3 * W * H, "canny_nms": 4 * W * H, "warp": 433200 + 3 * W * H,
+                               "ccl": 6 * W * H, "canny_hyst": 2 * W * H}.get(stage, 4 * W * H)
+            ach = bytes_per_frame * per_launch_frames / avg_s / 1e9
+            r = dict(kernel=stage, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                     frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic_of(stage, per_launch_frames))
+            vf = valu_frac(stage)
+            if vf is not None:
+                r["valu_issue_frac"] = vf
+                r["note"] = ("nominally HBM-bound (SURVEY 8d), in fact bound by VALU instruction issue: "
+                             "valu_issue_frac of the SIMDs' issue slots are busy")
+            return r
         # roofline of the dominant kernel
         dom = max(stages, key=lambda k: stages[k]["ms_total"]) if stages else None
-        roof = None
-        if dom is not None:
-            per_launch_frames = prof_steps * F / stages[dom]["launches"]
-            avg_s = stages[dom]["ms_total"] / stages[dom]["launches"] * 1e-3
-            if dom in MACS:
-                # f16x2 executes three fp16 MFMAs per f32-equivalent MAC block: priced against the fp16 peak
-                peak = MFMA_F32_PEAK_TF if args.cnn == "fp32" else MFMA_BF16_PEAK_TF
-                ach = (3.0 if args.cnn == "f16x2" else 1.0) * 2.0 * MACS[dom] * per_launch_frames / avg_s / 1e12
-                roof = dict(kernel=dom, bound="mfma", achieved=round(ach, 3), peak=peak, unit="TFLOP/s",
-                            frac=round(ach / peak, 5), traffic=traffic_of(dom, per_launch_frames))
-            else:
-                bytes_per_frame = {"median": 2 * 3 * W * H, "canny_nms": 4 * W * H, "warp": 433200 + 3 * W * H,
-                                   "ccl": 6 * W * H, "canny_hyst": 2 * W * H}.get(dom, 4 * W * H)
-                ach = bytes_per_frame * per_launch_frames / avg_s / 1e9
-                roof = dict(kernel=dom, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic_of(dom, per_launch_frames))
-        # the filter pass (K1) is always reported as well: north_star quotes HBM roofline on it
-        filt = None
-        if "median" in stages:
-            avg_s = stages["median"]["ms_total"] / stages["median"]["launches"] * 1e-3
-            ach = 2 * 3 * W * H * (prof_steps * F / stages["median"]["launches"]) / avg_s / 1e9
-            filt = dict(kernel="median", bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(ach / HBM_PEAK_GBS, 5),
-                        traffic=traffic_of("median", prof_steps * F / stages["median"]["launches"]))
+        roof = roof_of(dom) if dom is not None else None
+        # the dominant matrix-core kernel and the filter pass (K1; north_star quotes the HBM roofline on it) are
+        # always reported as well
+        conv_stages = [k for k in stages if k in MACS]
+        mfma_roof = roof_of(max(conv_stages, key=lambda k: stages[k]["ms_total"])) if conv_stages else None
+        filt = roof_of("median") if "median" in stages else None
         out = {
             "metric": "frames/sec on 1920x1080 video + 19x19 stone-grid match % vs reference SGF",
             "value": round(world * F * args.steps / dt, 2),
@@ -292,6 +306,7 @@ def main():
                        "frames_per_gpu": F, "height": H, "width": W, "parallelism": "frames sharded x%d" % world,
                        "lanes_per_gpu": len(lanes)},
             "roofline": roof,
+            "mfma_kernel": mfma_roof,
             "filter_pass": filt,
             "stages": stages,
             "stage_timing": "HIP events per context stream over %d serial steps after the timed region; the timed "

@@ -120,8 +120,9 @@ int ck_mog2_destroy(ck_ctx* ctx, int handle);
  * (conv kernels are applied as true convolutions, as Keras-1 on Theano does).
  * `space` may be CK_DEVICE: e.g. data_ptr() of PyTorch-ROCm tensors. */
 int ck_cnn_set_weights(ck_ctx* ctx, const float* const weights[12], int space);
-int ck_cnn_set_mode(ck_ctx* ctx, int mode);      /* CK_CNN_FP32 (default: k-ordered f32 chain) | CK_CNN_BF16 |
-                                                    CK_CNN_F16X2 (f32-accurate: split fp16 operands, f32 accumulate) */
+int ck_cnn_set_mode(ck_ctx* ctx, int mode);      /* CK_CNN_F16X2 (default): f32 operands split into hi + lo fp16, three fp16 MFMAs per product,
+                                                    f32 accumulate -- as close to a float64 evaluation as the f32 chain is (profiles/r01_cnn_precision.txt);
+                                                    CK_CNN_FP32: k-ordered f32 MFMA chain; CK_CNN_BF16: bf16 operands */
 /* goban: n x 380 x 380 x 3.  Any of y (n*100*81 softmax), labels (n*361, 0=E 1=B 2=W),
  * conf (n*361 doubles, max(y)/sum(y)) may be NULL. */
 int ck_cnn_predict(ck_ctx* ctx, const uint8_t* goban, int n, int in_space,

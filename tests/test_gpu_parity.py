@@ -175,7 +175,10 @@ def test_mog2_sequence(ck, ora):
 
 
 # ---------------------------------------------------------------- K10..K12
-def test_cnn_parity(ck, ora, synth):
+@pytest.mark.parametrize("mode", ["f16x2", "fp32"])
+def test_cnn_parity(ck, ora, synth, mode):
+    """both f32-accurate modes against the oracle: the default split-precision mode and the k-ordered f32 chain"""
+    from camkifu_amd import capi
     W = synth.cnn_weights()
     ck.cnn_set_weights(W)
     sc = synth.scene(480, 640, seed=4, density=0.4)
@@ -184,7 +187,11 @@ def test_cnn_parity(ck, ora, synth):
     goban = ora.warp_perspective(sc["frame"].numpy(), M)
     rng = np.random.default_rng(9)
     gobans = np.stack([goban, rng.integers(0, 256, (380, 380, 3), dtype=np.uint8)])
-    y, labels, conf = ck.cnn_predict(gobans)
+    ck.cnn_set_mode(capi.CK_CNN_F16X2 if mode == "f16x2" else capi.CK_CNN_FP32)
+    try:
+        y, labels, conf = ck.cnn_predict(gobans)
+    finally:
+        ck.cnn_set_mode(capi.CK_CNN_DEFAULT)
     for k in range(2):
         y2 = ora.cnn_predict_regions(W, gobans[k])
         assert np.abs(y[k] - y2).max() <= 1e-4
@@ -330,12 +337,13 @@ def test_cnn_bf16_mode_close_to_fp32(ck, ora, synth):
         sc = synth.scene(480, 640, seed=40 + seed, density=0.1 + 0.08 * seed)
         gobans.append(ora.warp_perspective(sc["frame"].numpy(), ora.get_perspective_transform(sc["corners"], dst)))
     gobans = np.stack(gobans)
+    ck.cnn_set_mode(capi.CK_CNN_FP32)
     y32, l32, c32 = ck.cnn_predict(gobans)
     ck.cnn_set_mode(capi.CK_CNN_BF16)
     try:
         y16, l16, c16 = ck.cnn_predict(gobans)
     finally:
-        ck.cnn_set_mode(capi.CK_CNN_FP32)
+        ck.cnn_set_mode(capi.CK_CNN_DEFAULT)
     agree = float((l32 == l16).mean())
     print("bf16 vs fp32: label agreement %.5f, max |dy| %.4f" % (agree, float(np.abs(y32 - y16).max())))
     assert agree >= 0.99
@@ -578,12 +586,13 @@ def test_cnn_split_fp16_mode_is_f32_accurate(ck, ora, synth):
             gobans.append(ora.warp_perspective(sc["frame"].numpy(), ora.get_perspective_transform(sc["corners"], dst)))
         gobans.append(rng.integers(0, 256, (380, 380, 3), dtype=np.uint8))
         gobans = np.stack(gobans)
+        ck.cnn_set_mode(capi.CK_CNN_FP32)
         y32, l32, c32 = ck.cnn_predict(gobans)
         ck.cnn_set_mode(capi.CK_CNN_F16X2)
         try:
             y, lab, conf = ck.cnn_predict(gobans)
         finally:
-            ck.cnn_set_mode(capi.CK_CNN_FP32)
+            ck.cnn_set_mode(capi.CK_CNN_DEFAULT)
         assert np.abs(y - y32).max() <= 1e-5, np.abs(y - y32).max()
         assert np.array_equal(lab, l32)
         assert np.abs(conf - c32).max() <= 1e-5
