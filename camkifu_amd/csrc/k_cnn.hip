@@ -35,6 +35,12 @@
 #ifndef C4_WM
 #define C4_WM 2
 #endif
+#ifndef H2C2_PF
+#define H2C2_PF 2
+#endif
+#ifndef H2C34_PF
+#define H2C34_PF 2
+#endif
 #ifndef H2C2_TB
 #define H2C2_TB 16
 #endif
@@ -552,7 +558,7 @@ __device__ __forceinline__ void split_h2(float x, _Float16& hi, _Float16& lo)
     lo = (_Float16)(x - (float)hi);
 }
 
-template <int H, int W, int CIN, int KH, int KW, int COUT, int TB, int YB, int WAVES_M, int RN, bool POOL>
+template <int H, int W, int CIN, int KH, int KW, int COUT, int TB, int YB, int WAVES_M, int RN, bool POOL, int PF, bool SB>
 __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfma16_h2_kernel(
     const float* __restrict__ in, const uint16_t* __restrict__ wt, const float* __restrict__ bias,
     float* __restrict__ out, float wscale_inv)
@@ -638,8 +644,14 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
     const uint4* wq = reinterpret_cast<const uint4*>(wt) + (size_t)(wn * RN) * KS * 128 + lane;
     auto k_loop = [&](auto nv_tag) {
         constexpr int NV = decltype(nv_tag)::value;
-        constexpr int PF = 2;
-        uint4 bq[PF][RN][2];
+        // Weight fragments run PF k-steps ahead of their use through a ring of PF + 1 register slots.  A step's
+        // MFMAs are short here (16 cycles each), so the distance has to be real: the loads for step s + PF are
+        // issued at the top of step s and a scheduling barrier keeps the compiler from sinking them next to
+        // their first use (which is what it does otherwise: vmcnt(0) right behind the load).  SB = false leaves the
+        // schedule to the compiler: with 7 tiles x 3 channel tiles per wave (conv3) the barriers make it keep every
+        // A fragment of a step live and the occupancy collapses.
+        constexpr int NS = PF + 1;
+        uint4 bq[NS][RN][2];
 #pragma unroll
         for (int u = 0; u < PF; u++)
 #pragma unroll
@@ -654,15 +666,19 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
 #pragma unroll
                 for (int cc = 0; cc < CINP / 32; cc++) {
                     const int step = (i * KW + j) * (CINP / 32) + cc;
+                    if (step + PF < KS) {
+#pragma unroll
+                        for (int n = 0; n < RN; n++) {
+                            bq[(step + PF) % NS][n][0] = wq[((size_t)n * KS + step + PF) * 128];
+                            bq[(step + PF) % NS][n][1] = wq[((size_t)n * KS + step + PF) * 128 + 64];
+                        }
+                    }
+                    if constexpr (SB) __builtin_amdgcn_sched_barrier(0);
                     h8 bh[RN], bl[RN];
 #pragma unroll
                     for (int n = 0; n < RN; n++) {
-                        bh[n] = __builtin_bit_cast(h8, bq[step % PF][n][0]);
-                        bl[n] = __builtin_bit_cast(h8, bq[step % PF][n][1]);
-                        if (step + PF < KS) {
-                            bq[step % PF][n][0] = wq[((size_t)n * KS + step + PF) * 128];
-                            bq[step % PF][n][1] = wq[((size_t)n * KS + step + PF) * 128 + 64];
-                        }
+                        bh[n] = __builtin_bit_cast(h8, bq[step % NS][n][0]);
+                        bl[n] = __builtin_bit_cast(h8, bq[step % NS][n][1]);
                     }
 #pragma unroll
                     for (int r = 0; r < NV; r++) {
@@ -676,6 +692,7 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
                             acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[n], acc[r][n], 0, 0, 0);
                         }
                     }
+                    if constexpr (SB) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -1232,7 +1249,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             // 32 rows: 4 groups of (4 waves x 2 rows), pooled output 16x16x32
             // 8x8 pooling tiles of 4x4 pixels: workgroups of whole tile rows, pooled output 16x16x32
             if (h2)
-                hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, H2C2_TB, 64 / H2C2_TB, H2C2_WM, 2, true>), dim3(np, 64 / H2C2_TB), dim3(64 * H2C2_WM), 0, ctx->stream,
+                hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, H2C2_TB, 64 / H2C2_TB, H2C2_WM, 2, true, H2C2_PF, true>), dim3(np, 64 / H2C2_TB), dim3(64 * H2C2_WM), 0, ctx->stream,
                                    (const float*)a1, (const uint16_t*)W.c2w_h2.p, (const float*)W.c2b.p, p2, 1.f / H2_WSCALE);
             else
             hipLaunchKernelGGL((conv_mfma16_f32_kernel<36, 36, 32, 5, 5, 32, C2_TB, 64 / C2_TB, C2_WM, C2_RN, true>), dim3(np, 64 / C2_TB),
@@ -1244,7 +1261,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             TimeScope ts(ctx, "cnn_conv3");
             // 13 pixel tiles x 6 channel tiles of 16
             if (h2)
-                hipLaunchKernelGGL((conv_mfma16_h2_kernel<16, 16, 32, 3, 3, 90, 13, 1, 2, 3, false>), dim3(np), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL((conv_mfma16_h2_kernel<16, 16, 32, 3, 3, 90, 13, 1, 2, 3, false, 2, false>), dim3(np), dim3(256), 0, ctx->stream,
                                    (const float*)p2, (const uint16_t*)W.c3w_h2.p, (const float*)W.c3b.p, a3, 1.f / H2_WSCALE);
             else
             hipLaunchKernelGGL((conv_mfma16_f32_kernel<16, 16, 32, 3, 3, 90, 13, 1, C3_WM, 1, false>), dim3(np), dim3(384 * C3_WM), 0,
@@ -1255,7 +1272,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             TimeScope ts(ctx, "cnn_conv4");
             // 9 tiles of four pooling windows x 6 channel tiles; pooled 6x6x90 written directly
             if (h2)
-                hipLaunchKernelGGL((conv_mfma16_h2_kernel<14, 14, 90, 3, 3, 90, 9, 1, 2, 3, true>), dim3(np), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL((conv_mfma16_h2_kernel<14, 14, 90, 3, 3, 90, 9, 1, 2, 3, true, H2C34_PF, true>), dim3(np), dim3(256), 0, ctx->stream,
                                    (const float*)a3, (const uint16_t*)W.c4w_h2.p, (const float*)W.c4b.p, p4, 1.f / H2_WSCALE);
             else
             hipLaunchKernelGGL((conv_mfma16_f32_kernel<14, 14, 90, 3, 3, 90, 9, 1, C4_WM, 1, true>), dim3(np), dim3(384 * C4_WM), 0,
