@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--streams", action="store_true",
+                    help="BASELINE config 5: every GPU processes its OWN video stream (seed + rank), no record gather; "
+                         "the default is ONE video whose frames are dealt to the ranks and gathered (configs 3 / 4)")
     ap.add_argument("--lanes", type=int, default=LANES_DEFAULT,
                     help="pairs of (board, stones) contexts per GPU; the batch is split between them so more "
                          "kernels are in flight and drain / host gaps of one lane are filled by the others")
@@ -105,14 +108,15 @@ def main():
     # new stone every 5 frames.  Global frame g lives on rank g mod world (the
     # pipeline's sharding), so every rank builds the same move list and renders only its frames;
     # frames that show an unchanged position are the last render under fresh sensor noise.
-    rng = np.random.default_rng(synth.SEED)                     # identical on every rank
+    dworld, drank = (1, 0) if args.streams else (world, rank)   # how the VIDEO is laid out over the ranks
+    rng = np.random.default_rng(synth.SEED + (rank if args.streams else 0))     # one game: identical on every rank
     corners = synth.random_corners(H, W, rng)
     frames = torch.empty((F, H, W, 3), dtype=torch.uint8, device=dev)
     stones0 = synth.random_stones(rng, density=0.3)
     true_moves = [("EBW"[stones0[r, c]], r, c) for r in range(19) for c in range(19) if stones0[r, c]]
     n_init = len(true_moves)
     positions, st, color = [stones0.copy()], stones0.copy(), 1
-    for k in range((world * F - 1) // 5):
+    for k in range((dworld * F - 1) // 5):
         while True:
             r, c = rng.integers(1, 18, 2)
             if st[r, c] == 0:
@@ -124,7 +128,7 @@ def main():
     truth = np.zeros((F, 19, 19), np.uint8)
     last_pos, last = -1, None
     for i in range(F):
-        g_idx = i * world + rank
+        g_idx = i * dworld + drank
         pos = g_idx // 5
         if pos != last_pos:
             frames[i] = synth.render(H, W, positions[pos], corners, seed=synth.SEED + g_idx, device=dev)
@@ -145,7 +149,7 @@ def main():
     M = capi.get_perspective_transform(corners, dst)
     from camkifu_amd import pipeline
     from camkifu_amd.controller import ControllerHeadless
-    pipe = pipeline.FastFilePipeline(H, W, ControllerHeadless(), ctx=ctx, ctx_board=ctx_b, rank=rank, world=world,
+    pipe = pipeline.FastFilePipeline(H, W, ControllerHeadless(), ctx=ctx, ctx_board=ctx_b, rank=drank, world=dworld,
                                      device=cdev)
     # one host thread per context (a context is single-threaded by contract), each with its own stream
     pools = [(ThreadPoolExecutor(1), ThreadPoolExecutor(1)) for _ in lanes]
@@ -178,7 +182,7 @@ def main():
         t_a = time.perf_counter()
         rec = pipeline.pack_records_raw(board[0], board[1], labels.cpu().numpy(), conf.cpu().numpy())
         t_b = time.perf_counter()
-        full = pipeline.gather_records(rec, world * F, rank, world, cdev) if world > 1 else rec
+        full = pipeline.gather_records(rec, world * F, rank, world, cdev) if dworld > 1 else rec
         t_c = time.perf_counter()
         pipe.stones = pipeline.StonesFold(ControllerHeadless())     # every step replays the same game from scratch
         pipe.fold(full)
@@ -303,7 +307,7 @@ def main():
             "dtype": {"fp32": "u8+f32", "bf16": "u8+bf16", "f16x2": "u8+f16x2(f32 accumulate)"}[args.cnn], "data": "synthetic",
             "config": {"workload": "%dx%d synthetic video, %d-frame batch per GPU, board detect (K1-K6) + "
                                    "stones detect (K8,K10-K12), cnn %s" % (W, H, F, args.cnn),
-                       "frames_per_gpu": F, "height": H, "width": W, "parallelism": "frames sharded x%d" % world,
+                       "frames_per_gpu": F, "height": H, "width": W, "parallelism": ("%d independent streams" % world) if args.streams else ("frames sharded x%d" % world),
                        "lanes_per_gpu": len(lanes)},
             "roofline": roof,
             "mfma_kernel": mfma_roof,
