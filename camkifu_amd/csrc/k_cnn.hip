@@ -35,6 +35,12 @@
 #ifndef C4_WM
 #define C4_WM 2
 #endif
+#ifndef H2C3_PF
+#define H2C3_PF 2
+#endif
+#ifndef H2C3_SB
+#define H2C3_SB false
+#endif
 #ifndef H2C2_PF
 #define H2C2_PF 2
 #endif
@@ -1261,7 +1267,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             TimeScope ts(ctx, "cnn_conv3");
             // 13 pixel tiles x 6 channel tiles of 16
             if (h2)
-                hipLaunchKernelGGL((conv_mfma16_h2_kernel<16, 16, 32, 3, 3, 90, 13, 1, 2, 3, false, 2, false>), dim3(np), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL((conv_mfma16_h2_kernel<16, 16, 32, 3, 3, 90, 13, 1, 2, 3, false, H2C3_PF, H2C3_SB>), dim3(np), dim3(256), 0, ctx->stream,
                                    (const float*)p2, (const uint16_t*)W.c3w_h2.p, (const float*)W.c3b.p, a3, 1.f / H2_WSCALE);
             else
             hipLaunchKernelGGL((conv_mfma16_f32_kernel<16, 16, 32, 3, 3, 90, 13, 1, C3_WM, 1, false>), dim3(np), dim3(384 * C3_WM), 0,
