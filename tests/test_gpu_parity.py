@@ -598,3 +598,34 @@ def test_cnn_split_fp16_mode_is_f32_accurate(ck, ora, synth):
         assert np.abs(conf - c32).max() <= 1e-5
         y_ora = ora.cnn_predict_regions(W, gobans[0])
         assert np.abs(y[0] - y_ora).max() <= 1e-4
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_board_detect_random_textures(ck, ora, seed):
+    """ck_board_detect (K1..K6 chained on the device, K3 reusing K2's components) against the oracle chain on
+    images that are nothing like a board: blobs, bars and noise at several sizes, widths that do and do not take
+    the dword row kernel, edges on and off the image frame; a low Hough threshold so that many lines come out"""
+    rng = np.random.default_rng(100 + seed)
+    h, w = [(96, 128), (97, 131), (120, 160), (64, 200), (150, 90), (128, 132)][seed]
+    frames = []
+    for k in range(3):
+        img = np.full((h, w, 3), 90, np.float32) + rng.normal(0, 6, (h, w, 3))
+        for _ in range(rng.integers(3, 9)):
+            y0, x0 = rng.integers(0, h - 20), rng.integers(0, w - 20)
+            hh, ww = rng.integers(8, 60), rng.integers(8, 60)
+            img[y0:y0 + hh, x0:x0 + ww] += rng.choice([-70, 80, 130]) * rng.uniform(0.5, 1.0)
+        if k == 1:
+            img[:, : w // 3] += 100                     # a step edge running off the top and bottom of the frame
+        if k == 2:
+            img[h // 2:, :] -= 60                       # and one running off both sides
+        frames.append(np.clip(img, 0, 255).astype(np.uint8))
+    frames = np.stack(frames)
+    thr = max(8, min(h, w) // 6)
+    out = ck.board_detect(frames, hough_thresh=thr, cap=4096)
+    for k in range(3):
+        ref = ora.board_lines(ora.canny(ora.median(frames[k], 15), 25, 75), thr)
+        assert out[k]["n_contours"] == ref["n_contours"], (seed, k)
+        kk = max(ref["status"], 0)
+        assert out[k]["n_lines"] == kk and np.array_equal(out[k]["lines"][:kk], ref["lines"][:kk]), (seed, k)
+        if ref["n_contours"]:
+            assert out[k]["biggest_area"] == ref["biggest_area"], (seed, k)
