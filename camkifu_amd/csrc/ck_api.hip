@@ -130,6 +130,7 @@ void ck_ctx_destroy(ck_ctx* ctx)
                        &ctx->cnn.c2w_bf, &ctx->cnn.c3w_bf, &ctx->cnn.c4w_bf, &ctx->cnn.d1w_bf,
                        &ctx->cnn.c1w_h2, &ctx->cnn.c2w_h2, &ctx->cnn.c3w_h2, &ctx->cnn.c4w_h2 };
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    if (ctx->cnn_flag_host) (void)hipHostFree(ctx->cnn_flag_host);
     for (auto& m : ctx->mog2) {
         DevBuf* mb[] = { &m.weight, &m.variance, &m.mean, &m.nmodes };
         for (DevBuf* b : mb) if (b->p) (void)hipFree(b->p);
@@ -363,10 +364,38 @@ static int cnn_predict_dev(ck_ctx* ctx, const uint8_t* d_goban, int n, float* y,
     CK_TRY(ck_ensure(ctx, ctx->ybuf, (size_t)n * 8100 * sizeof(float)));
     CK_TRY(ck_ensure(ctx, ctx->lblbuf, (size_t)n * 361));
     CK_TRY(ck_ensure(ctx, ctx->confbuf, (size_t)n * 361 * sizeof(double)));
-    CK_TRY(k_cnn_predict(ctx, d_goban, n, (float*)ctx->ybuf.p, (uint8_t*)ctx->lblbuf.p, (double*)ctx->confbuf.p));
+    if (ctx->cnn_mode == CK_CNN_F16X2) {
+        // Safety net of the split-precision mode: an activation beyond the fp16 range (|x| > 65000; never seen with
+        // 8-bit images and sane weights) would turn into inf.  The kernels raise a flag in host-mapped memory, which
+        // cnn_finish() looks at after the one synchronisation the call needs anyway.
+        if (!ctx->cnn_flag_host) {
+            CK_HIP(ctx, hipHostMalloc((void**)&ctx->cnn_flag_host, 64, hipHostMallocMapped));
+            CK_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->cnn_flag_dev, ctx->cnn_flag_host, 0));
+        }
+        *ctx->cnn_flag_host = 0;
+        CK_TRY(k_cnn_predict(ctx, d_goban, n, (float*)ctx->ybuf.p, (uint8_t*)ctx->lblbuf.p, (double*)ctx->confbuf.p, ctx->cnn_flag_dev));
+    } else {
+        CK_TRY(k_cnn_predict(ctx, d_goban, n, (float*)ctx->ybuf.p, (uint8_t*)ctx->lblbuf.p, (double*)ctx->confbuf.p));
+    }
     if (y) CK_TRY(ck_from_device(ctx, y, ctx->ybuf.p, (size_t)n * 8100 * sizeof(float), out_space));
     if (labels) CK_TRY(ck_from_device(ctx, labels, ctx->lblbuf.p, (size_t)n * 361, out_space));
     if (conf) CK_TRY(ck_from_device(ctx, conf, ctx->confbuf.p, (size_t)n * 361 * sizeof(double), out_space));
+    return CK_OK;
+}
+
+// synchronise; if the split-precision kernels flagged a value outside the fp16 range, recompute the batch with
+// the f32 kernels (the goban images are still in place) and deliver again
+static int cnn_finish(ck_ctx* ctx, const uint8_t* d_goban, int n, float* y, uint8_t* labels, double* conf, int out_space)
+{
+    CK_TRY(finish(ctx));
+    if (ctx->cnn_mode == CK_CNN_F16X2 && ctx->cnn_flag_host && *(volatile int*)ctx->cnn_flag_host) {
+        ctx->cnn_mode = CK_CNN_FP32;
+        const int rc = cnn_predict_dev(ctx, d_goban, n, y, labels, conf, out_space);
+        ctx->cnn_mode = CK_CNN_F16X2;
+        ctx->cnn_fallbacks++;
+        if (rc) return rc;
+        return finish(ctx);
+    }
     return CK_OK;
 }
 
@@ -379,7 +408,7 @@ int ck_cnn_predict(ck_ctx* ctx, const uint8_t* goban, int n, int in_space,
     const void* d_in;
     CK_TRY(ck_to_device(ctx, goban, (size_t)n * 380 * 380 * 3, in_space, ctx->in_stage, &d_in));
     CK_TRY(cnn_predict_dev(ctx, (const uint8_t*)d_in, n, y, labels, conf, out_space));
-    return finish(ctx);
+    return cnn_finish(ctx, (const uint8_t*)d_in, n, y, labels, conf, out_space);
 }
 
 int ck_stones_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
@@ -393,7 +422,7 @@ int ck_stones_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int i
     CK_TRY(ck_ensure(ctx, ctx->goban, (size_t)n * 380 * 380 * 3));
     CK_TRY(k_warp(ctx, (const uint8_t*)d_in, n, h, w, d_minv, m_count, 380, (uint8_t*)ctx->goban.p));
     CK_TRY(cnn_predict_dev(ctx, (const uint8_t*)ctx->goban.p, n, nullptr, labels, conf, out_space));
-    return finish(ctx);
+    return cnn_finish(ctx, (const uint8_t*)ctx->goban.p, n, nullptr, labels, conf, out_space);
 }
 
 int ck_mog2_create(ck_ctx* ctx, int h, int w, int* handle)

@@ -75,6 +75,9 @@ struct ck_ctx {
     size_t host_pinned_cap = 0;
 
     CnnWeights cnn;
+    int* cnn_flag_host = nullptr;    // host-mapped flag: the split-precision kernels met a value outside the fp16 range
+    int* cnn_flag_dev = nullptr;
+    int cnn_fallbacks = 0;           // batches the split-precision mode handed back to the f32 kernels
     int cnn_mode = CK_CNN_F16X2;     // f32-accurate and 2.3x faster than the k-ordered f32 chain (CK_CNN_FP32)
     std::vector<Mog2State> mog2;
 };
@@ -129,7 +132,9 @@ int k_warp(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, const double*
 int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int hough_thresh,
                   float* lines, int cap, ck_board_result* res, uint8_t* d_ghost_out,
                   const int* d_canny_border_flag = nullptr);
-int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int n, float* d_y, uint8_t* d_labels, double* d_conf);
+// d_nonfinite (nullable): set to 1 when a softmax came out inf / NaN
+int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int n, float* d_y, uint8_t* d_labels, double* d_conf,
+                  int* d_nonfinite = nullptr);
 int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space);
 int k_mog2_apply(ck_ctx* ctx, Mog2State& st, const uint8_t* d_img, double lr, uint8_t* d_fg);
 

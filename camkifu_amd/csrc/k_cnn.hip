@@ -567,7 +567,7 @@ __device__ __forceinline__ void split_h2(float x, _Float16& hi, _Float16& lo)
 template <int H, int W, int CIN, int KH, int KW, int COUT, int TB, int YB, int WAVES_M, int RN, bool POOL, int PF, bool SB>
 __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfma16_h2_kernel(
     const float* __restrict__ in, const uint16_t* __restrict__ wt, const float* __restrict__ bias,
-    float* __restrict__ out, float wscale_inv)
+    float* __restrict__ out, float wscale_inv, int* __restrict__ overflow)
 {
 #pragma clang fp contract(off)
     constexpr int OH = H - KH + 1, OW = W - KW + 1, M = OH * OW;
@@ -596,10 +596,14 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
     if (row_cnt > ROWS) row_cnt = ROWS;
     {
         const float2* g = reinterpret_cast<const float2*>(in + ((size_t)patch * H + oy_min) * W * CIN);
+        float big = 0.f;
 #pragma unroll 4
         for (int i = tid; i < row_cnt * W * (CIN / 2); i += NTHREADS) {
             const int pxl = i / (CIN / 2), c = i % (CIN / 2);
             const float2 v = g[i];
+            // an activation outside the fp16 range would become inf (and the relu would then hide the NaN): the
+            // largest magnitude is tracked and checked once, the host recomputes a flagged batch with the f32 kernels
+            big = fmaxf(big, fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)));
             _Float16 h0, l0, h1, l1;
             split_h2(v.x, h0, l0);
             split_h2(v.y, h1, l1);
@@ -608,6 +612,7 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
             *reinterpret_cast<h2v*>(d) = h2v{h0, h1};
             *reinterpret_cast<h2v*>(d + CINP) = h2v{l0, l1};
         }
+        if (overflow && !(big <= 65000.f)) *overflow = 1;       // also true for NaN
         if constexpr (CINP > CIN)
             for (int i = tid; i < row_cnt * W * (CINP - CIN); i += NTHREADS) {
                 const int pxl = i / (CINP - CIN), c = CIN + i % (CINP - CIN);
@@ -988,7 +993,7 @@ __global__ __launch_bounds__(64) void fc2_softmax_kernel(const float* __restrict
 // later region wins: cell (r, c) takes its value from region (I(r), I(c)) with I(17) = I(18) = 9.
 namespace {
 __global__ __launch_bounds__(128) void decode_kernel(const float* __restrict__ y, uint8_t* __restrict__ labels,
-                                                     double* __restrict__ conf, int nframes)
+                                                     double* __restrict__ conf, int nframes, int* __restrict__ nonfinite)
 {
     __shared__ int lab[100];
     __shared__ double cf[100];
@@ -1004,6 +1009,7 @@ __global__ __launch_bounds__(128) void decode_kernel(const float* __restrict__ y
         }
         lab[t] = label;
         cf[t] = (double)yy[label] / s;
+        if (nonfinite && !(s - s == 0.0)) *nonfinite = 1;      // inf / NaN somewhere in this softmax
     }
     __syncthreads();
     for (int cell = t; cell < 361; cell += 128) {
@@ -1174,7 +1180,8 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
     return CK_OK;
 }
 
-int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, uint8_t* d_labels, double* d_conf)
+int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, uint8_t* d_labels, double* d_conf,
+                  int* d_nonfinite)
 {
     // convolutions run in chunks of frames so the activation scratch stays bounded; the dense
     // tail runs once over the whole batch (its 32-patch MFMA tiles need many waves in flight)
@@ -1231,7 +1238,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
                            (const uint16_t*)q4_all, (const uint16_t*)W.d1w_bf.p, (const float*)W.d1b.p, hb, np);
         hipLaunchKernelGGL(fc2_softmax_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float*)hb,
                            (const float*)W.d2w.p, (const float*)W.d2b.p, d_y, np);
-        hipLaunchKernelGGL(decode_kernel, dim3(nframes), dim3(128), 0, ctx->stream, (const float*)d_y, d_labels, d_conf, nframes);
+        hipLaunchKernelGGL(decode_kernel, dim3(nframes), dim3(128), 0, ctx->stream, (const float*)d_y, d_labels, d_conf, nframes, d_nonfinite);
         CK_HIP(ctx, hipGetLastError());
         return CK_OK;
     }
@@ -1256,7 +1263,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             // 8x8 pooling tiles of 4x4 pixels: workgroups of whole tile rows, pooled output 16x16x32
             if (h2)
                 hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, H2C2_TB, 64 / H2C2_TB, H2C2_WM, 2, true, H2C2_PF, true>), dim3(np, 64 / H2C2_TB), dim3(64 * H2C2_WM), 0, ctx->stream,
-                                   (const float*)a1, (const uint16_t*)W.c2w_h2.p, (const float*)W.c2b.p, p2, 1.f / H2_WSCALE);
+                                   (const float*)a1, (const uint16_t*)W.c2w_h2.p, (const float*)W.c2b.p, p2, 1.f / H2_WSCALE, d_nonfinite);
             else
             hipLaunchKernelGGL((conv_mfma16_f32_kernel<36, 36, 32, 5, 5, 32, C2_TB, 64 / C2_TB, C2_WM, C2_RN, true>), dim3(np, 64 / C2_TB),
                                dim3(64 * C2_WM * (2 / C2_RN)), 0, ctx->stream, (const float*)a1, (const float*)W.c2w.p,
@@ -1268,7 +1275,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             // 13 pixel tiles x 6 channel tiles of 16
             if (h2)
                 hipLaunchKernelGGL((conv_mfma16_h2_kernel<16, 16, 32, 3, 3, 90, 13, 1, 2, 3, false, H2C3_PF, H2C3_SB>), dim3(np), dim3(256), 0, ctx->stream,
-                                   (const float*)p2, (const uint16_t*)W.c3w_h2.p, (const float*)W.c3b.p, a3, 1.f / H2_WSCALE);
+                                   (const float*)p2, (const uint16_t*)W.c3w_h2.p, (const float*)W.c3b.p, a3, 1.f / H2_WSCALE, d_nonfinite);
             else
             hipLaunchKernelGGL((conv_mfma16_f32_kernel<16, 16, 32, 3, 3, 90, 13, 1, C3_WM, 1, false>), dim3(np), dim3(384 * C3_WM), 0,
                                ctx->stream, (const float*)p2, (const float*)W.c3w.p, (const float*)W.c3b.p, a3);
@@ -1279,7 +1286,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             // 9 tiles of four pooling windows x 6 channel tiles; pooled 6x6x90 written directly
             if (h2)
                 hipLaunchKernelGGL((conv_mfma16_h2_kernel<14, 14, 90, 3, 3, 90, 9, 1, 2, 3, true, H2C34_PF, true>), dim3(np), dim3(256), 0, ctx->stream,
-                                   (const float*)a3, (const uint16_t*)W.c4w_h2.p, (const float*)W.c4b.p, p4, 1.f / H2_WSCALE);
+                                   (const float*)a3, (const uint16_t*)W.c4w_h2.p, (const float*)W.c4b.p, p4, 1.f / H2_WSCALE, d_nonfinite);
             else
             hipLaunchKernelGGL((conv_mfma16_f32_kernel<14, 14, 90, 3, 3, 90, 9, 1, C4_WM, 1, true>), dim3(np), dim3(384 * C4_WM), 0,
                                ctx->stream, (const float*)a3, (const float*)W.c4w.p, (const float*)W.c4b.p, p4);
@@ -1293,7 +1300,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
                            (const float*)p4_all, (const float*)W.d1w.p, (const float*)W.d1b.p, h1, np);
         hipLaunchKernelGGL(fc2_softmax_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float*)h1,
                            (const float*)W.d2w.p, (const float*)W.d2b.p, d_y, np);
-        hipLaunchKernelGGL(decode_kernel, dim3(nframes), dim3(128), 0, ctx->stream, (const float*)d_y, d_labels, d_conf, nframes);
+        hipLaunchKernelGGL(decode_kernel, dim3(nframes), dim3(128), 0, ctx->stream, (const float*)d_y, d_labels, d_conf, nframes, d_nonfinite);
         CK_HIP(ctx, hipGetLastError());
     }
     return CK_OK;

@@ -629,3 +629,22 @@ def test_board_detect_random_textures(ck, ora, seed):
         assert out[k]["n_lines"] == kk and np.array_equal(out[k]["lines"][:kk], ref["lines"][:kk]), (seed, k)
         if ref["n_contours"]:
             assert out[k]["biggest_area"] == ref["biggest_area"], (seed, k)
+
+
+def test_split_precision_falls_back_when_fp16_overflows(ck, synth):
+    """activations beyond the fp16 range (weights blown up on purpose) turn into inf in the split-precision
+    kernels; the decode kernel notices and the batch is recomputed by the f32 kernels: same bits as CK_CNN_FP32"""
+    from camkifu_amd import capi
+    W = {k: (v * 40.0 if k in ("c1w", "c2w", "c3w") else v) for k, v in synth.cnn_weights().items()}
+    ck.cnn_set_weights(W)
+    gobans = np.random.default_rng(3).integers(0, 256, (2, 380, 380, 3), dtype=np.uint8)
+    try:
+        ck.cnn_set_mode(capi.CK_CNN_FP32)
+        y32, l32, c32 = ck.cnn_predict(gobans)
+        assert np.isfinite(y32).all()
+        ck.cnn_set_mode(capi.CK_CNN_F16X2)
+        y, lab, conf = ck.cnn_predict(gobans)
+    finally:
+        ck.cnn_set_mode(capi.CK_CNN_DEFAULT)
+        ck.cnn_set_weights(synth.cnn_weights())
+    assert np.array_equal(y, y32) and np.array_equal(lab, l32) and np.array_equal(conf, c32)
