@@ -35,6 +35,9 @@
 #ifndef C4_WM
 #define C4_WM 2
 #endif
+#ifndef H2_STAGE_UNROLL
+#define H2_STAGE_UNROLL 8
+#endif
 #ifndef H2C3_PF
 #define H2C3_PF 2
 #endif
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
     {
         const float2* g = reinterpret_cast<const float2*>(in + ((size_t)patch * H + oy_min) * W * CIN);
         float big = 0.f;
-#pragma unroll 4
+#pragma unroll H2_STAGE_UNROLL
         for (int i = tid; i < row_cnt * W * (CIN / 2); i += NTHREADS) {
             const int pxl = i / (CIN / 2), c = i % (CIN / 2);
             const float2 v = g[i];
