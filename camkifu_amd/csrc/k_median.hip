@@ -33,6 +33,10 @@
 //     spills when held to 4; measured 40.1 / 38.8 us against 38.3 us for the single body.
 #include "ck_common.h"
 
+#ifndef MED_MFMA
+#define MED_MFMA 1
+#endif
+
 namespace {
 
 constexpr int HOUT = 16;              // output rows per lane
@@ -174,6 +178,186 @@ __global__ __launch_bounds__(64) void median15_kernel(const uint8_t* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Matrix-core variant (the one launched).  Same radix descent, but the 15x15 box sum of the indicator
+// (x <= t) is two chained i8 MFMAs instead of SWAR adds and DPP shifts, which moves ~70 % of the
+// per-threshold VALU work to the matrix pipe (that pipe is otherwise idle in the board path):
+//   pass 1  C1[x][y_out] = sum_{y_in} Ind[y_in][x] * band[y_in][y_out]      A = the pixels themselves: a lane
+//           holds one column x and 16 consecutive rows as bytes, so the indicator (-128 per byte, SWAR, 2 ops per
+//           dword) IS the A operand; B = a constant band of -4.  C1 = 512 * (vertical count): its byte 1 = 2 * count.
+//   pack    the 4 results of a lane (4 adjacent columns of one output row) -> one dword (3 v_perm)
+//   pass 2  R[y_out][x_out] = sum_{x_in} C1b[y_out][x_in] * band[x_in][x_out] + 256 * 113,  band of -128:
+//           the packed dwords of the 4 column tiles ARE the A operand (the k order of A only has to match the
+//           constant B).  R = 256 * (113 - S):  R >= 256 if the median is above t, R <= 0 otherwise.
+//   update  med = med3(med, R, q + 2^b): one VALU op per pixel.  A pixel whose prefix is not q is left alone by the
+//           arithmetic itself: prefix > q means S < 113 and med > q + 2^b (median of the three = med); prefix < q means
+//           S >= 113, R <= 0 < med < q + 2^b.
+// The prefixes alive at the next level are published through 256 flag bytes in LDS (ds_write_b8 with the
+// median as the address: no VALU work) once per level.
+// Tile: 64x64 input pixels (62 used) -> 48x48 medians per wave; 12 + 9 MFMAs and ~104 VALU ops per threshold
+// against 376 VALU ops per 48x64 tile in the SWAR kernel above.
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int MT = 48;      // medians per tile edge
+
+struct BandTable {
+    uint32_t v[6 * 64 * 4];  // [vertical band for output-row tile 0..2 | horizontal band for output-column tile 0..2][lane][4]
+};
+constexpr BandTable make_band_table()
+{
+    BandTable T{};
+    for (int lane = 0; lane < 64; lane++) {
+        const int n = lane & 15, g = lane >> 4;
+        for (int t = 0; t < 3; t++)
+            for (int d = 0; d < 4; d++) {
+                uint32_t wv = 0, wh = 0;
+                for (int e = 0; e < 4; e++) {
+                    const int y_in = 16 * g + 4 * d + e;          // pass 1: k position (g, 4d+e) <-> input row
+                    const int dv = y_in - (16 * t + n);
+                    if (dv >= 0 && dv <= 14) wv |= 0xFCu << (8 * e);     // -4
+                    const int x_in = 16 * d + 4 * g + e;          // pass 2: k position (g, 4d+e) <-> input column
+                    const int dh = x_in - (16 * t + n);
+                    if (dh >= 0 && dh <= 14) wh |= 0x80u << (8 * e);     // -128
+                }
+                T.v[(t * 64 + lane) * 4 + d] = wv;
+                T.v[((3 + t) * 64 + lane) * 4 + d] = wh;
+            }
+    }
+    return T;
+}
+__device__ const BandTable g_band = make_band_table();
+
+__device__ __forceinline__ int imed3(int a, int b, int c)
+{
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    const int t = hi < c ? hi : c;
+    return lo > t ? lo : t;                 // v_med3_i32
+}
+
+// waves_per_eu(3): a register budget below 256 makes the compiler pick the MFMA forms that write VGPRs; with the
+// default budget the results land in AGPRs and every one of them costs a v_accvgpr_read (84 per threshold).
+__attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void median15_mfma_kernel(const uint8_t* __restrict__ in, int h, int w,
+                                                           uint8_t* __restrict__ out, int pitch)
+{
+    __shared__ uint32_t flags[64];
+    const int lane = threadIdx.x;
+    const int n = lane & 15, g = lane >> 4;
+    const int ox = blockIdx.x * MT, oy = blockIdx.y * MT;
+    const int f = blockIdx.z / 3, c = blockIdx.z % 3;
+    const uint8_t* src = in + (size_t)f * h * w * 3 + c;
+
+    // ---- load: column tile i, lane (n, g) <- column ox - 7 + 16 i + n, rows oy - 7 + 16 g + 0..15 (replicate border)
+    int yo[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        int y = oy - 7 + 16 * g + j;
+        y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+        yo[j] = y * w * 3;
+    }
+    v4i nx[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int x = ox - 7 + 16 * i + n;
+        x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+        const uint8_t* col = src + x * 3;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t v = (uint32_t)col[yo[4 * d]] | ((uint32_t)col[yo[4 * d + 1]] << 8) |
+                               ((uint32_t)col[yo[4 * d + 2]] << 16) | ((uint32_t)col[yo[4 * d + 3]] << 24);
+            nx[i][d] = (int)~v;
+        }
+    }
+    const v4i* bt = reinterpret_cast<const v4i*>(g_band.v);
+    v4i bv[3], bh[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        bv[t] = bt[t * 64 + lane];
+        bh[t] = bt[(3 + t) * 64 + lane];
+    }
+    const v4i zero = {0, 0, 0, 0};
+    const v4i c113 = {256 * 113, 256 * 113, 256 * 113, 256 * 113};
+
+    int med[3][3][4];
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) med[t][u][e] = 0;
+    flags[lane] = 0;
+
+    unsigned long long c0 = 1ull, c1 = 0ull, c2 = 0ull, c3 = 0ull;      // bit l of ck <-> prefix 4 l + k (wave-uniform)
+    for (int b = 7; b >= 0; b--) {
+        const int half = 1 << b;
+        {
+            for (;;) {
+                int q;
+                if (c0) { q = 4 * __builtin_ctzll(c0); c0 &= c0 - 1; }
+                else if (c1) { q = 4 * __builtin_ctzll(c1) + 1; c1 &= c1 - 1; }
+                else if (c2) { q = 4 * __builtin_ctzll(c2) + 2; c2 &= c2 - 1; }
+                else if (c3) { q = 4 * __builtin_ctzll(c3) + 3; c3 &= c3 - 1; }
+                else break;
+                const uint32_t T = (uint32_t)(q + half) * 0x01010101u;      // t + 1 in every byte
+                const int C = q + half;
+                v4i a2[3];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    v4i ind;
+#pragma unroll
+                    for (int d = 0; d < 4; d++)
+                        ind[d] = (int)(__builtin_amdgcn_lerp((uint32_t)nx[i][d], T, 0u) & 0x80808080u);   // -128 where x <= t
+#pragma unroll
+                    for (int t = 0; t < 3; t++) {
+                        const v4i c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ind, bv[t], zero, 0, 0, 0);
+                        const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)c1[1], (uint32_t)c1[0], 0x0c0c0501u);
+                        const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)c1[3], (uint32_t)c1[2], 0x0c0c0501u);
+                        a2[t][i] = (int)__builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 3; t++)
+#pragma unroll
+                    for (int u = 0; u < 3; u++) {
+                        const v4i r = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2[t], bh[u], c113, 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) med[t][u][e] = imed3(med[t][u][e], r[e], C);
+                    }
+            }
+        }
+        if (b == 0) break;
+        // the distinct prefixes of the tile -> the set of the next level
+        uint8_t* fb = reinterpret_cast<uint8_t*>(flags);
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+#pragma unroll
+            for (int u = 0; u < 3; u++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) fb[med[t][u][e]] = 1;
+        const uint32_t fw = flags[lane];
+        flags[lane] = 0;
+        c0 = __builtin_amdgcn_ballot_w64((fw & 0xFFu) != 0);
+        c1 = __builtin_amdgcn_ballot_w64((fw & 0xFF00u) != 0);
+        c2 = __builtin_amdgcn_ballot_w64((fw & 0xFF0000u) != 0);
+        c3 = __builtin_amdgcn_ballot_w64((fw & 0xFF000000u) != 0);
+    }
+
+    // ---- store: planar; lane (n, g) holds rows 16 t + 4 g + e of column 16 u + n
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+        const int x = ox + 16 * u + n;
+        if (x < w) {
+            uint8_t* dst = out + ((size_t)(f * 3 + c) * h) * pitch + x;
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int y = oy + 16 * t + 4 * g + e;
+                    if (y < h) dst[(size_t)y * pitch] = (uint8_t)med[t][u][e];
+                }
+        }
+    }
+}
+
 __global__ void planar_to_interleaved_kernel(const uint8_t* __restrict__ planes, int h, int w, int pitch,
                                              uint8_t* __restrict__ out)
 {
@@ -207,8 +391,13 @@ __global__ void interleaved_to_planar_kernel(const uint8_t* __restrict__ in, int
 int k_median15_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, uint8_t* d_planes, int pitch)
 {
     TimeScope ts(ctx, "median");
+#if MED_MFMA
+    dim3 grid((w + MT - 1) / MT, (h + MT - 1) / MT, n * 3);
+    hipLaunchKernelGGL(median15_mfma_kernel, grid, dim3(64), 0, ctx->stream, d_bgr, h, w, d_planes, pitch);
+#else
     dim3 grid((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H, n * 3);
     hipLaunchKernelGGL(median15_kernel, grid, dim3(64), 0, ctx->stream, d_bgr, h, w, d_planes, pitch);
+#endif
     CK_HIP(ctx, hipGetLastError());
     return CK_OK;
 }
