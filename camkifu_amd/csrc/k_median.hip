@@ -36,7 +36,6 @@
 #ifndef MED_MFMA
 #define MED_MFMA 1
 #endif
-
 namespace {
 
 constexpr int HOUT = 16;              // output rows per lane
@@ -180,28 +179,32 @@ __global__ __launch_bounds__(64) void median15_kernel(const uint8_t* __restrict_
 
 // ------------------------------------------------------------------------------------------
 // Matrix-core variant (the one launched).  Same radix descent, but the 15x15 box sum of the indicator
-// (x <= t) is two chained i8 MFMAs instead of SWAR adds and DPP shifts, which moves ~70 % of the
+// (x <= t) is two chained i8 MFMAs instead of SWAR adds and DPP shifts, which moves most of the
 // per-threshold VALU work to the matrix pipe (that pipe is otherwise idle in the board path):
 //   pass 1  C1[x][y_out] = sum_{y_in} Ind[y_in][x] * band[y_in][y_out]      A = the pixels themselves: a lane
 //           holds one column x and 16 consecutive rows as bytes, so the indicator (-128 per byte, SWAR, 2 ops per
-//           dword) IS the A operand; B = a constant band of -4.  C1 = 512 * (vertical count): its byte 1 = 2 * count.
-//   pack    the 4 results of a lane (4 adjacent columns of one output row) -> one dword (3 v_perm)
-//   pass 2  R[y_out][x_out] = sum_{x_in} C1b[y_out][x_in] * band[x_in][x_out] + 256 * 113,  band of -128:
-//           the packed dwords of the 4 column tiles ARE the A operand (the k order of A only has to match the
-//           constant B).  R = 256 * (113 - S):  R >= 256 if the median is above t, R <= 0 otherwise.
+//           dword) IS the A operand; B = a constant band of -4.  C1 = 512 * (vertical count) <= 7680: as four
+//           bytes that is (0, 2 * count, 0, 0).
+//   pass 2  R[y_out][x_out] = sum_{x_in} C1[y_out][x_in] * band[x_in][x_out] + 256 * 113.  The four i32 results a
+//           lane holds after pass 1 (4 adjacent columns of one output row) are used AS THEY ARE as the 16 k-bytes
+//           of the A operand: 12 of the 16 bytes are zero and the constant B (band of -128) has its weights at the
+//           other four, so nothing is repacked; a 16-column output tile needs the two column tiles its 30-column
+//           window spans = two accumulating MFMAs.  R = 256 * (113 - S):  >= 256 if the median is above t, <= 0
+//           otherwise.
 //   update  med = med3(med, R, q + 2^b): one VALU op per pixel.  A pixel whose prefix is not q is left alone by the
 //           arithmetic itself: prefix > q means S < 113 and med > q + 2^b (median of the three = med); prefix < q means
 //           S >= 113, R <= 0 < med < q + 2^b.
 // The prefixes alive at the next level are published through 256 flag bytes in LDS (ds_write_b8 with the
 // median as the address: no VALU work) once per level.
-// Tile: 64x64 input pixels (62 used) -> 48x48 medians per wave; 12 + 9 MFMAs and ~104 VALU ops per threshold
-// against 376 VALU ops per 48x64 tile in the SWAR kernel above.
+// Tile: 64x64 input pixels (62 used) -> 48x48 medians per wave; 12 + 18 MFMAs and 68 VALU ops per threshold
+// against 376 VALU ops per 48x64 tile in the SWAR kernel above.  Measured rates (tools/micro/mfma_i8.hip): one
+// v_mfma_i32_16x16x64_i8 = 18 cycles of the matrix pipe and ~8 cycles during which the SIMD issues no VALU op.
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int MT = 48;      // medians per tile edge
 
 struct BandTable {
-    uint32_t v[6 * 64 * 4];  // [vertical band for output-row tile 0..2 | horizontal band for output-column tile 0..2][lane][4]
+    uint32_t v[5 * 64 * 4];  // [vertical band for output-row tile 0..2 | horizontal band, same / next column tile][lane][4]
 };
 constexpr BandTable make_band_table()
 {
@@ -210,17 +213,20 @@ constexpr BandTable make_band_table()
         const int n = lane & 15, g = lane >> 4;
         for (int t = 0; t < 3; t++)
             for (int d = 0; d < 4; d++) {
-                uint32_t wv = 0, wh = 0;
+                uint32_t wv = 0;
                 for (int e = 0; e < 4; e++) {
                     const int y_in = 16 * g + 4 * d + e;          // pass 1: k position (g, 4d+e) <-> input row
                     const int dv = y_in - (16 * t + n);
                     if (dv >= 0 && dv <= 14) wv |= 0xFCu << (8 * e);     // -4
-                    const int x_in = 16 * d + 4 * g + e;          // pass 2: k position (g, 4d+e) <-> input column
-                    const int dh = x_in - (16 * t + n);
-                    if (dh >= 0 && dh <= 14) wh |= 0x80u << (8 * e);     // -128
                 }
                 T.v[(t * 64 + lane) * 4 + d] = wv;
-                T.v[((3 + t) * 64 + lane) * 4 + d] = wh;
+            }
+        for (int k = 0; k < 2; k++)
+            for (int e = 0; e < 4; e++) {
+                // pass 2: dword e of the A operand is the raw i32 of column 4g + e of column tile u + k; its byte 1
+                // carries the value.  Output column n of tile u.
+                const int dh = 16 * k + 4 * g + e - n;
+                T.v[((3 + k) * 64 + lane) * 4 + e] = (dh >= 0 && dh <= 14) ? (0x80u << 8) : 0u;     // -128
             }
     }
     return T;
@@ -235,9 +241,9 @@ __device__ __forceinline__ int imed3(int a, int b, int c)
 }
 
 // waves_per_eu(3): a register budget below 256 makes the compiler pick the MFMA forms that write VGPRs; with the
-// default budget the results land in AGPRs and every one of them costs a v_accvgpr_read (84 per threshold).
-__attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void median15_mfma_kernel(const uint8_t* __restrict__ in, int h, int w,
-                                                           uint8_t* __restrict__ out, int pitch)
+// default budget the results land in AGPRs and every one of them costs a v_accvgpr_read.
+__attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void median15_mfma_kernel(
+    const uint8_t* __restrict__ in, int h, int w, uint8_t* __restrict__ out, int pitch)
 {
     __shared__ uint32_t flags[64];
     const int lane = threadIdx.x;
@@ -247,33 +253,52 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
     const uint8_t* src = in + (size_t)f * h * w * 3 + c;
 
     // ---- load: column tile i, lane (n, g) <- column ox - 7 + 16 i + n, rows oy - 7 + 16 g + 0..15 (replicate border)
-    int yo[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        int y = oy - 7 + 16 * g + j;
-        y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-        yo[j] = y * w * 3;
-    }
     v4i nx[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int x = ox - 7 + 16 * i + n;
-        x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
-        const uint8_t* col = src + x * 3;
+    if (ox >= 7 && ox + 56 < w && oy >= 7 && oy + 56 < h) {
+        // interior tile: one per-lane offset, everything else is wave-uniform (scalar base + immediate)
+        const uint8_t* base = src + ((size_t)(oy - 7) * w + (ox - 7)) * 3;
+        uint32_t voff = (uint32_t)((16 * g * w + n) * 3);
+        asm volatile("" : "+v"(voff));          // keep it one per-lane offset: scalar base + voff + immediate per load
 #pragma unroll
         for (int d = 0; d < 4; d++) {
-            const uint32_t v = (uint32_t)col[yo[4 * d]] | ((uint32_t)col[yo[4 * d + 1]] << 8) |
-                               ((uint32_t)col[yo[4 * d + 2]] << 16) | ((uint32_t)col[yo[4 * d + 3]] << 24);
-            nx[i][d] = (int)~v;
+            const uint8_t* r0 = base + (size_t)(uint32_t)((4 * d) * w * 3);
+            const uint8_t* r1 = base + (size_t)(uint32_t)((4 * d + 1) * w * 3);
+            const uint8_t* r2 = base + (size_t)(uint32_t)((4 * d + 2) * w * 3);
+            const uint8_t* r3 = base + (size_t)(uint32_t)((4 * d + 3) * w * 3);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t v = (uint32_t)(r0 + 48 * i)[voff] | ((uint32_t)(r1 + 48 * i)[voff] << 8) |
+                                   ((uint32_t)(r2 + 48 * i)[voff] << 16) | ((uint32_t)(r3 + 48 * i)[voff] << 24);
+                nx[i][d] = (int)~v;
+            }
+        }
+    } else {
+        int yo[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            int y = oy - 7 + 16 * g + j;
+            y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+            yo[j] = y * w * 3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int x = ox - 7 + 16 * i + n;
+            x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+            const uint8_t* col = src + x * 3;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t v = (uint32_t)col[yo[4 * d]] | ((uint32_t)col[yo[4 * d + 1]] << 8) |
+                                   ((uint32_t)col[yo[4 * d + 2]] << 16) | ((uint32_t)col[yo[4 * d + 3]] << 24);
+                nx[i][d] = (int)~v;
+            }
         }
     }
     const v4i* bt = reinterpret_cast<const v4i*>(g_band.v);
-    v4i bv[3], bh[3];
+    v4i bv[3], bh[2];
 #pragma unroll
-    for (int t = 0; t < 3; t++) {
-        bv[t] = bt[t * 64 + lane];
-        bh[t] = bt[(3 + t) * 64 + lane];
-    }
+    for (int t = 0; t < 3; t++) bv[t] = bt[t * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 2; k++) bh[k] = bt[(3 + k) * 64 + lane];
     const v4i zero = {0, 0, 0, 0};
     const v4i c113 = {256 * 113, 256 * 113, 256 * 113, 256 * 113};
 
@@ -289,39 +314,35 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
     unsigned long long c0 = 1ull, c1 = 0ull, c2 = 0ull, c3 = 0ull;      // bit l of ck <-> prefix 4 l + k (wave-uniform)
     for (int b = 7; b >= 0; b--) {
         const int half = 1 << b;
-        {
-            for (;;) {
-                int q;
-                if (c0) { q = 4 * __builtin_ctzll(c0); c0 &= c0 - 1; }
-                else if (c1) { q = 4 * __builtin_ctzll(c1) + 1; c1 &= c1 - 1; }
-                else if (c2) { q = 4 * __builtin_ctzll(c2) + 2; c2 &= c2 - 1; }
-                else if (c3) { q = 4 * __builtin_ctzll(c3) + 3; c3 &= c3 - 1; }
-                else break;
-                const uint32_t T = (uint32_t)(q + half) * 0x01010101u;      // t + 1 in every byte
-                const int C = q + half;
-                v4i a2[3];
+        for (;;) {
+            int q;
+            if (c0) { q = 4 * __builtin_ctzll(c0); c0 &= c0 - 1; }
+            else if (c1) { q = 4 * __builtin_ctzll(c1) + 1; c1 &= c1 - 1; }
+            else if (c2) { q = 4 * __builtin_ctzll(c2) + 2; c2 &= c2 - 1; }
+            else if (c3) { q = 4 * __builtin_ctzll(c3) + 3; c3 &= c3 - 1; }
+            else break;
+            const uint32_t T = (uint32_t)(q + half) * 0x01010101u;      // t + 1 in every byte
+            const int C = q + half;
+            v4i ind[4];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    v4i ind;
+            for (int i = 0; i < 4; i++)
 #pragma unroll
-                    for (int d = 0; d < 4; d++)
-                        ind[d] = (int)(__builtin_amdgcn_lerp((uint32_t)nx[i][d], T, 0u) & 0x80808080u);   // -128 where x <= t
+                for (int d = 0; d < 4; d++)
+                    ind[i][d] = (int)(__builtin_amdgcn_lerp((uint32_t)nx[i][d], T, 0u) & 0x80808080u);   // -128 where x <= t
 #pragma unroll
-                    for (int t = 0; t < 3; t++) {
-                        const v4i c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(ind, bv[t], zero, 0, 0, 0);
-                        const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)c1[1], (uint32_t)c1[0], 0x0c0c0501u);
-                        const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)c1[3], (uint32_t)c1[2], 0x0c0c0501u);
-                        a2[t][i] = (int)__builtin_amdgcn_perm(p23, p01, 0x05040100u);
-                    }
-                }
+            for (int t = 0; t < 3; t++) {
+                v4i c1v[4];
 #pragma unroll
-                for (int t = 0; t < 3; t++)
+                for (int i = 0; i < 4; i++) c1v[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ind[i], bv[t], zero, 0, 0, 0);
+                v4i r[3];
 #pragma unroll
-                    for (int u = 0; u < 3; u++) {
-                        const v4i r = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2[t], bh[u], c113, 0, 0, 0);
+                for (int u = 0; u < 3; u++) r[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(c1v[u], bh[0], c113, 0, 0, 0);
 #pragma unroll
-                        for (int e = 0; e < 4; e++) med[t][u][e] = imed3(med[t][u][e], r[e], C);
-                    }
+                for (int u = 0; u < 3; u++) r[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(c1v[u + 1], bh[1], r[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 3; u++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) med[t][u][e] = imed3(med[t][u][e], r[u][e], C);
             }
         }
         if (b == 0) break;
@@ -342,18 +363,31 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
     }
 
     // ---- store: planar; lane (n, g) holds rows 16 t + 4 g + e of column 16 u + n
+    uint8_t* plane = out + ((size_t)(f * 3 + c) * h) * pitch;
+    if (ox + MT <= w && oy + MT <= h) {
+        uint8_t* base = plane + (size_t)oy * pitch + ox;
+        const uint32_t voff = (uint32_t)(4 * g * pitch + n);
 #pragma unroll
-    for (int u = 0; u < 3; u++) {
-        const int x = ox + 16 * u + n;
-        if (x < w) {
-            uint8_t* dst = out + ((size_t)(f * 3 + c) * h) * pitch + x;
+        for (int t = 0; t < 3; t++)
 #pragma unroll
-            for (int t = 0; t < 3; t++)
+            for (int e = 0; e < 4; e++) {
+                uint8_t* row = base + (size_t)(16 * t + e) * pitch;
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int y = oy + 16 * t + 4 * g + e;
-                    if (y < h) dst[(size_t)y * pitch] = (uint8_t)med[t][u][e];
-                }
+                for (int u = 0; u < 3; u++) (row + 16 * u)[voff] = (uint8_t)med[t][u][e];
+            }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int x = ox + 16 * u + n;
+            if (x < w) {
+#pragma unroll
+                for (int t = 0; t < 3; t++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int y = oy + 16 * t + 4 * g + e;
+                        if (y < h) plane[(size_t)y * pitch + x] = (uint8_t)med[t][u][e];
+                    }
+            }
         }
     }
 }
