@@ -264,6 +264,12 @@ def main():
             if not t or "valu_wave_insts_per_frame" not in t:
                 return None
             return round(t["valu_wave_insts_per_frame"] * 4.0 / (1024 * 2.4e9 * stages[stage]["us_per_frame"] * 1e-6), 4)
+        def mfma_busy_frac(stage, cycles_per_inst):
+            """share of the kernel time the matrix pipe is busy: MFMA instructions (PMC SQ_INSTS_MFMA) x their pipe cycles"""
+            t = pmc.get(stage)
+            if not t or not t.get("mfma_wave_insts_per_frame"):
+                return None
+            return round(t["mfma_wave_insts_per_frame"] * cycles_per_inst / (1024 * 2.4e9 * stages[stage]["us_per_frame"] * 1e-6), 4)
 
         def roof_of(stage):
             per_launch_frames = prof_steps * F / stages[stage]["launches"]
@@ -286,8 +292,15 @@ def main():
             vf = valu_frac(stage)
             if vf is not None:
                 r["valu_issue_frac"] = vf
-                r["note"] = ("nominally HBM-bound (SURVEY 8d), in fact bound by VALU instruction issue: "
-                             "valu_issue_frac of the SIMDs' issue slots are busy")
+                mf = mfma_busy_frac(stage, 16.0)        # v_mfma_i32_16x16x64_i8: 4 passes of 4 cycles
+                if mf is not None:
+                    r["mfma_busy_frac"] = mf
+                    r["note"] = ("nominally HBM-bound (SURVEY 8d), in fact bound by instruction issue: the box sums run on the i8 "
+                                 "matrix cores (busy mfma_busy_frac of the kernel time), the rest on the vector ALUs (valu_issue_frac of "
+                                 "their issue slots, at the nominal 2.4 GHz); the two add up, a SIMD overlaps them only marginally")
+                else:
+                    r["note"] = ("nominally HBM-bound (SURVEY 8d), in fact bound by VALU instruction issue: "
+                                 "valu_issue_frac of the SIMDs' issue slots are busy")
             return r
         # roofline of the dominant kernel
         dom = max(stages, key=lambda k: stages[k]["ms_total"]) if stages else None

@@ -10,7 +10,11 @@
 //   in its tile (a 256-bit wave-uniform set), so a tile costs (#distinct medians-ish)
 //   box filters instead of 255 -- medians of a 15x15 window vary slowly.
 //
-// Mapping: one wave = one 48x64 output tile of one channel.  64 lanes = 16 (x) x 4 (y);
+// Two kernels evaluate the box sums.  median15_mfma_kernel (further down, the one launched) does them on the
+// i8 matrix cores: 20 us per 1080p frame.  median15_kernel (first below, kept as the all-VALU reference of
+// the same descent; build with -DMED_MFMA=0) does them with SWAR adds and DPP shifts: 38 us.
+//
+// median15_kernel mapping: one wave = one 48x64 output tile of one channel.  64 lanes = 16 (x) x 4 (y);
 // a lane owns 4 adjacent pixels packed in one dword (SWAR, byte lanes) and 16 output rows,
 // so the vertical pass is in-register and the horizontal pass crosses at most 4 lanes of
 // the same 16-lane DPP row.  Lanes 12..15 of each row only supply halo.
@@ -18,7 +22,7 @@
 // HBM traffic: each input byte is read ~(64*78)/(48*64) = 1.6x (L2 absorbs the halo),
 // output written once, planar [n][3][h][pitch] so the next stage reads dwords.
 //
-// The kernel is VALU-issue bound (every instruction below costs one 4-cycle wave64 slot, v_mad_u64_u32
+// The SWAR kernel is VALU-issue bound (every instruction below costs one 4-cycle wave64 slot, v_mad_u64_u32
 // two: tools/micro/valu_rates.hip), so its time is (#box filters per tile) x (376 instructions).
 // Costed against the distinct-prefix counts of real median images (1080p board scenes, ~20.6 box
 // filters per 48x64 tile, lower bound ~12.7 from the distinct medians):
@@ -197,8 +201,19 @@ __global__ __launch_bounds__(64) void median15_kernel(const uint8_t* __restrict_
 // The prefixes alive at the next level are published through 256 flag bytes in LDS (ds_write_b8 with the
 // median as the address: no VALU work) once per level.
 // Tile: 64x64 input pixels (62 used) -> 48x48 medians per wave; 12 + 18 MFMAs and 68 VALU ops per threshold
-// against 376 VALU ops per 48x64 tile in the SWAR kernel above.  Measured rates (tools/micro/mfma_i8.hip): one
-// v_mfma_i32_16x16x64_i8 = 18 cycles of the matrix pipe and ~8 cycles during which the SIMD issues no VALU op.
+// (32 indicator, 36 update) against 376 VALU ops per 48x64 tile in the SWAR kernel above; ~19.6 thresholds per
+// tile on 1080p board scenes.
+// What bounds it (rocprofv3 --pmc, tools/pmc_median.sh; micro-benchmarks tools/micro/mfma_i8.hip, mfma_form.hip):
+// one v_mfma_i32_16x16x64_i8 holds the matrix pipe for 16-18 cycles and keeps the SIMD from issuing VALU ops
+// for ~8.5 of them, whichever register file its operands live in; VALU ops of other waves fill the rest.  Per
+// threshold that is 84 x 4.4 (VALU, with the per-tile overhead) + 30 x 8.5 = ~625 cycles against 30 x 17 = 510
+// of matrix-pipe time: the counters show the matrix pipe 56 % busy, the vector ALUs 63 %, both at once 25 % of
+// the time.  Tried on top, all within noise of each other (19.6 - 20.8 us on one box):
+//   * merging the two column-tile quads of a window into one operand (byte 1 | byte 3, one v_lshl_or per dword)
+//     for 0 / 6 / 7 / 9 of the 9 output tiles: trades 4 VALU ops for 1 MFMA, the same cost either way;
+//   * packing all four column tiles into one 64-column operand (3 v_perm per quad, 9 pass-2 MFMAs): 21.6 us;
+//   * explicit MFMA / VALU interleaving of one wave's instruction stream (sched_group_barrier): no change,
+//     the 4 waves of a SIMD already fill each other's gaps.
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int MT = 48;      // medians per tile edge

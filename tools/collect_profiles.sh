@@ -16,7 +16,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch --
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 1 --warmup 0 --frames 64 --lanes 1 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err
 echo "write done"
-rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/pmc_valu -- python3 bench.py --steps 1 --warmup 0 --frames 64 --lanes 1 --no-cpu-baseline > /dev/null 2> $O/pmc_valu.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc_valu -- python3 bench.py --steps 1 --warmup 0 --frames 64 --lanes 1 --no-cpu-baseline > /dev/null 2> $O/pmc_valu.err
 echo "valu done"
 python bench.py --cnn fp32 > $O/bench_fp32.json 2> $O/bench_fp32.err
 echo "bench fp32 done"
