@@ -11,6 +11,10 @@
 #include "ck_common.h"
 #include "ck_uf.h"
 
+#ifndef NMS_PACKED
+#define NMS_PACKED 1
+#endif
+
 namespace {
 
 constexpr int TW = 64, TH = 16;
@@ -150,6 +154,196 @@ __global__ __launch_bounds__(256) void canny_nms_kernel(const uint8_t* __restric
     for (int i = tid; i < ccount; i += 256) clist[i] = cbuf[i];
 }
 
+// ------------------------------------------------------------------------------------------
+// Packed variant of the kernel above (the one launched; -DNMS_PACKED=0 builds the scalar one).  Same results; the
+// scalar kernel is VALU-bound at ~178 lane-ops per pixel, this one needs about a third of that:
+//   * gradient phase in packed 16-bit math (v_pk_*): a thread owns 4 adjacent columns as two u16 pairs and walks
+//     3 gradient rows down its 5 pixel rows; one v_perm per tap pair widens the bytes, the separable Sobel, the
+//     |dx| + |dy| magnitude and the first-maximum channel choice (mask by saturating subtract, v_bfi) all work on
+//     pairs.  Columns outside the image are replicated when the tile is staged, so no tap is clamped here.
+//   * the sector (two 32-bit fixed-point tangent tests) is computed in the NMS phase, and only by waves that hold a
+//     pixel above the low threshold -- after the median filter most of a frame is flat.
+// Tile: 64 x (15 PK - 2) output pixels per 256-thread workgroup (17 column quads x 15 row segments of PK gradient rows).
+#ifndef NMS_PK
+#define NMS_PK 2
+#endif
+constexpr int PK = NMS_PK;                   // gradient rows per thread
+constexpr int PGR = 15 * PK;                 // gradient rows (1-px halo)
+constexpr int PTH = PGR - 2;                 // output rows per tile
+constexpr int PLH = PTH + 4;                 // pixel rows (2-px halo)
+constexpr int PGW = 68;                      // gradient columns held: x = ox - 2 .. ox + 65
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u16x2 widen(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, sel));
+}
+
+__global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __restrict__ planes, int h, int w, int pitch,
+                                                               int low, int high, uint8_t* __restrict__ map,
+                                                               int32_t* __restrict__ labels, int32_t* __restrict__ cand,
+                                                               int* __restrict__ cand_count)
+{
+    // pixel tile: columns ox-4 .. ox+67 (18 aligned dwords per row), rows oy-2 .. oy+PTH+1, border replicated.
+    // The candidate buffer of the last phase reuses its space.
+    constexpr int PXW = 3 * PLH * LWD, CBUF = PTH * TW;
+    __shared__ uint32_t smem[PXW > CBUF ? PXW : CBUF];
+    uint32_t (*pxw)[PLH][LWD] = reinterpret_cast<uint32_t (*)[PLH][LWD]>(smem);
+    int32_t* cbuf = reinterpret_cast<int32_t*>(smem);
+    __shared__ __attribute__((aligned(8))) uint16_t mag[PGR][PGW];
+    __shared__ __attribute__((aligned(8))) int16_t gdx[PGR][PGW], gdy[PGR][PGW];
+    __shared__ int ccount, cbase;
+    const int f = blockIdx.z;
+    const int ox = blockIdx.x * TW, oy = blockIdx.y * PTH;
+    const int tid = threadIdx.x;
+    const uint8_t* base = planes + (size_t)f * 3 * h * pitch;
+    if (tid == 0) ccount = 0;
+
+    const uint32_t plane = (uint32_t)h * pitch;
+    for (int i = tid; i < PLH * LWD; i += 256) {
+        const int r = i / LWD, cd = i % LWD;
+        int y = oy - 2 + r;
+        y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+        const int x = ox - 4 + 4 * cd;                 // pitch is a multiple of 64 and ox of 64: aligned
+        const uint8_t* row = base + (uint32_t)(y * pitch);
+        if (x >= 0 && x + 3 < w) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) pxw[c][r][cd] = *reinterpret_cast<const uint32_t*>(row + c * plane + x);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int xc = x + k;
+                    xc = xc < 0 ? 0 : (xc > w - 1 ? w - 1 : xc);
+                    v |= (uint32_t)row[c * plane + xc] << (8 * k);
+                }
+                pxw[c][r][cd] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    if (tid < 17 * 15) {
+        const int cj = tid % 17, seg = tid / 17;
+        // this thread's gradient columns: array index 4 cj + i  <->  x = ox - 2 + 4 cj + i
+        const int x0 = ox - 2 + 4 * cj;
+        u16x2 xmP, xmQ;                                // 0xFFFF where the column lies inside the image
+        xmP[0] = (x0 >= 0 && x0 < w) ? 0xFFFF : 0;
+        xmP[1] = (x0 + 1 >= 0 && x0 + 1 < w) ? 0xFFFF : 0;
+        xmQ[0] = (x0 + 2 >= 0 && x0 + 2 < w) ? 0xFFFF : 0;
+        xmQ[1] = (x0 + 3 >= 0 && x0 + 3 < w) ? 0xFFFF : 0;
+        s16x2 hdP[3][3], hdQ[3][3];                    // [row slot][channel]
+        u16x2 hsP[3][3], hsQ[3][3];
+#pragma unroll
+        for (int k = 0; k < PK + 2; k++) {
+            const int pr = seg * PK + k;               // pixel-tile row
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const uint32_t A = pxw[c][pr][cj], B = pxw[c][pr][cj + 1];
+                const u16x2 p12 = widen(B, A, 0x0c020c01u), p23 = widen(B, A, 0x0c030c02u), p34 = widen(B, A, 0x0c040c03u),
+                            p45 = widen(B, A, 0x0c050c04u), p56 = widen(B, A, 0x0c060c05u);
+                hdP[k % 3][c] = __builtin_bit_cast(s16x2, (u16x2)(p34 - p12));
+                hsP[k % 3][c] = p23 * (unsigned short)2 + p12 + p34;
+                hdQ[k % 3][c] = __builtin_bit_cast(s16x2, (u16x2)(p56 - p34));
+                hsQ[k % 3][c] = p45 * (unsigned short)2 + p34 + p56;
+            }
+            if (k >= 2) {
+                const int gr = seg * PK + k - 2;       // gradient row  <->  y = oy - 1 + gr
+                const int y = oy - 1 + gr;
+                const unsigned short ym = (y >= 0 && y < h) ? 0xFFFF : 0;
+                auto grad = [&](const s16x2 (&hd)[3][3], const u16x2 (&hs)[3][3], u16x2 xm, u16x2& best, s16x2& bdx, s16x2& bdy) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const s16x2 dx = hd[(k - 2) % 3][c] + hd[(k - 1) % 3][c] * (short)2 + hd[k % 3][c];
+                        const s16x2 dy = __builtin_bit_cast(s16x2, (u16x2)(hs[k % 3][c] - hs[(k - 2) % 3][c]));
+                        const u16x2 m = __builtin_bit_cast(u16x2, (s16x2)(__builtin_elementwise_max(dx, -dx) + __builtin_elementwise_max(dy, -dy)));
+                        if (c == 0) { best = m; bdx = dx; bdy = dy; }
+                        else {
+                            // strictly greater takes over (the first maximum wins, as in the scalar loop)
+                            const s16x2 gt = (__builtin_bit_cast(s16x2, best) - __builtin_bit_cast(s16x2, m)) >> (short)15;   // magnitudes < 2^15
+                            const uint32_t g = __builtin_bit_cast(uint32_t, gt);
+                            best = __builtin_elementwise_max(best, m);
+                            bdx = __builtin_bit_cast(s16x2, (__builtin_bit_cast(uint32_t, dx) & g) | (__builtin_bit_cast(uint32_t, bdx) & ~g));
+                            bdy = __builtin_bit_cast(s16x2, (__builtin_bit_cast(uint32_t, dy) & g) | (__builtin_bit_cast(uint32_t, bdy) & ~g));
+                        }
+                    }
+                    best = best & xm & ym;             // outside the image the magnitude is 0
+                };
+                u16x2 bP, bQ;
+                s16x2 dxP, dyP, dxQ, dyQ;
+                grad(hdP, hsP, xmP, bP, dxP, dyP);
+                grad(hdQ, hsQ, xmQ, bQ, dxQ, dyQ);
+                *reinterpret_cast<uint2*>(&mag[gr][4 * cj]) = make_uint2(__builtin_bit_cast(uint32_t, bP), __builtin_bit_cast(uint32_t, bQ));
+                *reinterpret_cast<uint2*>(&gdx[gr][4 * cj]) = make_uint2(__builtin_bit_cast(uint32_t, dxP), __builtin_bit_cast(uint32_t, dxQ));
+                *reinterpret_cast<uint2*>(&gdy[gr][4 * cj]) = make_uint2(__builtin_bit_cast(uint32_t, dyP), __builtin_bit_cast(uint32_t, dyQ));
+            }
+        }
+    }
+    __syncthreads();
+
+    // NMS: one thread = 4 consecutive pixels of one row (one dword of the map)
+    const int TG22 = 13573;   // (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
+    const uint16_t* magf = &mag[0][0];
+    for (int q = tid; q < PTH * 16; q += 256) {
+        const int r = q >> 4, col0 = (q & 15) * 4;
+        const int y = oy + r;
+        uint32_t mapw = 0x01010101u;
+        int keepmask = 0;
+        if (y < h) {
+            const int i0 = (r + 1) * PGW + col0 + 2;   // output pixel (r, col)  <->  gradient (r + 1, array column col + 2)
+            const uint32_t m01 = *reinterpret_cast<const uint32_t*>(magf + i0), m23 = *reinterpret_cast<const uint32_t*>(magf + i0 + 2);
+            const int mk[4] = {(int)(m01 & 0xFFFF), (int)(m01 >> 16), (int)(m23 & 0xFFFF), (int)(m23 >> 16)};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int m = mk[k];
+                const bool candp = m > low && ox + col0 + k < w;
+                if (__builtin_amdgcn_ballot_w64(candp) == 0) continue;      // whole wave flat here
+                if (candp) {
+                    const int i = i0 + k;
+                    const int bdx = (&gdx[0][0])[i], bdy = (&gdy[0][0])[i];
+                    const int ax = abs(bdx), ay = abs(bdy) << 15;
+                    const int tg22x = ax * TG22;
+                    int o, m2 = m;
+                    if (ay < tg22x) { o = 1; m2 = m + 1; }                             // sector 0: left, right (>=)
+                    else if (ay > tg22x + (ax << 16)) { o = PGW; m2 = m + 1; }         // sector 1: up, down (>=)
+                    else o = ((bdx ^ bdy) < 0) ? PGW - 1 : PGW + 1;                    // diagonals
+                    if (m > magf[i - o] && m2 > magf[i + o]) {
+                        const uint32_t v = m > high ? 2u : 0u;
+                        mapw = (mapw & ~(0xFFu << (8 * k))) | (v << (8 * k));
+                        keepmask |= 1 << k;
+                    }
+                }
+            }
+            const int x0 = ox + col0;
+            const size_t idx = ((size_t)f * h + y) * w + x0;
+            if (x0 + 3 < w && ((idx & 3) == 0)) *reinterpret_cast<uint32_t*>(map + idx) = mapw;
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (x0 + k < w) map[idx + k] = (uint8_t)(mapw >> (8 * k));
+            }
+        }
+        const int nk = __builtin_popcount(keepmask);
+        if (nk) {
+            int slot = atomicAdd(&ccount, nk);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (keepmask & (1 << k)) {
+                    const int p = y * w + ox + col0 + k;
+                    labels[(size_t)f * h * w + p] = p;
+                    cbuf[slot++] = p;
+                }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) cbase = ccount ? atomicAdd(cand_count + f, ccount) : 0;
+    __syncthreads();
+    int32_t* clist = cand + (size_t)f * h * w + cbase;
+    for (int i = tid; i < ccount; i += 256) clist[i] = cbuf[i];
+}
+
 // The three hysteresis kernels walk the per-frame candidate list (a few % of the pixels)
 // with a fixed grid and a grid-stride loop; the count is read from device memory.
 constexpr int LIST_BLOCKS = 64;
@@ -231,9 +425,15 @@ int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, in
     {
         TimeScope ts(ctx, "canny_nms");
         CK_HIP(ctx, hipMemsetAsync(d_count, 0, (size_t)n * 4, ctx->stream));
+#if NMS_PACKED
+        dim3 grid((w + TW - 1) / TW, (h + PTH - 1) / PTH, n);
+        hipLaunchKernelGGL(canny_nms_packed_kernel, grid, dim3(256), 0, ctx->stream, d_planes, h, w, pitch, low, high, d_map,
+                           d_labels, d_cand, d_count);
+#else
         dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, n);
         hipLaunchKernelGGL(canny_nms_kernel, grid, dim3(256), 0, ctx->stream, d_planes, h, w, pitch, low, high, d_map,
                            d_labels, d_cand, d_count);
+#endif
         CK_HIP(ctx, hipGetLastError());
     }
     if (d_map_out) CK_HIP(ctx, hipMemcpyAsync(d_map_out, d_map, npx, hipMemcpyDeviceToDevice, ctx->stream));
