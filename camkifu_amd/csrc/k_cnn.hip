@@ -38,6 +38,18 @@
 #ifndef H2_STAGE_UNROLL
 #define H2_STAGE_UNROLL 8
 #endif
+#ifndef H2C2_SWZ
+#define H2C2_SWZ 1      // conv2: swizzled LDS tile, 24 pixel tiles per block (3 per wave); 0 = padded tile, 16 per block
+#endif
+#ifndef H2C2S_PF
+#define H2C2S_PF 1      // 3 x 2 accumulator tiles leave room for a 2-slot weight ring only (PF 2: 141 VGPRs, 3 waves per SIMD, 17.3 us)
+#endif
+#ifndef H2C2S_SB
+#define H2C2S_SB true
+#endif
+#ifndef H2_EXP
+#define H2_EXP 0      // timing experiments only (1: weight fragments loaded once, 2: activation fragments read once)
+#endif
 #ifndef H2C3_PF
 #define H2C3_PF 2
 #endif
@@ -253,6 +265,7 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
             }
         }
     };
+    if (tile0 >= RT) return;                   // the last block of a patch may hold fewer tiles than waves x R
     if (nv == R) k_loop(std::integral_constant<int, R>{});
     else if constexpr (R * WAVES_M > TB) k_loop(std::integral_constant<int, R - 1>{});
 
@@ -567,7 +580,7 @@ __device__ __forceinline__ void split_h2(float x, _Float16& hi, _Float16& lo)
     lo = (_Float16)(x - (float)hi);
 }
 
-template <int H, int W, int CIN, int KH, int KW, int COUT, int TB, int YB, int WAVES_M, int RN, bool POOL, int PF, bool SB>
+template <int H, int W, int CIN, int KH, int KW, int COUT, int TB, int YB, int WAVES_M, int RN, bool POOL, int PF, bool SB, bool SWZ = false>
 __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfma16_h2_kernel(
     const float* __restrict__ in, const uint16_t* __restrict__ wt, const float* __restrict__ bias,
     float* __restrict__ out, float wscale_inv, int* __restrict__ overflow)
@@ -576,8 +589,13 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
     constexpr int OH = H - KH + 1, OW = W - KW + 1, M = OH * OW;
     constexpr int NT = cdiv(COUT, 16), WAVES_N = NT / RN;
     constexpr int CINP = cdiv(CIN, 32) * 32;
-    constexpr int PS = 2 * CINP + 8;                               // halves per pixel
-    constexpr int RS = lds_stride_b(W * PS, POOL ? 32 : (8 * OW) % 64, 64);     // halves per row
+    // SWZ: no padding -- a pixel is exactly its 8 chunks of 16 bytes (hi 0..3, lo 4..7) and chunk c of pixel x sits in
+    // slot c ^ ((x >> 1) & 7); rows are 32 bytes apart modulo 256.  A fragment read (16 pixels x one chunk: 16 adjacent
+    // pixels of a row, or the 4x4 block of a pooling tile) then covers all 16 slots of the 64 banks, and a 16-row tile of
+    // conv2 takes 73 KB instead of 83: two workgroups with 3 pixel tiles per wave fit a CU.
+    static_assert(!SWZ || (CINP == 32 && POOL), "swizzled layout: 32 channels, pooling tiles");
+    constexpr int PS = SWZ ? 2 * CINP : 2 * CINP + 8;              // halves per pixel
+    constexpr int RS = SWZ ? W * PS + 16 : lds_stride_b(W * PS, POOL ? 32 : (8 * OW) % 64, 64);     // halves per row
     constexpr int KS = KH * KW * (CINP / 32);
     constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
     constexpr int R = cdiv(TB, WAVES_M);
@@ -610,10 +628,17 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
             _Float16 h0, l0, h1, l1;
             split_h2(v.x, h0, l0);
             split_h2(v.y, h1, l1);
-            _Float16* d = &lds[(pxl / W) * RS + (pxl % W) * PS + 2 * c];
             typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<h2v*>(d) = h2v{h0, h1};
-            *reinterpret_cast<h2v*>(d + CINP) = h2v{l0, l1};
+            if constexpr (SWZ) {
+                const int x = pxl % W, sw = (x >> 1) & 7;
+                _Float16* d = &lds[(pxl / W) * RS + x * PS + (2 * c & 7)];
+                *reinterpret_cast<h2v*>(d + (((c >> 2) ^ sw) << 3)) = h2v{h0, h1};
+                *reinterpret_cast<h2v*>(d + (((c >> 2) ^ sw ^ 4) << 3)) = h2v{l0, l1};
+            } else {
+                _Float16* d = &lds[(pxl / W) * RS + (pxl % W) * PS + 2 * c];
+                *reinterpret_cast<h2v*>(d) = h2v{h0, h1};
+                *reinterpret_cast<h2v*>(d + CINP) = h2v{l0, l1};
+            }
         }
         if (overflow && !(big <= 65000.f)) *overflow = 1;       // also true for NaN
         if constexpr (CINP > CIN)
@@ -627,7 +652,7 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
     __syncthreads();
 
     const int tile0 = tile_blk + wm * R;
-    int abase[R];
+    int abase[R], axr[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         int t = tile0 + r;
@@ -642,7 +667,8 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
             if (m > M - 1) m = M - 1;
             oy = m / OW; ox = m % OW;
         }
-        abase[r] = (oy - oy_min) * RS + ox * PS + 8 * kq;
+        abase[r] = SWZ ? (oy - oy_min) * RS + ox * PS : (oy - oy_min) * RS + ox * PS + 8 * kq;
+        axr[r] = ox;
     }
     f32x4 acc[R][RN];
 #pragma unroll
@@ -666,6 +692,59 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
         // A fragment of a step live and the occupancy collapses.
         constexpr int NS = PF + 1;
         uint4 bq[NS][RN][2];
+        if constexpr (SWZ) {
+            // column tap outermost: the swizzle depends on x = ox + j only, so the two fragment addresses of a pixel
+            // tile are computed once per tap column and the KH rows are immediate offsets.  The weight fragments stay in
+            // (i, j) order in memory; seq = j * KH + i is the order they are used in.
+            auto step_of = [](int seq) { return (seq % KH) * KW + seq / KH; };
+#pragma unroll
+            for (int u = 0; u < PF; u++)
+#pragma unroll
+                for (int n = 0; n < RN; n++)
+#pragma unroll
+                    for (int pl = 0; pl < 2; pl++) bq[u][n][pl] = wq[((size_t)n * KS + step_of(u)) * 128 + pl * 64];
+#pragma unroll
+            for (int j = 0; j < KW; j++) {
+                int ahj[NV > 0 ? NV : 1], alj[NV > 0 ? NV : 1];
+#pragma unroll
+                for (int r = 0; r < NV; r++) {
+                    const int ch = kq ^ (((axr[r] + j) >> 1) & 7);
+                    ahj[r] = abase[r] + j * PS + (ch << 3);
+                    alj[r] = abase[r] + j * PS + ((ch ^ 4) << 3);
+                }
+#pragma unroll
+                for (int i = 0; i < KH; i++) {
+                    const int seq = j * KH + i;
+                    if (seq + PF < KS) {
+#pragma unroll
+                        for (int n = 0; n < RN; n++) {
+                            bq[(seq + PF) % NS][n][0] = wq[((size_t)n * KS + step_of(seq + PF)) * 128];
+                            bq[(seq + PF) % NS][n][1] = wq[((size_t)n * KS + step_of(seq + PF)) * 128 + 64];
+                        }
+                    }
+                    if constexpr (SB) __builtin_amdgcn_sched_barrier(0);
+                    h8 bh[RN], bl[RN];
+#pragma unroll
+                    for (int n = 0; n < RN; n++) {
+                        bh[n] = __builtin_bit_cast(h8, bq[seq % NS][n][0]);
+                        bl[n] = __builtin_bit_cast(h8, bq[seq % NS][n][1]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < NV; r++) {
+                        const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&lds[ahj[r] + i * RS]));
+                        const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&lds[alj[r] + i * RS]));
+#pragma unroll
+                        for (int n = 0; n < RN; n++) {
+                            acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[n], acc[r][n], 0, 0, 0);
+                            acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[n], acc[r][n], 0, 0, 0);
+                            acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[n], acc[r][n], 0, 0, 0);
+                        }
+                    }
+                    if constexpr (SB) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < PF; u++)
 #pragma unroll
@@ -680,7 +759,7 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
 #pragma unroll
                 for (int cc = 0; cc < CINP / 32; cc++) {
                     const int step = (i * KW + j) * (CINP / 32) + cc;
-                    if (step + PF < KS) {
+                    if (step + PF < KS && (H2_EXP != 1 || step == 0)) {
 #pragma unroll
                         for (int n = 0; n < RN; n++) {
                             bq[(step + PF) % NS][n][0] = wq[((size_t)n * KS + step + PF) * 128];
@@ -696,7 +775,7 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
                     }
 #pragma unroll
                     for (int r = 0; r < NV; r++) {
-                        const _Float16* ap = &lds[abase[r] + i * RS + j * PS + 32 * cc];
+                        const _Float16* ap = &lds[abase[r] + (H2_EXP == 2 ? 0 : i * RS + j * PS + 32 * cc)];
                         const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(ap));
                         const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(ap + CINP));
 #pragma unroll
@@ -1265,7 +1344,11 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             // 32 rows: 4 groups of (4 waves x 2 rows), pooled output 16x16x32
             // 8x8 pooling tiles of 4x4 pixels: workgroups of whole tile rows, pooled output 16x16x32
             if (h2)
+#if H2C2_SWZ
+                hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, 24, 3, 8, 2, true, H2C2S_PF, H2C2S_SB, true>), dim3(np, 3), dim3(512), 0, ctx->stream,
+#else
                 hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, H2C2_TB, 64 / H2C2_TB, H2C2_WM, 2, true, H2C2_PF, true>), dim3(np, 64 / H2C2_TB), dim3(64 * H2C2_WM), 0, ctx->stream,
+#endif
                                    (const float*)a1, (const uint16_t*)W.c2w_h2.p, (const float*)W.c2b.p, p2, 1.f / H2_WSCALE, d_nonfinite);
             else
             hipLaunchKernelGGL((conv_mfma16_f32_kernel<36, 36, 32, 5, 5, 32, C2_TB, 64 / C2_TB, C2_WM, C2_RN, true>), dim3(np, 64 / C2_TB),
