@@ -41,6 +41,9 @@
 #ifndef H2C2_SWZ
 #define H2C2_SWZ 1      // conv2: swizzled LDS tile, 24 pixel tiles per block (3 per wave); 0 = padded tile, 16 per block
 #endif
+#ifndef H2_FUSE1
+#define H2_FUSE1 1       // conv1 computed inside conv2 (needs H2C2_SWZ)
+#endif
 #ifndef H2C2S_PF
 #define H2C2S_PF 1      // 3 x 2 accumulator tiles leave room for a 2-slot weight ring only (PF 2: 141 VGPRs, 3 waves per SIMD, 17.3 us)
 #endif
@@ -580,10 +583,12 @@ __device__ __forceinline__ void split_h2(float x, _Float16& hi, _Float16& lo)
     lo = (_Float16)(x - (float)hi);
 }
 
-template <int H, int W, int CIN, int KH, int KW, int COUT, int TB, int YB, int WAVES_M, int RN, bool POOL, int PF, bool SB, bool SWZ = false>
+template <int H, int W, int CIN, int KH, int KW, int COUT, int TB, int YB, int WAVES_M, int RN, bool POOL, int PF, bool SB, bool SWZ = false,
+          bool FUSE1 = false>
 __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfma16_h2_kernel(
     const float* __restrict__ in, const uint16_t* __restrict__ wt, const float* __restrict__ bias,
-    float* __restrict__ out, float wscale_inv, int* __restrict__ overflow)
+    float* __restrict__ out, float wscale_inv, int* __restrict__ overflow,
+    const uint8_t* __restrict__ goban1 = nullptr, const uint16_t* __restrict__ wf1 = nullptr, const float* __restrict__ bias1 = nullptr)
 {
 #pragma clang fp contract(off)
     constexpr int OH = H - KH + 1, OW = W - KW + 1, M = OH * OW;
@@ -615,7 +620,94 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
     const int oy_min = POOL ? 4 * (tile_blk / (OW / 4)) : (tile_blk * 16) / OW;
     int row_cnt = H - oy_min;
     if (row_cnt > ROWS) row_cnt = ROWS;
-    {
+    if constexpr (FUSE1) {
+        // conv1 (5x5x3 -> 32, relu) of the 40x40 u8 patch computed HERE for the rows this block needs: its output goes
+        // straight into the swizzled tile as hi/lo halves and never exists in HBM.  Same arithmetic as conv1_h2_kernel
+        // (K = 6 kernel rows x 16 slots in three k-steps, weights as the A operand, two MFMAs per product), so the
+        // values are bit-identical to the unfused pair of kernels; a block recomputes the 4 halo rows it shares with
+        // its neighbour (+33 % of a layer that is 6 % of the network).
+        static_assert(SWZ && W == 36 && CIN == 32 && KH == 5, "conv1 fusion is wired for conv2");
+        constexpr int IRS = 128;                              // halves per staged input row: 120 used, 8 zero
+        constexpr int IROWS = ROWS + 4;
+        __shared__ __attribute__((aligned(16))) _Float16 in1[(IROWS + 1) * IRS];   // + one zero row under kernel row 5
+        const int frame = patch / 100, reg = patch % 100;
+        const int py0 = region_origin(reg / 10) + oy_min, px0 = region_origin(reg % 10);
+        const int rows_in = row_cnt + 4;
+        const uint8_t* src = goban1 + ((size_t)frame * 380 + py0) * 380 * 3 + (size_t)px0 * 3;
+        for (int d = tid; d < IROWS * 32 + IRS / 4; d += NTHREADS) {
+            const int r = d >> 5, cd = d & 31;                // 30 dwords of pixels + 2 of padding per row; then the zero row
+            uint32_t raw = 0u;
+            if (r < rows_in && cd < 30) raw = reinterpret_cast<const uint32_t*>(src + (size_t)r * 380 * 3)[cd];
+            typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<h4v*>(&in1[4 * d]) = h4v{(_Float16)(float)(raw & 0xFFu), (_Float16)(float)((raw >> 8) & 0xFFu),
+                                                       (_Float16)(float)((raw >> 16) & 0xFFu), (_Float16)(float)(raw >> 24)};
+        }
+        h8 w1[3][2][2];
+#pragma unroll
+        for (int sx = 0; sx < 3; sx++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++)
+                    w1[sx][n][pl] = __builtin_bit_cast(h8, reinterpret_cast<const uint4*>(wf1)[((n * 3 + sx) * 2 + pl) * 64 + lane]);
+        float4 bv1[2];
+#pragma unroll
+        for (int n = 0; n < 2; n++) bv1[n] = *reinterpret_cast<const float4*>(bias1 + n * 16 + 4 * kq);
+        __syncthreads();
+        const int ntile1 = row_cnt * W / 16;                 // 36 or 27 tiles of 16 conv1 pixels
+        constexpr int NW = NTHREADS / 64, R1 = cdiv(ROWS * W / 16, NW);
+        float big = 0.f;
+#pragma unroll
+        for (int r = 0; r < R1; r++) {
+            const int tile = wave + NW * r;
+            if (tile < ntile1) {
+                const int m = tile * 16 + l15, my = m / W, mx = m % W;
+                const int a0 = (my + (kq >> 1)) * IRS + mx * 3 + 8 * (kq & 1);
+                const uint32_t ash = (uint32_t)(a0 & 1) << 4;
+                f32x4 c1[2];
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) c1[n][e] = 0.f;
+#pragma unroll
+                for (int sx = 0; sx < 3; sx++) {
+                    // 8 halves from an odd or even half offset: five aligned dwords, funnel-shifted by 0 or 16 bits
+                    const uint32_t* aq = reinterpret_cast<const uint32_t*>(&in1[(a0 & ~1) + 2 * sx * IRS]);
+                    const uint32_t d0 = aq[0], d1 = aq[1], d2 = aq[2], d3 = aq[3], d4 = aq[4];
+                    const uint4 au = make_uint4(__builtin_amdgcn_alignbit(d1, d0, ash), __builtin_amdgcn_alignbit(d2, d1, ash),
+                                                __builtin_amdgcn_alignbit(d3, d2, ash), __builtin_amdgcn_alignbit(d4, d3, ash));
+                    const h8 a = __builtin_bit_cast(h8, au);
+#pragma unroll
+                    for (int n = 0; n < 2; n++) {
+                        c1[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[sx][n][1], a, c1[n], 0, 0, 0);
+                        c1[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[sx][n][0], a, c1[n], 0, 0, 0);
+                    }
+                }
+                // lane (pixel l15, kq) holds channels 16 n + 4 kq .. + 3: half a chunk of the pixel
+                const int sw = (mx >> 1) & 7;
+                _Float16* px = &lds[my * RS + mx * PS + 4 * (kq & 1)];
+#pragma unroll
+                for (int n = 0; n < 2; n++) {
+                    float v[4] = {c1[n][0] * wscale_inv + bv1[n].x, c1[n][1] * wscale_inv + bv1[n].y,
+                                  c1[n][2] * wscale_inv + bv1[n].z, c1[n][3] * wscale_inv + bv1[n].w};
+                    typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+                    h4v hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        big = fmaxf(big, v[e]);
+                        _Float16 hh, ll;
+                        split_h2(v[e], hh, ll);
+                        hi[e] = hh; lo[e] = ll;
+                    }
+                    const int c = 2 * n + (kq >> 1);
+                    *reinterpret_cast<h4v*>(px + ((c ^ sw) << 3)) = hi;
+                    *reinterpret_cast<h4v*>(px + ((c ^ sw ^ 4) << 3)) = lo;
+                }
+            }
+        }
+        if (overflow && !(big <= 65000.f)) *overflow = 1;
+    } else {
         const float2* g = reinterpret_cast<const float2*>(in + ((size_t)patch * H + oy_min) * W * CIN);
         float big = 0.f;
 #pragma unroll H2_STAGE_UNROLL
@@ -1332,7 +1424,9 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         float* p4 = p4_all + (size_t)f0 * 100 * 3240;
         {
             TimeScope ts(ctx, "cnn_conv1");
-            if (h2)
+            if (h2 && H2C2_SWZ && H2_FUSE1) {
+                // conv1 is computed inside conv2's staging (below)
+            } else if (h2)
                 hipLaunchKernelGGL((conv1_h2_kernel<C1_R>), dim3(std::min(np * 3, C1_GRID)), dim3(64 * (27 / C1_R)), 0, ctx->stream, gob,
                                    (const uint16_t*)W.c1w_h2.p, (const float*)W.c1b.p, a1, np * 3, 1.f / H2_WSCALE);
             else
@@ -1343,13 +1437,16 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             TimeScope ts(ctx, "cnn_conv2");
             // 32 rows: 4 groups of (4 waves x 2 rows), pooled output 16x16x32
             // 8x8 pooling tiles of 4x4 pixels: workgroups of whole tile rows, pooled output 16x16x32
-            if (h2)
+            if (h2) {
 #if H2C2_SWZ
-                hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, 24, 3, 8, 2, true, H2C2S_PF, H2C2S_SB, true>), dim3(np, 3), dim3(512), 0, ctx->stream,
+                hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, 24, 3, 8, 2, true, H2C2S_PF, H2C2S_SB, true, H2_FUSE1 != 0>), dim3(np, 3), dim3(512), 0, ctx->stream,
+                                   (const float*)a1, (const uint16_t*)W.c2w_h2.p, (const float*)W.c2b.p, p2, 1.f / H2_WSCALE, d_nonfinite,
+                                   gob, (const uint16_t*)W.c1w_h2.p, (const float*)W.c1b.p);
 #else
                 hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, H2C2_TB, 64 / H2C2_TB, H2C2_WM, 2, true, H2C2_PF, true>), dim3(np, 64 / H2C2_TB), dim3(64 * H2C2_WM), 0, ctx->stream,
-#endif
                                    (const float*)a1, (const uint16_t*)W.c2w_h2.p, (const float*)W.c2b.p, p2, 1.f / H2_WSCALE, d_nonfinite);
+#endif
+            }
             else
             hipLaunchKernelGGL((conv_mfma16_f32_kernel<36, 36, 32, 5, 5, 32, C2_TB, 64 / C2_TB, C2_WM, C2_RN, true>), dim3(np, 64 / C2_TB),
                                dim3(64 * C2_WM * (2 / C2_RN)), 0, ctx->stream, (const float*)a1, (const float*)W.c2w.p,
