@@ -275,6 +275,7 @@ def main():
         fused_conv1 = args.cnn == "f16x2" and "cnn_conv1" in stages and stages["cnn_conv1"]["us_per_frame"] < 0.5
         if fused_conv1:
             del stages["cnn_conv1"]
+        fused_conv34 = args.cnn == "f16x2" and "cnn_conv4" in stages and "cnn_conv3" not in stages
 
         def roof_of(stage):
             per_launch_frames = prof_steps * F / stages[stage]["launches"]
@@ -291,6 +292,9 @@ def main():
                 if fused_conv1 and stage == "cnn_conv2":
                     macs += 2.0 * MACS["cnn_conv1"]          # conv1 runs inside this kernel (two fp16 MFMAs per product)
                     r_note = "conv1 is computed inside this kernel's staging; its algorithmic flops are included, the halo rows recomputed per block are not"
+                if fused_conv34 and stage == "cnn_conv4":
+                    macs += mults * MACS["cnn_conv3"]        # conv3 + conv4 of a patch run in one workgroup
+                    r_note = "conv3 and conv4 in one kernel (conv3's output stays in LDS); flops of both"
                 ach = 2.0 * macs * per_launch_frames / avg_s / 1e12
                 r = dict(kernel=stage, bound="mfma", achieved=round(ach, 3), peak=peak, unit="TFLOP/s",
                          frac=round(ach / peak, 5), traffic=traffic_of(stage, per_launch_frames))

@@ -41,6 +41,9 @@
 #ifndef H2C2_SWZ
 #define H2C2_SWZ 1      // conv2: swizzled LDS tile, 24 pixel tiles per block (3 per wave); 0 = padded tile, 16 per block
 #endif
+#ifndef H2_FUSE34
+#define H2_FUSE34 1      // conv3 and conv4 in one workgroup, conv3's output stays in LDS
+#endif
 #ifndef H2_FUSE1
 #define H2_FUSE1 1       // conv1 computed inside conv2 (needs H2C2_SWZ)
 #endif
@@ -268,7 +271,6 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
             }
         }
     };
-    if (tile0 >= RT) return;                   // the last block of a patch may hold fewer tiles than waves x R
     if (nv == R) k_loop(std::integral_constant<int, R>{});
     else if constexpr (R * WAVES_M > TB) k_loop(std::integral_constant<int, R - 1>{});
 
@@ -583,9 +585,28 @@ __device__ __forceinline__ void split_h2(float x, _Float16& hi, _Float16& lo)
     lo = (_Float16)(x - (float)hi);
 }
 
+// halves of LDS one block's input tile takes (same formulas as in the body)
+template <int H, int W, int CIN, int KH, int KW, int TB, bool POOL, bool SWZ>
+constexpr int h2_tile_halves()
+{
+    constexpr int OW = W - KW + 1, M = (H - KH + 1) * OW, CINP = cdiv(CIN, 32) * 32;
+    constexpr int PS = SWZ ? 2 * CINP : 2 * CINP + 8;
+    constexpr int RS = SWZ ? W * PS + 16 : lds_stride_b(W * PS, POOL ? 32 : (8 * OW) % 64, 64);
+    constexpr int ROWS_RAW = POOL ? 4 * (TB / (OW / 4)) + KH - 1 : (TB * 16 + OW - 2) / OW + 1 + KH - 1;
+    (void)M;
+    return (ROWS_RAW < H ? ROWS_RAW : H) * RS;
+}
+
+// The layer itself, as a device function over a caller-owned LDS tile so that two layers can share one workgroup:
+//   IN_LDS  : the input tile is already in `lds` (written by the previous layer's call), nothing is staged;
+//   NXT_W>0 : the output (relu, not pooled) is not written to `out` but split into hi/lo halves straight into `lds`
+//             in the NEXT layer's tile layout (NXT_W pixels per row, NXT_PS halves per pixel, NXT_RS per row,
+//             NXT_CINP channels per plane, channels COUT..NXT_CINP-1 zeroed) -- after a barrier, because that tile
+//             overlays this layer's input.
 template <int H, int W, int CIN, int KH, int KW, int COUT, int TB, int YB, int WAVES_M, int RN, bool POOL, int PF, bool SB, bool SWZ = false,
-          bool FUSE1 = false>
-__global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfma16_h2_kernel(
+          bool FUSE1 = false, bool IN_LDS = false, int NXT_W = 0, int NXT_PS = 0, int NXT_RS = 0, int NXT_CINP = 0>
+__device__ __forceinline__ void conv_h2_body(
+    _Float16* __restrict__ lds, const int patch, const int blk_y,
     const float* __restrict__ in, const uint16_t* __restrict__ wt, const float* __restrict__ bias,
     float* __restrict__ out, float wscale_inv, int* __restrict__ overflow,
     const uint8_t* __restrict__ goban1 = nullptr, const uint16_t* __restrict__ wf1 = nullptr, const float* __restrict__ bias1 = nullptr)
@@ -610,13 +631,12 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
     static_assert(CIN % 2 == 0, "channel pairs");
     constexpr int ROWS_RAW = POOL ? 4 * (TB / (OW / 4)) + KH - 1 : (TB * 16 + OW - 2) / OW + 1 + KH - 1;
     constexpr int ROWS = ROWS_RAW < H ? ROWS_RAW : H;
-    __shared__ __attribute__((aligned(16))) _Float16 lds[ROWS * RS];
+    static_assert(ROWS * RS == h2_tile_halves<H, W, CIN, KH, KW, TB, POOL, SWZ>(), "tile size helper out of step");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WAVES_N, wm = wave / WAVES_N;
     const int l15 = lane & 15, kq = lane >> 4;
-    const int patch = blockIdx.x;
-    const int tile_blk = blockIdx.y * TB;
+    const int tile_blk = blk_y * TB;
     const int oy_min = POOL ? 4 * (tile_blk / (OW / 4)) : (tile_blk * 16) / OW;
     int row_cnt = H - oy_min;
     if (row_cnt > ROWS) row_cnt = ROWS;
@@ -707,7 +727,7 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
             }
         }
         if (overflow && !(big <= 65000.f)) *overflow = 1;
-    } else {
+    } else if constexpr (!IN_LDS) {
         const float2* g = reinterpret_cast<const float2*>(in + ((size_t)patch * H + oy_min) * W * CIN);
         float big = 0.f;
 #pragma unroll H2_STAGE_UNROLL
@@ -741,7 +761,7 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
                 d[CINP] = (_Float16)0.f;
             }
     }
-    __syncthreads();
+    if constexpr (!IN_LDS) __syncthreads();
 
     const int tile0 = tile_blk + wm * R;
     int abase[R], axr[R];
@@ -882,8 +902,15 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
             }
         }
     };
-    if (nv == R) k_loop(std::integral_constant<int, R>{});
-    else if constexpr (R * WAVES_M > TB) k_loop(std::integral_constant<int, R - 1>{});
+    const bool idle = tile0 >= RT;             // the last block of a patch may hold fewer tiles than waves x R
+    if (!idle) {
+        if (nv == R) k_loop(std::integral_constant<int, R>{});
+        else if constexpr (R * WAVES_M > TB) k_loop(std::integral_constant<int, R - 1>{});
+    }
+
+    float nxt_big = 0.f;
+    if constexpr (NXT_W > 0) __syncthreads();          // every wave is done with the input tile the output overlays
+    if (idle) return;
 
 #pragma unroll
     for (int n = 0; n < RN; n++) {
@@ -902,6 +929,25 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
                 const int py = 2 * (t / (OW / 4)) + (kq >> 1), px = 2 * (t % (OW / 4)) + (kq & 1);
                 if (r < nv && t < RT && co < COUT) o[(size_t)(py * (OW / 2) + px) * COUT + co] = mx;
             }
+        } else if constexpr (NXT_W > 0) {
+            static_assert(NT * 16 == NXT_CINP && M == NXT_W * NXT_W, "the next layer's tile holds exactly this layer's output");
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int m = (tile0 + r) * 16 + 4 * kq + e;
+                    float v = acc[r][n][e] * wscale_inv + bv;
+                    v = (v > 0.f && co < COUT) ? v : 0.f;
+                    nxt_big = fmaxf(nxt_big, v);
+                    _Float16 hh, ll;
+                    split_h2(v, hh, ll);
+                    if (r < nv && m < M) {
+                        _Float16* d = &lds[(m / NXT_W) * NXT_RS + (m % NXT_W) * NXT_PS + co];
+                        d[0] = hh;
+                        d[NXT_CINP] = ll;
+                    }
+                }
+            }
         } else {
             float* o = out + (size_t)patch * M * COUT;
 #pragma unroll
@@ -916,6 +962,39 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
             }
         }
     }
+    if constexpr (NXT_W > 0) {
+        if (overflow && !(nxt_big <= 65000.f)) *overflow = 1;
+    }
+}
+
+template <int H, int W, int CIN, int KH, int KW, int COUT, int TB, int YB, int WAVES_M, int RN, bool POOL, int PF, bool SB, bool SWZ = false,
+          bool FUSE1 = false>
+__global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfma16_h2_kernel(
+    const float* __restrict__ in, const uint16_t* __restrict__ wt, const float* __restrict__ bias,
+    float* __restrict__ out, float wscale_inv, int* __restrict__ overflow,
+    const uint8_t* __restrict__ goban1 = nullptr, const uint16_t* __restrict__ wf1 = nullptr, const float* __restrict__ bias1 = nullptr)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 lds[h2_tile_halves<H, W, CIN, KH, KW, TB, POOL, SWZ>()];
+    conv_h2_body<H, W, CIN, KH, KW, COUT, TB, YB, WAVES_M, RN, POOL, PF, SB, SWZ, FUSE1>(lds, blockIdx.x, blockIdx.y, in, wt, bias, out,
+                                                                                        wscale_inv, overflow, goban1, wf1, bias1);
+}
+
+// conv3 (3x3x32 -> 90, relu) and conv4 (3x3x90 -> 90, relu, 2x2 max-pool) of one patch in one workgroup: conv3's
+// 14x14x90 output is written as hi/lo halves into conv4's LDS tile (which overlays conv3's own input tile once its
+// k-loop is done) instead of going to HBM and back.  Same arithmetic in the same order as the two kernels apart.
+__global__ __launch_bounds__(256, 2) void conv34_h2_kernel(
+    const float* __restrict__ in, const uint16_t* __restrict__ wt3, const float* __restrict__ bias3,
+    const uint16_t* __restrict__ wt4, const float* __restrict__ bias4, float* __restrict__ out, float wscale_inv,
+    int* __restrict__ overflow)
+{
+    constexpr int T3 = h2_tile_halves<16, 16, 32, 3, 3, 13, false, false>(), T4 = h2_tile_halves<14, 14, 90, 3, 3, 9, true, false>();
+    constexpr int PS4 = 2 * 96 + 8, RS4 = lds_stride_b(14 * PS4, 32, 64);
+    __shared__ __attribute__((aligned(16))) _Float16 lds[T3 > T4 ? T3 : T4];
+    conv_h2_body<16, 16, 32, 3, 3, 90, 13, 1, 2, 3, false, H2C3_PF, H2C3_SB, false, false, false, 14, PS4, RS4, 96>(
+        lds, blockIdx.x, 0, in, wt3, bias3, nullptr, wscale_inv, overflow);
+    __syncthreads();
+    conv_h2_body<14, 14, 90, 3, 3, 90, 9, 1, 2, 3, true, H2C34_PF, true, false, false, true>(
+        lds, blockIdx.x, 0, nullptr, wt4, bias4, out, wscale_inv, overflow);
 }
 
 // conv1 in split-precision mode.  The u8 pixels are exact in fp16, so only the weights are split and a product
@@ -1453,26 +1532,33 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
                                (const float*)W.c2b.p, p2);
         }
         float* a3 = a1;
-        {
-            TimeScope ts(ctx, "cnn_conv3");
-            // 13 pixel tiles x 6 channel tiles of 16
-            if (h2)
-                hipLaunchKernelGGL((conv_mfma16_h2_kernel<16, 16, 32, 3, 3, 90, 13, 1, 2, 3, false, H2C3_PF, H2C3_SB>), dim3(np), dim3(256), 0, ctx->stream,
-                                   (const float*)p2, (const uint16_t*)W.c3w_h2.p, (const float*)W.c3b.p, a3, 1.f / H2_WSCALE, d_nonfinite);
-            else
-            hipLaunchKernelGGL((conv_mfma16_f32_kernel<16, 16, 32, 3, 3, 90, 13, 1, C3_WM, 1, false>), dim3(np), dim3(384 * C3_WM), 0,
-                               ctx->stream, (const float*)p2, (const float*)W.c3w.p, (const float*)W.c3b.p, a3);
-        }
-
-        {
+        if (h2 && H2_FUSE34) {
             TimeScope ts(ctx, "cnn_conv4");
-            // 9 tiles of four pooling windows x 6 channel tiles; pooled 6x6x90 written directly
-            if (h2)
-                hipLaunchKernelGGL((conv_mfma16_h2_kernel<14, 14, 90, 3, 3, 90, 9, 1, 2, 3, true, H2C34_PF, true>), dim3(np), dim3(256), 0, ctx->stream,
-                                   (const float*)a3, (const uint16_t*)W.c4w_h2.p, (const float*)W.c4b.p, p4, 1.f / H2_WSCALE, d_nonfinite);
-            else
-            hipLaunchKernelGGL((conv_mfma16_f32_kernel<14, 14, 90, 3, 3, 90, 9, 1, C4_WM, 1, true>), dim3(np), dim3(384 * C4_WM), 0,
-                               ctx->stream, (const float*)a3, (const float*)W.c4w.p, (const float*)W.c4b.p, p4);
+            // conv3 + conv4 of a patch in one workgroup; pooled 6x6x90 written directly
+            hipLaunchKernelGGL(conv34_h2_kernel, dim3(np), dim3(256), 0, ctx->stream, (const float*)p2, (const uint16_t*)W.c3w_h2.p,
+                               (const float*)W.c3b.p, (const uint16_t*)W.c4w_h2.p, (const float*)W.c4b.p, p4, 1.f / H2_WSCALE, d_nonfinite);
+        } else {
+            {
+                TimeScope ts(ctx, "cnn_conv3");
+                // 13 pixel tiles x 6 channel tiles of 16
+                if (h2)
+                    hipLaunchKernelGGL((conv_mfma16_h2_kernel<16, 16, 32, 3, 3, 90, 13, 1, 2, 3, false, H2C3_PF, H2C3_SB>), dim3(np), dim3(256), 0, ctx->stream,
+                                       (const float*)p2, (const uint16_t*)W.c3w_h2.p, (const float*)W.c3b.p, a3, 1.f / H2_WSCALE, d_nonfinite);
+                else
+                hipLaunchKernelGGL((conv_mfma16_f32_kernel<16, 16, 32, 3, 3, 90, 13, 1, C3_WM, 1, false>), dim3(np), dim3(384 * C3_WM), 0,
+                                   ctx->stream, (const float*)p2, (const float*)W.c3w.p, (const float*)W.c3b.p, a3);
+            }
+
+            {
+                TimeScope ts(ctx, "cnn_conv4");
+                // 9 tiles of four pooling windows x 6 channel tiles; pooled 6x6x90 written directly
+                if (h2)
+                    hipLaunchKernelGGL((conv_mfma16_h2_kernel<14, 14, 90, 3, 3, 90, 9, 1, 2, 3, true, H2C34_PF, true>), dim3(np), dim3(256), 0, ctx->stream,
+                                       (const float*)a3, (const uint16_t*)W.c4w_h2.p, (const float*)W.c4b.p, p4, 1.f / H2_WSCALE, d_nonfinite);
+                else
+                hipLaunchKernelGGL((conv_mfma16_f32_kernel<14, 14, 90, 3, 3, 90, 9, 1, C4_WM, 1, true>), dim3(np), dim3(384 * C4_WM), 0,
+                                   ctx->stream, (const float*)a3, (const float*)W.c4w.p, (const float*)W.c4b.p, p4);
+            }
         }
         CK_HIP(ctx, hipGetLastError());
     }
