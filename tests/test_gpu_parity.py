@@ -40,6 +40,16 @@ def test_median_random_shapes(ck, ora, shape):
     assert np.array_equal(ck.median15(img), ora.median(img, 15))
 
 
+def test_median_interior_tiles_worst_case(ck, ora):
+    """pure noise (up to 255 thresholds per tile) on a frame large enough to hold interior 48x48 tiles (the
+    scalar-base load / store path of the matrix-core kernel) next to border tiles, odd width"""
+    rng = np.random.default_rng(4848)
+    img = rng.integers(0, 256, (170, 203, 3), dtype=np.uint8)
+    assert np.array_equal(ck.median15(img), ora.median(img, 15))
+    img[40:120, 60:150] = rng.integers(100, 104, (80, 90, 3), dtype=np.uint8)      # a nearly flat patch inside
+    assert np.array_equal(ck.median15(img), ora.median(img, 15))
+
+
 def test_median_extremes_and_batch(ck, ora):
     rng = np.random.default_rng(11)
     imgs = np.stack([np.zeros((40, 70, 3), np.uint8), np.full((40, 70, 3), 255, np.uint8),
