@@ -38,7 +38,7 @@ struct CnnWeights {
     // bf16 packs for the MFMA path
     DevBuf c2w_bf, c3w_bf, c4w_bf, d1w_bf;
     // hi / lo fp16 planes for the split-precision mode
-    DevBuf c1w_h2, c2w_h2, c3w_h2, c4w_h2;
+    DevBuf c1w_h2, c2w_h2, c3w_h2, c4w_h2, d1w_h2;
 };
 
 struct ck_ctx {

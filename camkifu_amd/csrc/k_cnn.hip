@@ -41,6 +41,9 @@
 #ifndef H2C2_SWZ
 #define H2C2_SWZ 1      // conv2: swizzled LDS tile, 24 pixel tiles per block (3 per wave); 0 = padded tile, 16 per block
 #endif
+#ifndef H2_FC1
+#define H2_FC1 1         // first dense layer in split precision too
+#endif
 #ifndef H2_FUSE34
 #define H2_FUSE34 1      // conv3 and conv4 in one workgroup, conv3's output stays in LDS
 #endif
@@ -1210,6 +1213,120 @@ __global__ __launch_bounds__(256) void fc1_mfma16_kernel(const float* __restrict
     }
 }
 
+// The same dense layer in split precision (CK_CNN_F16X2): v_mfma_f32_16x16x32_f16, three MFMAs per product.
+// The f32 kernel above streams the whole 2 MB weight matrix through every wave (16 patches) and is bound by the
+// L2 for it; here a workgroup of 64 patches splits the OUTPUT tiles over its waves (tiles w, w + 4, w + 8), so each
+// weight fragment is loaded once per workgroup, and every wave reads all 64 patches' activations from the LDS chunk
+// (split into hi/lo halves once, when the chunk is staged; the next chunk's loads are in flight meanwhile).
+//   wt : [10 output tiles][104 k-steps][hi|lo][64 lanes][8] fp16, weights x 2^8, K padded 3240 -> 3328 with zeros
+__global__ __launch_bounds__(256) void fc1_h2_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wt,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int npatch,
+                                                     float wscale_inv, int* __restrict__ overflow)
+{
+#pragma clang fp contract(off)
+    constexpr int KIN = 3240, NOUT = 160, KC = 128, NCH = 26, KS = 104, RSH = 2 * KC + 8;  // 264 halves per patch row
+    constexpr int SPC = KC / 32;                    // k-steps per chunk: even, so the 2-slot weight ring stays in phase
+    constexpr int NLD = 64 * (KC / 4) / 256;        // float4 loads per thread and chunk
+    __shared__ __attribute__((aligned(16))) _Float16 lds[64 * RSH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int p0 = blockIdx.x * 64;
+    const int ntw = wave < 2 ? 3 : 2;               // output tiles wave, wave + 4, wave + 8 (< 10)
+    const uint4* wq = reinterpret_cast<const uint4*>(wt) + lane;
+    f32x4 acc[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[t][j][e] = 0.f;
+
+    float4 raw[NLD];
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int i = tid + 256 * q, row = i / (KC / 4), c4 = i % (KC / 4);
+            int p = p0 + row;
+            p = p > npatch - 1 ? npatch - 1 : p;
+            const int k = ch * KC + 4 * c4;
+            raw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ch < NCH && k < KIN) raw[q] = *reinterpret_cast<const float4*>(x + (size_t)p * KIN + k);
+        }
+    };
+    uint4 wf[2][3][2];                               // [ring slot][tile][hi|lo]
+    auto wload = [&](int slot, int s) {
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+            if (t < ntw) {
+                wf[slot][t][0] = wq[(((size_t)(wave + 4 * t) * KS + s) * 2) * 64];
+                wf[slot][t][1] = wq[(((size_t)(wave + 4 * t) * KS + s) * 2 + 1) * 64];
+            }
+    };
+    fetch(0);
+    wload(0, 0);
+    float big = 0.f;
+    for (int ch = 0; ch < NCH; ch++) {
+        __syncthreads();                             // previous chunk fully consumed
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int i = tid + 256 * q, row = i / (KC / 4), c4 = i % (KC / 4);
+            const float v[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
+            typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+            h4v hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                big = fmaxf(big, __builtin_fabsf(v[e]));
+                _Float16 hh, ll;
+                split_h2(v[e], hh, ll);
+                hi[e] = hh; lo[e] = ll;
+            }
+            *reinterpret_cast<h4v*>(&lds[row * RSH + 4 * c4]) = hi;
+            *reinterpret_cast<h4v*>(&lds[row * RSH + KC + 4 * c4]) = lo;
+        }
+        __syncthreads();
+        fetch(ch + 1);
+#pragma unroll
+        for (int ks = 0; ks < SPC; ks++) {
+            const int s = ch * SPC + ks;
+            if (s + 1 < KS) wload((ks + 1) & 1, s + 1);
+            h8 xh[4], xl[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const _Float16* ap = &lds[(16 * j + l15) * RSH + 32 * ks + 8 * kq];
+                xh[j] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(ap));
+                xl[j] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(ap + KC));
+            }
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+                if (t < ntw) {
+                    const h8 wh = __builtin_bit_cast(h8, wf[ks & 1][t][0]), wl = __builtin_bit_cast(h8, wf[ks & 1][t][1]);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[j], acc[t][j], 0, 0, 0);
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[j], acc[t][j], 0, 0, 0);
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[j], acc[t][j], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    if (overflow && !(big <= 65000.f)) *overflow = 1;
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+        if (t < ntw) {
+            const int o0 = (wave + 4 * t) * 16 + 4 * kq;
+            const float4 bv = *reinterpret_cast<const float4*>(bias + o0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int p = p0 + 16 * j + l15;
+                float4 v;
+                v.x = acc[t][j][0] * wscale_inv + bv.x; v.y = acc[t][j][1] * wscale_inv + bv.y;
+                v.z = acc[t][j][2] * wscale_inv + bv.z; v.w = acc[t][j][3] * wscale_inv + bv.w;
+                v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                if (p < npatch) *reinterpret_cast<float4*>(out + (size_t)p * NOUT + o0) = v;
+            }
+        }
+}
+
 // dense 160 -> 81 and softmax.  One wave per patch.
 __global__ __launch_bounds__(64) void fc2_softmax_kernel(const float* __restrict__ h1, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int npatch)
@@ -1420,6 +1537,24 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
     CK_TRY(pack_h2(host[2].data(), 5, 5, 32, 32, ctx->cnn.c2w_h2));
     CK_TRY(pack_h2(host[4].data(), 3, 3, 32, 90, ctx->cnn.c3w_h2));
     CK_TRY(pack_h2(host[6].data(), 3, 3, 90, 90, ctx->cnn.c4w_h2));
+    {   // dense1 for fc1_h2_kernel: [output tile][k-step][plane][lane = kslot*16 + output][8 consecutive k], weights x 2^8
+        std::vector<uint16_t> v((size_t)10 * 104 * 2 * 64 * 8, 0);
+        for (int t = 0; t < 10; t++)
+            for (int st = 0; st < 104; st++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int e = 0; e < 8; e++) {
+                        const int k = 32 * st + 8 * (lane / 16) + e, o = 16 * t + lane % 16;
+                        if (k >= 3240) continue;
+                        const float wv = host[8][(size_t)k * 160 + o] * H2_WSCALE;
+                        const _Float16 hi = (_Float16)wv;
+                        const _Float16 lo = (_Float16)(wv - (float)hi);
+                        const size_t base = (((size_t)t * 104 + st) * 2) * 64 * 8 + (size_t)lane * 8 + e;
+                        memcpy(&v[base], &hi, 2);
+                        memcpy(&v[base + 64 * 8], &lo, 2);
+                    }
+        CK_TRY(ck_ensure(ctx, ctx->cnn.d1w_h2, v.size() * 2));
+        CK_HIP(ctx, hipMemcpy(ctx->cnn.d1w_h2.p, v.data(), v.size() * 2, hipMemcpyHostToDevice));
+    }
     {
         std::vector<uint16_t> v((size_t)160 * 3456, 0);
         for (int o = 0; o < 160; o++)
@@ -1565,6 +1700,10 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
     {
         TimeScope ts(ctx, "cnn_tail");
         const int np = nframes * 100;
+        if (h2 && H2_FC1)
+            hipLaunchKernelGGL(fc1_h2_kernel, dim3((np + 63) / 64), dim3(256), 0, ctx->stream, (const float*)p4_all,
+                               (const uint16_t*)W.d1w_h2.p, (const float*)W.d1b.p, h1, np, 1.f / H2_WSCALE, d_nonfinite);
+        else
         hipLaunchKernelGGL(fc1_mfma16_kernel, dim3((np + 63) / 64), dim3(256), 0, ctx->stream,
                            (const float*)p4_all, (const float*)W.d1w.p, (const float*)W.d1b.p, h1, np);
         hipLaunchKernelGGL(fc2_softmax_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float*)h1,
