@@ -56,9 +56,6 @@
 #ifndef H2C2S_SB
 #define H2C2S_SB true
 #endif
-#ifndef H2_EXP
-#define H2_EXP 0      // timing experiments only (1: weight fragments loaded once, 2: activation fragments read once)
-#endif
 #ifndef H2C3_PF
 #define H2C3_PF 2
 #endif
@@ -874,7 +871,7 @@ __device__ __forceinline__ void conv_h2_body(
 #pragma unroll
                 for (int cc = 0; cc < CINP / 32; cc++) {
                     const int step = (i * KW + j) * (CINP / 32) + cc;
-                    if (step + PF < KS && (H2_EXP != 1 || step == 0)) {
+                    if (step + PF < KS) {
 #pragma unroll
                         for (int n = 0; n < RN; n++) {
                             bq[(step + PF) % NS][n][0] = wq[((size_t)n * KS + step + PF) * 128];
@@ -890,7 +887,7 @@ __device__ __forceinline__ void conv_h2_body(
                     }
 #pragma unroll
                     for (int r = 0; r < NV; r++) {
-                        const _Float16* ap = &lds[abase[r] + (H2_EXP == 2 ? 0 : i * RS + j * PS + 32 * cc)];
+                        const _Float16* ap = &lds[abase[r] + i * RS + j * PS + 32 * cc];
                         const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(ap));
                         const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(ap + CINP));
 #pragma unroll
