@@ -20,7 +20,8 @@
 // The three biggest contours need float rotating calipers; that scalar, branchy search runs
 // on the host for the few components whose bounding box could still make the top three.
 // Hough voting keeps a slab of theta rows in LDS per workgroup (LDS atomics), then writes
-// the rows out coalesced -- the global accumulator is never zero-filled or atomically hit.
+// the rows out coalesced -- the global accumulator is never zero-filled or atomically hit (and with HOUGH_FUSED,
+// the default, it does not exist at all: the peak test runs on the LDS slab of 16-bit counters).
 #include <math.h>
 
 #include <algorithm>
@@ -28,6 +29,10 @@
 #include <thread>
 
 #include "ck_common.h"
+
+#ifndef HOUGH_FUSED
+#define HOUGH_FUSED 1     // votes and peak test in one kernel (0: separate kernels through a global accumulator)
+#endif
 #include "ck_uf.h"
 
 #pragma clang fp contract(off)
@@ -535,6 +540,63 @@ __global__ void hough_peaks_kernel(const int32_t* __restrict__ accum, int numrho
     }
 }
 
+// ---- H + I fused: the votes of rb theta rows (plus one halo row either side) as 16-bit counters packed two per
+// LDS dword, peaks found on the slab itself: the accumulator never exists in HBM.  A cell's count is at most the
+// number of ghost pixels on one discrete line (< w + h), so the halves cannot carry into each other.
+__global__ __launch_bounds__(256) void hough_vote_peaks_kernel(const uint32_t* __restrict__ hpts, FrameTab* __restrict__ tab,
+                                                               int pcap, const float* __restrict__ trig /* cos[180], sin[180] */,
+                                                               int numrho, int rb, int threshold,
+                                                               int32_t* __restrict__ peaks /* f*PEAK_CAP*2 */)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) uint32_t slab16[];
+    const int f = blockIdx.y;
+    const int n0 = blockIdx.x * rb;                       // first inner row
+    const int stride = numrho + 2;                        // as the global accumulator had: a zero guard cell either side
+    const int rowdw = (stride + 1) >> 1;                  // dwords per LDS row
+    const int nrows = rb + 2;                             // LDS row j <-> theta row n0 - 1 + j
+    for (int i = threadIdx.x; i < nrows * rowdw; i += 256) slab16[i] = 0u;
+    __syncthreads();
+    int npts = tab[f].n_hough_pts;
+    if (npts > pcap) npts = pcap;
+    const uint32_t* P = hpts + (size_t)f * pcap;
+    const int half = (numrho - 1) / 2;
+    const int j_lo = n0 == 0 ? 1 : 0;
+    int j_hi = NUMANGLE - (n0 - 1);                       // exclusive: rows past theta 179 stay zero
+    if (j_hi > nrows) j_hi = nrows;
+    for (int i = threadIdx.x; i < npts; i += 256) {
+        const uint32_t pk = P[i];
+        const float xf = (float)(pk & 0xFFFF), yf = (float)(pk >> 16);
+        for (int j = j_lo; j < j_hi; j++) {
+            const int n = n0 - 1 + j;
+            const float a = xf * trig[n];
+            const float b = yf * trig[NUMANGLE + n];
+            const float s = a + b;
+            const int c = (int)rintf(s) + half + 1;       // cell index inside the row
+            atomicAdd(&slab16[j * rowdw + (c >> 1)], 1u << (16 * (c & 1)));
+        }
+    }
+    __syncthreads();
+    const uint16_t* cnt = reinterpret_cast<const uint16_t*>(slab16);
+    const int rowhw = 2 * rowdw;
+    for (int k = 0; k < rb; k++) {
+        const int n = n0 + k;
+        if (n >= NUMANGLE) break;
+        const uint16_t* row = cnt + (k + 1) * rowhw;
+        for (int r = threadIdx.x; r < numrho; r += 256) {
+            const int v = row[r + 1];
+            if (v <= threshold) continue;
+            if (v > row[r] && v >= row[r + 2] && v > row[r + 1 - rowhw] && v >= row[r + 1 + rowhw]) {
+                const int i = atomicAdd(&tab[f].n_peaks, 1);
+                if (i < PEAK_CAP) {
+                    peaks[((size_t)f * PEAK_CAP + i) * 2] = (n + 1) * stride + r + 1;
+                    peaks[((size_t)f * PEAK_CAP + i) * 2 + 1] = v;
+                } else tab[f].overflow = 1;
+            }
+        }
+    }
+}
+
 template <typename F>
 void parallel_for(int n, F fn)
 {
@@ -778,9 +840,13 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
             trig[k] = (float)(cos((double)ang) * 1.f);
         }
     }
+#if !HOUGH_FUSED
     CK_TRY(ck_ensure(ctx, ctx->accum, (size_t)n * (NUMANGLE + 2) * stride * 4));
+#endif
     CK_TRY(ck_ensure(ctx, ctx->peaks, (size_t)n * PEAK_CAP * 8 + (size_t)n * pcap * 4));
+#if !HOUGH_FUSED
     int32_t* d_accum = (int32_t*)ctx->accum.p;
+#endif
     int32_t* d_peaks = (int32_t*)ctx->peaks.p;
     uint32_t* d_hpts = (uint32_t*)(d_peaks + (size_t)n * PEAK_CAP * 2);
     {
@@ -791,6 +857,20 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
                            (const int32_t*)d_sel, d_tab, (const int32_t*)blist, pcap, d_hpts, d_ghost_out);
         CK_HIP(ctx, hipGetLastError());
     }
+#if HOUGH_FUSED
+    {
+        TimeScope ts(ctx, "hough_vote");
+        const size_t row_bytes = (size_t)((stride + 1) / 2) * 4;           // 16-bit counters, two per dword
+        int rb = (int)((144 * 1024) / row_bytes) - 2;                      // inner rows per workgroup (+ 2 halo rows)
+        if (rb > 10) rb = 10;
+        if (rb < 1) return ck_fail(ctx, CK_ERR_ARG, "image too large for the Hough LDS slab");
+        CK_HIP(ctx, hipFuncSetAttribute((const void*)hough_vote_peaks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)((rb + 2) * row_bytes)));
+        hipLaunchKernelGGL(hough_vote_peaks_kernel, dim3((NUMANGLE + rb - 1) / rb, n), dim3(256), (rb + 2) * row_bytes, ctx->stream,
+                           (const uint32_t*)d_hpts, d_tab, pcap, (const float*)d_trig, numrho, rb, hough_thresh, d_peaks);
+        CK_HIP(ctx, hipGetLastError());
+    }
+#else
     {
         TimeScope ts(ctx, "hough_vote");
         const size_t row_bytes = (size_t)stride * 4;
@@ -809,6 +889,7 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
                            (const int32_t*)d_accum, numrho, hough_thresh, d_tab, d_peaks);
         CK_HIP(ctx, hipGetLastError());
     }
+#endif
     lap("ghost+hough");
     CK_HIP(ctx, hipMemcpyAsync(tab.data(), d_tab, tab_bytes, hipMemcpyDeviceToHost, ctx->stream));
     CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
