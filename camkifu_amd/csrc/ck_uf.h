@@ -60,3 +60,18 @@ __device__ __forceinline__ int wave_append(int* counter, bool flag)
     if (!flag) return -1;
     return base + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
 }
+
+// List kernels: workgroup -> (frame, block of the frame's grid-stride loop).  Launched either as a 2-D grid (block, frame) or,
+// with CK_LIST_XCD, as a 1-D grid of nblk * frames workgroups in which all blocks of a frame get ids congruent modulo 8:
+// workgroup ids go round-robin over the 8 XCDs, so a frame's union-find traffic stays in ONE L2 (frames % 8 == 0 only).
+#ifndef CK_LIST_XCD
+#define CK_LIST_XCD 1
+#endif
+__device__ __forceinline__ void list_frame_block(int nblk, int& f, int& bx)
+{
+    if (gridDim.y > 1) { f = blockIdx.y; bx = blockIdx.x; return; }
+    const int L = blockIdx.x, n = gridDim.x / nblk;
+    if ((n & 7) == 0) { const int slot = L >> 3; f = (slot / nblk) * 8 + (L & 7); bx = slot % nblk; }
+    else { f = L / nblk; bx = L % nblk; }
+}
+static inline dim3 list_grid(int nblk, int n) { return CK_LIST_XCD ? dim3((unsigned)(nblk * n)) : dim3(nblk, n); }

@@ -346,7 +346,10 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
 
 // The three hysteresis kernels walk the per-frame candidate list (a few % of the pixels)
 // with a fixed grid and a grid-stride loop; the count is read from device memory.
-constexpr int LIST_BLOCKS = 64;
+#ifndef CANNY_LIST_BLOCKS
+#define CANNY_LIST_BLOCKS 64
+#endif
+constexpr int LIST_BLOCKS = CANNY_LIST_BLOCKS;
 
 // link every candidate with its already-scanned 8-neighbours (W, N, and NW / NE only when
 // N is not itself a candidate -- otherwise the link is implied)
@@ -354,12 +357,13 @@ __global__ __launch_bounds__(256) void canny_link_kernel(const uint8_t* __restri
                                                          int32_t* __restrict__ labels, const int32_t* __restrict__ cand,
                                                          const int* __restrict__ cand_count)
 {
-    const int f = blockIdx.y;
+    int f, bx;
+    list_frame_block(LIST_BLOCKS, f, bx);
     const int n = cand_count[f];
     const uint8_t* m = map + (size_t)f * h * w;
     int32_t* L = labels + (size_t)f * h * w;
     const int32_t* C = cand + (size_t)f * h * w;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += LIST_BLOCKS * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < n; i += LIST_BLOCKS * 256) {
         const int p = C[i];
         const int y = p / w, x = p - y * w;
         if (x > 0 && m[p - 1] != 1) uf_union(L, p, p - 1);
@@ -377,11 +381,12 @@ __global__ __launch_bounds__(256) void canny_flatten_mark_kernel(const uint8_t* 
                                                                  int32_t* __restrict__ labels, uint8_t* __restrict__ edges,
                                                                  const int32_t* __restrict__ cand, const int* __restrict__ cand_count)
 {
-    const int f = blockIdx.y;
+    int f, bx;
+    list_frame_block(LIST_BLOCKS, f, bx);
     const int n = cand_count[f];
     const size_t off = (size_t)f * h * w;
     const int32_t* C = cand + off;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += LIST_BLOCKS * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < n; i += LIST_BLOCKS * 256) {
         const int p = C[i];
         const int root = uf_find(labels + off, p);
         labels[off + p] = root;
@@ -395,11 +400,12 @@ __global__ __launch_bounds__(256) void canny_final_kernel(int h, int w, const in
                                                           uint8_t* __restrict__ edges, const int32_t* __restrict__ cand,
                                                           const int* __restrict__ cand_count, int* __restrict__ border_flag)
 {
-    const int f = blockIdx.y;
+    int f, bx;
+    list_frame_block(LIST_BLOCKS, f, bx);
     const int n = cand_count[f];
     const size_t off = (size_t)f * h * w;
     const int32_t* C = cand + off;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += LIST_BLOCKS * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < n; i += LIST_BLOCKS * 256) {
         const int p = C[i];
         const int root = labels[off + p];
         const uint8_t e = edges[off + root];           // root entries were written by the previous kernel
@@ -441,7 +447,7 @@ int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, in
         TimeScope ts(ctx, "canny_hyst");
         CK_HIP(ctx, hipMemsetAsync(d_edges, 0, npx, ctx->stream));
         if (d_border_flag) CK_HIP(ctx, hipMemsetAsync(d_border_flag, 0, (size_t)n * 4, ctx->stream));
-        dim3 grid(LIST_BLOCKS, n);
+        const dim3 grid = list_grid(LIST_BLOCKS, n);
         hipLaunchKernelGGL(canny_link_kernel, grid, dim3(256), 0, ctx->stream, (const uint8_t*)d_map, h, w, d_labels,
                            (const int32_t*)d_cand, (const int*)d_count);
         hipLaunchKernelGGL(canny_flatten_mark_kernel, grid, dim3(256), 0, ctx->stream, (const uint8_t*)d_map, h, w,

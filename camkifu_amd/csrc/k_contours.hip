@@ -53,7 +53,10 @@ struct FrameTab {        // device-side per-frame counters
     int pad0, pad1;
 };
 
-constexpr int LIST_BLOCKS = 48;          // grid-stride blocks per frame for the list kernels
+#ifndef CCL_LIST_BLOCKS
+#define CCL_LIST_BLOCKS 48
+#endif
+constexpr int LIST_BLOCKS = CCL_LIST_BLOCKS;          // grid-stride blocks per frame for the list kernels
 
 // ---- A. frame clearing + parent initialisation + edge list -----------------------------
 // one wave per image row; walks the row in 64-pixel segments carrying the position of the
@@ -257,13 +260,14 @@ __global__ __launch_bounds__(256) void link_list_kernel(const uint8_t* __restric
                                                         const int32_t* __restrict__ elist,
                                                         const int* __restrict__ canny_border_flag)
 {
-    const int f = blockIdx.y;
+    int f, bx;
+    list_frame_block(LIST_BLOCKS, f, bx);
     const bool edges_linked = canny_border_flag != nullptr && canny_border_flag[f] == 0;   // parents kept from Canny
     const int ne = tab[f].n_edges;
     const uint8_t* e = ez + (size_t)f * h * w;
     int32_t* L = labels + (size_t)f * h * w;
     const int32_t* E = elist + (size_t)f * h * w;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < ne + h - 1; i += LIST_BLOCKS * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < ne + h - 1; i += LIST_BLOCKS * 256) {
         if (i < ne) {
             const int p = E[i];                        // 1 <= x <= w-2, 1 <= y <= h-2
             if (!edges_linked) {
@@ -289,13 +293,14 @@ __global__ __launch_bounds__(256) void flatten_list_kernel(const uint8_t* __rest
                                                            int32_t* __restrict__ labels, const FrameTab* __restrict__ tab,
                                                            const int32_t* __restrict__ elist)
 {
-    const int f = blockIdx.y;
+    int f, bx;
+    list_frame_block(LIST_BLOCKS, f, bx);
     const int ne = tab[f].n_edges;
     const size_t off = (size_t)f * h * w;
     const uint8_t* e = ez + off;
     int32_t* L = labels + off;
     const int32_t* E = elist + off;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < ne + h; i += LIST_BLOCKS * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < ne + h; i += LIST_BLOCKS * 256) {
         if (i < ne) {
             const int p = E[i];
             L[p] = uf_find(L, p);
@@ -319,13 +324,14 @@ __global__ __launch_bounds__(256) void roots_list_kernel(int h, int w, const int
                                                          int32_t* __restrict__ roots, int32_t* __restrict__ aabb,
                                                          const int32_t* __restrict__ elist)
 {
-    const int f = blockIdx.y;
+    int f, bx;
+    list_frame_block(LIST_BLOCKS, f, bx);
     const int ne = tab[f].n_edges;
     const size_t off = (size_t)f * h * w;
     const int32_t* L = labels + off;
     const int32_t* E = elist + off;
     const int root0 = L[0];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < ne; i += LIST_BLOCKS * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < ne; i += LIST_BLOCKS * 256) {
         const int p = E[i];
         if (L[p] != p) continue;
         if (!in_s0(L, p - 1, root0)) continue;      // west neighbour of a first pixel is background
@@ -344,7 +350,8 @@ __global__ __launch_bounds__(256) void border_list_kernel(const uint8_t* __restr
                                                           int maxc, FrameTab* __restrict__ tab, int32_t* __restrict__ aabb,
                                                           const int32_t* __restrict__ elist, int32_t* __restrict__ blist)
 {
-    const int f = blockIdx.y;
+    int f, bx;
+    list_frame_block(LIST_BLOCKS, f, bx);
     const int ne = tab[f].n_edges;
     const size_t off = (size_t)f * h * w;
     const uint8_t* e = ez + off;
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(256) void border_list_kernel(const uint8_t* __restr
     const int root0 = L[0];
     const int trips = (ne + LIST_BLOCKS * 256 - 1) / (LIST_BLOCKS * 256);      // uniform trip count
     for (int t = 0; t < trips; t++) {
-        const int i = t * LIST_BLOCKS * 256 + blockIdx.x * 256 + threadIdx.x;
+        const int i = t * LIST_BLOCKS * 256 + bx * 256 + threadIdx.x;
         bool b = false;
         int p = 0, cslot = -1;
         if (i < ne) {
@@ -435,13 +442,14 @@ __global__ __launch_bounds__(256) void gather_points_kernel(const uint8_t* __res
                                                             const int32_t* __restrict__ blist, int32_t* __restrict__ counter, int cap,
                                                             int32_t* __restrict__ pts /* x|y<<16, slot ; then frame */)
 {
-    const int f = blockIdx.y;
+    int f, bx;
+    list_frame_block(LIST_BLOCKS, f, bx);
     const int nb = tab[f].n_border;
     const size_t off = (size_t)f * h * w;
     const int32_t* B = blist + off;
     const int trips = (nb + LIST_BLOCKS * 256 - 1) / (LIST_BLOCKS * 256);       // uniform trip count
     for (int t = 0; t < trips; t++) {
-        const int i = t * LIST_BLOCKS * 256 + blockIdx.x * 256 + threadIdx.x;
+        const int i = t * LIST_BLOCKS * 256 + bx * 256 + threadIdx.x;
         bool take = false;
         int p = 0, slot = 0;
         if (i < nb) {
@@ -465,13 +473,14 @@ __global__ __launch_bounds__(256) void ghost_list_kernel(int h, int w, const int
                                                          FrameTab* __restrict__ tab, const int32_t* __restrict__ blist, int pcap,
                                                          uint32_t* __restrict__ hpts, uint8_t* __restrict__ ghost)
 {
-    const int f = blockIdx.y;
+    int f, bx;
+    list_frame_block(LIST_BLOCKS, f, bx);
     if (!sel[f * 4 + 3]) return;
     const int nb = tab[f].n_border;
     const size_t off = (size_t)f * h * w;
     const int32_t* B = blist + off;
     const int s0 = sel[f * 4], s1 = sel[f * 4 + 1], s2 = sel[f * 4 + 2];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nb; i += LIST_BLOCKS * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < nb; i += LIST_BLOCKS * 256) {
         const int p = B[i];
         const int slot = compid[off + labels[off + p]];
         if (slot != s0 && slot != s1 && slot != s2) continue;
@@ -661,7 +670,7 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
     int32_t* d_aabb = d_roots + (size_t)n * maxc;
     uint8_t* d_want = (uint8_t*)(d_aabb + (size_t)n * maxc * 4);
 
-    const dim3 lgrid(LIST_BLOCKS, n), lblock(256);
+    const dim3 lgrid = list_grid(LIST_BLOCKS, n), lblock(256);
     {
         TimeScope ts(ctx, "ccl");
         CK_HIP(ctx, hipMemsetAsync(d_tab, 0, tab_bytes, ctx->stream));
