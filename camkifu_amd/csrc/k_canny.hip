@@ -14,6 +14,9 @@
 #ifndef NMS_PACKED
 #define NMS_PACKED 1
 #endif
+#ifndef NMS_LOCAL_UF
+#define NMS_LOCAL_UF 1     // tile-local union-find of the candidates inside the NMS kernel (needs NMS_PACKED)
+#endif
 
 namespace {
 
@@ -192,7 +195,8 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
     uint32_t (*pxw)[PLH][LWD] = reinterpret_cast<uint32_t (*)[PLH][LWD]>(smem);
     int32_t* cbuf = reinterpret_cast<int32_t*>(smem);
     __shared__ __attribute__((aligned(8))) uint16_t mag[PGR][PGW];
-    __shared__ __attribute__((aligned(8))) int16_t gdx[PGR][PGW], gdy[PGR][PGW];
+    __shared__ __attribute__((aligned(16))) int16_t gxy[2][PGR][PGW];       // dx, dy of the chosen channel; later the tile-local parents
+    int16_t (*gdx)[PGW] = gxy[0], (*gdy)[PGW] = gxy[1];
     __shared__ int ccount, cbase;
     const int f = blockIdx.z;
     const int ox = blockIdx.x * TW, oy = blockIdx.y * PTH;
@@ -287,7 +291,13 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
     // NMS: one thread = 4 consecutive pixels of one row (one dword of the map)
     const int TG22 = 13573;   // (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
     const uint16_t* magf = &mag[0][0];
-    for (int q = tid; q < PTH * 16; q += 256) {
+    constexpr int NQ = (PTH * 16 + 255) / 256;
+    int km[NQ];
+#pragma unroll
+    for (int it = 0; it < NQ; it++) {
+        const int q = tid + 256 * it;
+        km[it] = 0;
+        if (q >= PTH * 16) continue;
         const int r = q >> 4, col0 = (q & 15) * 4;
         const int y = oy + r;
         uint32_t mapw = 0x01010101u;
@@ -325,17 +335,86 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
                 for (int k = 0; k < 4; k++) if (x0 + k < w) map[idx + k] = (uint8_t)(mapw >> (8 * k));
             }
         }
-        const int nk = __builtin_popcount(keepmask);
-        if (nk) {
-            int slot = atomicAdd(&ccount, nk);
+        km[it] = keepmask;
+    }
+#if NMS_LOCAL_UF
+    // Tile-local part of the hysteresis union-find, in LDS: every candidate is linked with its W / N (or NW, NE)
+    // neighbours inside this tile, so the global pass (canny_link_kernel) only has to visit the candidates on the
+    // tile's left, right and top edges.  Hooking is by smaller index and local order = raster order, so a local root
+    // is the first pixel of its local component, as the global structure wants.
+    __syncthreads();                                   // magnitudes and gradients are dead: their space holds the parents
+    int* lab = reinterpret_cast<int*>(&gxy[0][0][0]);
+    static_assert(sizeof(gxy) >= PTH * TW * 4, "parents fit the gradient arrays");
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (keepmask & (1 << k)) {
-                    const int p = y * w + ox + col0 + k;
-                    labels[(size_t)f * h * w + p] = p;
-                    cbuf[slot++] = p;
-                }
+    for (int it = 0; it < NQ; it++) {
+        const int q = tid + 256 * it;
+        if (q >= PTH * 16) continue;
+        // local index = r * 64 + col = 4 q + k; a pixel whose west neighbour inside the quad is kept starts out
+        // pointing at the head of that little run (one union less)
+        int4 v;
+        v.x = (km[it] & 1) ? 4 * q : -1;
+        v.y = (km[it] & 2) ? ((km[it] & 1) ? v.x : 4 * q + 1) : -1;
+        v.z = (km[it] & 4) ? ((km[it] & 2) ? v.y : 4 * q + 2) : -1;
+        v.w = (km[it] & 8) ? ((km[it] & 4) ? v.z : 4 * q + 3) : -1;
+        *reinterpret_cast<int4*>(lab + 4 * q) = v;
+    }
+    __syncthreads();
+    auto lfind = [&](int a) {
+        int p = __hip_atomic_load(lab + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (p != a) { a = p; p = __hip_atomic_load(lab + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        return a;
+    };
+    auto lunion = [&](int a, int b) {
+        for (;;) {
+            a = lfind(a); b = lfind(b);
+            if (a == b) return;
+            if (a < b) { const int t = a; a = b; b = t; }
+            const int old = atomicMin(lab + a, b);
+            if (old == a) return;
+            a = old;
         }
+    };
+#pragma unroll
+    for (int it = 0; it < NQ; it++) {
+        const int q = tid + 256 * it;
+        if (q >= PTH * 16 || !km[it]) continue;
+        const int r = q >> 4, col0 = (q & 15) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (!(km[it] & (1 << k))) continue;
+            const int i = 4 * q + k, col = col0 + k;
+            if (k == 0 && col > 0 && lab[i - 1] >= 0) lunion(i, i - 1);       // k > 0: linked at initialisation
+            if (r > 0) {
+                if (lab[i - TW] >= 0) lunion(i, i - TW);
+                else {
+                    if (col > 0 && lab[i - TW - 1] >= 0) lunion(i, i - TW - 1);
+                    if (col < TW - 1 && lab[i - TW + 1] >= 0) lunion(i, i - TW + 1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#endif
+#pragma unroll
+    for (int it = 0; it < NQ; it++) {
+        const int q = tid + 256 * it;
+        const int nk = __builtin_popcount(km[it]);
+        if (q >= PTH * 16 || !nk) continue;
+        const int r = q >> 4, col0 = (q & 15) * 4;
+        const int y = oy + r;
+        int slot = atomicAdd(&ccount, nk);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (km[it] & (1 << k)) {
+                const int p = y * w + ox + col0 + k;
+#if NMS_LOCAL_UF
+                const int root = lfind(4 * q + k);
+                labels[(size_t)f * h * w + p] = (oy + (root >> 6)) * w + ox + (root & 63);
+#else
+                labels[(size_t)f * h * w + p] = p;
+#endif
+                cbuf[slot++] = p;
+            }
     }
     __syncthreads();
     if (tid == 0) cbase = ccount ? atomicAdd(cand_count + f, ccount) : 0;
@@ -366,6 +445,11 @@ __global__ __launch_bounds__(256) void canny_link_kernel(const uint8_t* __restri
     for (int i = bx * 256 + threadIdx.x; i < n; i += LIST_BLOCKS * 256) {
         const int p = C[i];
         const int y = p / w, x = p - y * w;
+#if NMS_PACKED && NMS_LOCAL_UF
+        // links inside a tile of the NMS kernel were made there, in LDS: only a tile's left / right / top edge has
+        // a W, N, NW or NE neighbour in another tile
+        { const int c = x % TW; if (c != 0 && c != TW - 1 && y % PTH != 0) continue; }
+#endif
         if (x > 0 && m[p - 1] != 1) uf_union(L, p, p - 1);
         if (y > 0) {
             if (m[p - w] != 1) uf_union(L, p, p - w);
