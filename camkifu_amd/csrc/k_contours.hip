@@ -280,7 +280,9 @@ __global__ __launch_bounds__(256) void link_list_kernel(const uint8_t* __restric
             }
             const int q1 = p + 1, q2 = p + w + 1;      // background stretches opening right of p
             if (!e[q1] && !e[q1 - w]) uf_union(L, q1, q1 - w);
-            if (!e[q2] && !e[q2 - w]) uf_union(L, q2, q2 - w);
+            // (if the pixel below p is an edge pixel too -- a vertical stroke -- that pixel's own q1 is this very
+            // stretch: leave it to it)
+            if (!e[q2] && !e[q2 - w] && !e[p + w]) uf_union(L, q2, q2 - w);
         } else {
             const int q = (i - ne + 1) * w;            // x = 0 of rows 1 .. h-1: always background
             uf_union(L, q, q - w);
