@@ -293,10 +293,12 @@ __global__ __launch_bounds__(256) void link_list_kernel(const uint8_t* __restric
 // ---- C. flatten the nodes that later lookups go through --------------------------------
 __global__ __launch_bounds__(256) void flatten_list_kernel(const uint8_t* __restrict__ ez, int h, int w,
                                                            int32_t* __restrict__ labels, const FrameTab* __restrict__ tab,
-                                                           const int32_t* __restrict__ elist)
+                                                           const int32_t* __restrict__ elist,
+                                                           const int* __restrict__ canny_border_flag)
 {
     int f, bx;
     list_frame_block(LIST_BLOCKS, f, bx);
+    const bool edges_flat = canny_border_flag != nullptr && canny_border_flag[f] == 0;   // Canny left every edge pixel at its root
     const int ne = tab[f].n_edges;
     const size_t off = (size_t)f * h * w;
     const uint8_t* e = ez + off;
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256) void flatten_list_kernel(const uint8_t* __rest
     for (int i = bx * 256 + threadIdx.x; i < ne + h; i += LIST_BLOCKS * 256) {
         if (i < ne) {
             const int p = E[i];
-            L[p] = uf_find(L, p);
+            if (!edges_flat) L[p] = uf_find(L, p);
             if (!e[p + 1]) L[p + 1] = uf_find(L, p + 1);       // head of the run right of p
         } else {
             const int q = (i - ne) * w;
@@ -693,7 +695,7 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         hipLaunchKernelGGL(link_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
                            (const FrameTab*)d_tab, (const int32_t*)elist, kflag);
         hipLaunchKernelGGL(flatten_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
-                           (const FrameTab*)d_tab, (const int32_t*)elist);
+                           (const FrameTab*)d_tab, (const int32_t*)elist, kflag);
         hipLaunchKernelGGL(roots_list_kernel, lgrid, lblock, 0, ctx->stream, h, w, (const int32_t*)L, compid, d_tab, maxc,
                            d_roots, d_aabb, (const int32_t*)elist);
         hipLaunchKernelGGL(border_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, (const int32_t*)L,
