@@ -152,6 +152,21 @@ def test_board_detect_full_chain(ck, ora, synth):
         assert out[k]["n_lines"] == o["status"] and np.array_equal(out[k]["lines"], o["lines"])
 
 
+def test_board_detect_batch_of_eight(ck, ora, synth):
+    """8 and 16 frames per call: the list kernels then run with all workgroups of a frame on one XCD (ids congruent
+    mod 8) and the hysteresis links are split between the NMS tiles (LDS) and the tile-edge pass; every frame against
+    the oracle, edge maps included"""
+    for n in (8, 16):
+        frames = np.stack([synth.scene(150, 200, seed=4100 + 31 * n + s)["frame"].numpy() for s in range(n)])
+        out = ck.board_detect(frames)
+        edges = ck.board_edges(frames)
+        for k in range(n):
+            e = ora.canny(ora.median(frames[k], 15), 25, 75)
+            assert np.array_equal(edges[k], e), (n, k)
+            o = ora.board_lines(e)
+            assert out[k]["n_lines"] == o["status"] and np.array_equal(out[k]["lines"], o["lines"]), (n, k)
+
+
 # ---------------------------------------------------------------- K7 / K8
 def test_warp_bit_exact(ck, ora, synth):
     from camkifu_amd import capi
