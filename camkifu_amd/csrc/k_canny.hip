@@ -186,7 +186,7 @@ __device__ __forceinline__ u16x2 widen(uint32_t hi, uint32_t lo, uint32_t sel)
 __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __restrict__ planes, int h, int w, int pitch,
                                                                int low, int high, uint8_t* __restrict__ map,
                                                                int32_t* __restrict__ labels, int32_t* __restrict__ cand,
-                                                               int* __restrict__ cand_count)
+                                                               int* __restrict__ cand_count, uint8_t* __restrict__ edges_zero)
 {
     // pixel tile: columns ox-4 .. ox+67 (18 aligned dwords per row), rows oy-2 .. oy+PTH+1, border replicated.
     // The candidate buffer of the last phase reuses its space.
@@ -329,10 +329,15 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
             }
             const int x0 = ox + col0;
             const size_t idx = ((size_t)f * h + y) * w + x0;
-            if (x0 + 3 < w && ((idx & 3) == 0)) *reinterpret_cast<uint32_t*>(map + idx) = mapw;
-            else {
+            // the edge image of the hysteresis pass starts out all zero: cleared here, next to the map store,
+            // instead of by a memset of its own
+            if (x0 + 3 < w && ((idx & 3) == 0)) {
+                *reinterpret_cast<uint32_t*>(map + idx) = mapw;
+                *reinterpret_cast<uint32_t*>(edges_zero + idx) = 0u;
+            } else {
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (x0 + k < w) map[idx + k] = (uint8_t)(mapw >> (8 * k));
+                for (int k = 0; k < 4; k++)
+                    if (x0 + k < w) { map[idx + k] = (uint8_t)(mapw >> (8 * k)); edges_zero[idx + k] = 0; }
             }
         }
         km[it] = keepmask;
@@ -518,7 +523,7 @@ int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, in
 #if NMS_PACKED
         dim3 grid((w + TW - 1) / TW, (h + PTH - 1) / PTH, n);
         hipLaunchKernelGGL(canny_nms_packed_kernel, grid, dim3(256), 0, ctx->stream, d_planes, h, w, pitch, low, high, d_map,
-                           d_labels, d_cand, d_count);
+                           d_labels, d_cand, d_count, d_edges);
 #else
         dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, n);
         hipLaunchKernelGGL(canny_nms_kernel, grid, dim3(256), 0, ctx->stream, d_planes, h, w, pitch, low, high, d_map,
@@ -529,7 +534,9 @@ int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, in
     if (d_map_out) CK_HIP(ctx, hipMemcpyAsync(d_map_out, d_map, npx, hipMemcpyDeviceToDevice, ctx->stream));
     {
         TimeScope ts(ctx, "canny_hyst");
-        CK_HIP(ctx, hipMemsetAsync(d_edges, 0, npx, ctx->stream));
+#if !NMS_PACKED
+        CK_HIP(ctx, hipMemsetAsync(d_edges, 0, npx, ctx->stream));     // the packed NMS kernel clears it itself
+#endif
         if (d_border_flag) CK_HIP(ctx, hipMemsetAsync(d_border_flag, 0, (size_t)n * 4, ctx->stream));
         const dim3 grid = list_grid(LIST_BLOCKS, n);
         hipLaunchKernelGGL(canny_link_kernel, grid, dim3(256), 0, ctx->stream, (const uint8_t*)d_map, h, w, d_labels,
