@@ -22,7 +22,7 @@ CK_BOARD_LINES, CK_BOARD_NO_CONTOUR, CK_BOARD_TOO_SMALL = 0, 1, 2
 EXPORTS = [
     "ck_ctx_create", "ck_ctx_destroy", "ck_last_error", "ck_backend", "ck_version", "ck_stream",
     "ck_timing_enable", "ck_timing_reset", "ck_timing_get",
-    "ck_median15", "ck_canny", "ck_board_edges", "ck_board_lines", "ck_board_detect",
+    "ck_median15", "ck_median", "ck_canny", "ck_goban_canny", "ck_board_edges", "ck_board_lines", "ck_board_detect",
     "ck_i420_to_bgr", "ck_get_perspective_transform", "ck_warp_perspective",
     "ck_mog2_create", "ck_mog2_apply", "ck_mog2_destroy",
     "ck_cnn_set_weights", "ck_cnn_set_mode", "ck_cnn_predict", "ck_stones_detect",
@@ -166,6 +166,24 @@ class Context:
         out, op, osp = self._out(bgr, tuple(bgr.shape), np.uint8)
         self._chk(lib().ck_median15(self._h, p, n, h, w, sp, op, osp))
         return out
+
+    def median(self, bgr, ksize):
+        """cv2.medianBlur(bgr, ksize) for odd ksize in 3..17 (same matrix-core kernel, other window)"""
+        n, h, w = self._shape(bgr, 3)
+        p, sp, keep = _in(bgr)
+        out, op, osp = self._out(bgr, tuple(bgr.shape), np.uint8)
+        self._chk(lib().ck_median(self._h, p, n, h, w, int(ksize), sp, op, osp))
+        return out
+
+    def goban_canny(self, bgr, want_otsu=False):
+        """SfContours.get_canny (stone/sf_contours.py:332-340): medianBlur 13 then 7, Otsu level of the grey image,
+        Canny(median, otsu / 2, otsu) -> edges (and the Otsu levels)"""
+        n, h, w = self._shape(bgr, 3)
+        p, sp, keep = _in(bgr)
+        edges, ep, osp = self._out(bgr, tuple(bgr.shape[:-1]), np.uint8)
+        otsu = np.zeros(n, np.float64)
+        self._chk(lib().ck_goban_canny(self._h, p, n, h, w, sp, ep, osp, otsu.ctypes.data_as(C.c_void_p)))
+        return (edges, otsu) if want_otsu else edges
 
     # ---- K2 ---------------------------------------------------------------------------------
     def canny(self, img3, low=25, high=75, want_map=False):

@@ -3,6 +3,10 @@
 // which the stage kernels are launched on the context's stream.
 #include <stdarg.h>
 
+#include <cfloat>
+#include <cmath>
+#include <algorithm>
+#include <vector>
 #include "ck_common.h"
 
 thread_local std::string g_ck_create_error;
@@ -183,14 +187,20 @@ static int finish(ck_ctx* ctx)
 
 int ck_median15(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space, uint8_t* out, int out_space)
 {
+    return ck_median(ctx, bgr, n, h, w, 15, in_space, out, out_space);
+}
+
+int ck_median(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int ksize, int in_space, uint8_t* out, int out_space)
+{
     CK_TRY(check_img(ctx, bgr, n, h, w));
     if (!out) return ck_fail(ctx, CK_ERR_ARG, "out is NULL");
+    if (ksize < 3 || ksize > 17 || !(ksize & 1)) return ck_fail(ctx, CK_ERR_ARG, "median window %d: odd sizes 3..17 only", ksize);
     const size_t bytes = (size_t)n * h * w * 3;
     const int pitch = ck_pitch(w);
     const void* d_in;
     CK_TRY(ck_to_device(ctx, bgr, bytes, in_space, ctx->in_stage, &d_in));
     CK_TRY(ck_ensure(ctx, ctx->planes, (size_t)n * 3 * h * pitch));
-    CK_TRY(k_median15_planar(ctx, (const uint8_t*)d_in, n, h, w, (uint8_t*)ctx->planes.p, pitch));
+    CK_TRY(k_median_planar(ctx, (const uint8_t*)d_in, n, h, w, ksize, (uint8_t*)ctx->planes.p, pitch));
     uint8_t* d_out = out;
     if (out_space == CK_HOST) { CK_TRY(ck_ensure(ctx, ctx->out_stage, bytes)); d_out = (uint8_t*)ctx->out_stage.p; }
     CK_TRY(k_planar_to_interleaved(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, d_out));
@@ -223,6 +233,71 @@ int ck_canny(ck_ctx* ctx, const uint8_t* img3, int n, int h, int w, int in_space
         CK_TRY(ck_from_device(ctx, edges, d_edges, npx, CK_HOST));
         if (map_out) CK_TRY(ck_from_device(ctx, map_out, d_mapout, npx, CK_HOST));
     }
+    return finish(ctx);
+}
+
+// OpenCV's getThreshVal_Otsu_8u restated (double arithmetic, the FLT_EPSILON guards, first maximum wins)
+static double otsu_level(const int* hist, size_t npx)
+{
+    double mu = 0, scale = 1. / (double)npx;
+    for (int i = 0; i < 256; i++) mu += i * (double)hist[i];
+    mu *= scale;
+    double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+    for (int i = 0; i < 256; i++) {
+        const double p_i = hist[i] * scale;
+        mu1 *= q1;
+        q1 += p_i;
+        const double q2 = 1. - q1;
+        if (std::min(q1, q2) < FLT_EPSILON || std::max(q1, q2) > 1. - FLT_EPSILON) continue;
+        mu1 = (mu1 + i * p_i) / q1;
+        const double mu2 = (mu - q1 * mu1) / q2;
+        const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+        if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+    }
+    return max_val;
+}
+
+int ck_goban_canny(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space, uint8_t* edges, int out_space,
+                   double* otsu_out)
+{
+    CK_TRY(check_img(ctx, bgr, n, h, w));
+    if (!edges) return ck_fail(ctx, CK_ERR_ARG, "edges is NULL");
+    const size_t npx1 = (size_t)h * w, npx = (size_t)n * npx1;
+    const int pitch = ck_pitch(w);
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, bgr, npx * 3, in_space, ctx->in_stage, &d_in));
+    CK_TRY(ck_ensure(ctx, ctx->planes, (size_t)n * 3 * h * pitch));
+    CK_TRY(ck_ensure(ctx, ctx->out_stage, npx * 3));
+    // medianBlur 13, then 7 (the kernel reads interleaved BGR and writes planes)
+    CK_TRY(k_median_planar(ctx, (const uint8_t*)d_in, n, h, w, 13, (uint8_t*)ctx->planes.p, pitch));
+    CK_TRY(k_planar_to_interleaved(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, (uint8_t*)ctx->out_stage.p));
+    CK_TRY(k_median_planar(ctx, (const uint8_t*)ctx->out_stage.p, n, h, w, 7, (uint8_t*)ctx->planes.p, pitch));
+    // grey histogram per frame -> Otsu level on the host (256 bins, double arithmetic as the library does it)
+    CK_TRY(ck_ensure(ctx, ctx->misc, (size_t)n * 256 * 4 + (size_t)n * 64 + 4096));
+    int* d_hist = (int*)ctx->misc.p;
+    CK_TRY(k_gray_hist(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, d_hist));
+    std::vector<int> hist((size_t)n * 256);
+    CK_HIP(ctx, hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CK_TRY(ck_ensure(ctx, ctx->map, npx));
+    CK_TRY(ck_ensure(ctx, ctx->labels, npx * 4));
+    uint8_t* d_edges = edges;
+    if (out_space == CK_HOST) { CK_TRY(ck_ensure(ctx, ctx->edges, npx)); d_edges = (uint8_t*)ctx->edges.p; }
+    // cv2.Canny(median, otsu / 2, otsu): thresholds are floored (L1 gradient); one pair per frame, one batched call
+    std::vector<int> thr((size_t)n * 2);
+    for (int f = 0; f < n; f++) {
+        const double otsu = otsu_level(&hist[(size_t)f * 256], npx1);
+        if (otsu_out) otsu_out[f] = otsu;
+        thr[2 * f] = (int)std::floor(otsu / 2);
+        thr[2 * f + 1] = (int)std::floor(otsu);
+    }
+    CK_TRY(ck_ensure(ctx, ctx->mats, (size_t)n * 8 + 1024));
+    int* d_thr = (int*)ctx->mats.p;
+    CK_HIP(ctx, hipMemcpyAsync(d_thr, thr.data(), thr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));           // thr is a local: the copy must be done before it goes
+    CK_TRY(k_canny_planar(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, 0, 0, (uint8_t*)ctx->map.p,
+                          (int32_t*)ctx->labels.p, d_edges, nullptr, nullptr, d_thr));
+    if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, edges, d_edges, npx, CK_HOST));
     return finish(ctx);
 }
 

@@ -120,12 +120,15 @@ static inline int ck_pitch(int w) { return (w + 63) & ~63; }
 
 // ---- kernels (one launcher per stage; all asynchronous on ctx->stream) -----------------
 int k_median15_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, uint8_t* d_planes, int pitch);
+int k_gray_hist(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, int* d_hist);
+int k_median_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int ksize, uint8_t* d_planes, int pitch);
 int k_planar_to_interleaved(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, uint8_t* d_out);
 int k_interleaved_to_planar(ck_ctx* ctx, const uint8_t* d_in, int n, int h, int w, int pitch, uint8_t* d_planes);
 // canny: planar 3-channel input -> map (0/1/2) -> edges (0/255); labels = scratch n*h*w int32
 // d_border_flag (nullable, n ints): set to 1 for frames that have an edge pixel on the image frame
 int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, int low, int high,
-                   uint8_t* d_map, int32_t* d_labels, uint8_t* d_edges, uint8_t* d_map_out, int* d_border_flag = nullptr);
+                   uint8_t* d_map, int32_t* d_labels, uint8_t* d_edges, uint8_t* d_map_out, int* d_border_flag = nullptr,
+                   const int* d_thr = nullptr /* per-frame (low, high) pairs on the device, override low / high */);
 int k_i420_to_bgr(ck_ctx* ctx, const uint8_t* d_i420, int n, int h, int w, uint8_t* d_bgr);
 int k_warp(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, const double* d_minv, int m_count,
            int dsize, uint8_t* d_out);

@@ -28,8 +28,10 @@ constexpr int MW = TW + 2, MH = TH + 2;     // magnitude tile with 1-px halo
 __global__ __launch_bounds__(256) void canny_nms_kernel(const uint8_t* __restrict__ planes, int h, int w, int pitch,
                                                         int low, int high, uint8_t* __restrict__ map,
                                                         int32_t* __restrict__ labels, int32_t* __restrict__ cand,
-                                                        int* __restrict__ cand_count)
+                                                        int* __restrict__ cand_count,
+    const int* __restrict__ thr /* nullable: per-frame (low, high) pairs */)
 {
+    if (thr) { low = thr[2 * blockIdx.z]; high = thr[2 * blockIdx.z + 1]; }
     // pixel tile: columns ox-4 .. ox+67 (18 aligned dwords per row), rows oy-2 .. oy+17
     __shared__ uint32_t pxw[3][LH][LWD];
     __shared__ int32_t mg[MH][MW + 1];       // mag | sector << 16
@@ -186,8 +188,10 @@ __device__ __forceinline__ u16x2 widen(uint32_t hi, uint32_t lo, uint32_t sel)
 __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __restrict__ planes, int h, int w, int pitch,
                                                                int low, int high, uint8_t* __restrict__ map,
                                                                int32_t* __restrict__ labels, int32_t* __restrict__ cand,
-                                                               int* __restrict__ cand_count, uint8_t* __restrict__ edges_zero)
+                                                               int* __restrict__ cand_count, uint8_t* __restrict__ edges_zero,
+    const int* __restrict__ thr /* nullable: per-frame (low, high) pairs */)
 {
+    if (thr) { low = thr[2 * blockIdx.z]; high = thr[2 * blockIdx.z + 1]; }
     // pixel tile: columns ox-4 .. ox+67 (18 aligned dwords per row), rows oy-2 .. oy+PTH+1, border replicated.
     // The candidate buffer of the last phase reuses its space.
     constexpr int PXW = 3 * PLH * LWD, CBUF = PTH * TW;
@@ -509,7 +513,8 @@ __global__ __launch_bounds__(256) void canny_final_kernel(int h, int w, const in
 }  // namespace
 
 int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, int low, int high,
-                   uint8_t* d_map, int32_t* d_labels, uint8_t* d_edges, uint8_t* d_map_out, int* d_border_flag)
+                   uint8_t* d_map, int32_t* d_labels, uint8_t* d_edges, uint8_t* d_map_out, int* d_border_flag,
+                   const int* d_thr)
 {
     if (low > high) { int t = low; low = high; high = t; }
     const size_t npx = (size_t)n * h * w;
@@ -523,11 +528,11 @@ int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, in
 #if NMS_PACKED
         dim3 grid((w + TW - 1) / TW, (h + PTH - 1) / PTH, n);
         hipLaunchKernelGGL(canny_nms_packed_kernel, grid, dim3(256), 0, ctx->stream, d_planes, h, w, pitch, low, high, d_map,
-                           d_labels, d_cand, d_count, d_edges);
+                           d_labels, d_cand, d_count, d_edges, d_thr);
 #else
         dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, n);
         hipLaunchKernelGGL(canny_nms_kernel, grid, dim3(256), 0, ctx->stream, d_planes, h, w, pitch, low, high, d_map,
-                           d_labels, d_cand, d_count);
+                           d_labels, d_cand, d_count, d_thr);
 #endif
         CK_HIP(ctx, hipGetLastError());
     }

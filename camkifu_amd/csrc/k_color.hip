@@ -81,6 +81,30 @@ __global__ __launch_bounds__(256) void i420_to_bgr_kernel(const uint8_t* __restr
     convert_block<PX>(Y, U, V, w, x, y, dst + (size_t)f * h * w * 3);
 }
 
+// cvtColor(COLOR_BGR2GRAY) of a planar BGR frame (8-bit fixed point: (1868 B + 9617 G + 4899 R + 2^13) >> 14) folded
+// straight into a 256-bin histogram per frame (LDS atomics, one flush per workgroup): the input of the Otsu level of
+// SfContours.get_canny (stone/sf_contours.py:338-339).
+__global__ __launch_bounds__(256) void gray_hist_kernel(const uint8_t* __restrict__ planes, int h, int w, int pitch,
+                                                        int* __restrict__ hist)
+{
+    __shared__ int lh[256];
+    const int f = blockIdx.y;
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint8_t* B = planes + (size_t)f * 3 * h * pitch;
+    const uint8_t* G = B + (size_t)h * pitch;
+    const uint8_t* R = G + (size_t)h * pitch;
+    const int npx = h * w;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npx; i += gridDim.x * 256) {
+        const int y = i / w, x = i - y * w;
+        const int o = y * pitch + x;
+        const int g = (1868 * B[o] + 9617 * G[o] + 4899 * R[o] + (1 << 13)) >> 14;
+        atomicAdd(&lh[g], 1);
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[f * 256 + threadIdx.x], lh[threadIdx.x]);
+}
+
 }  // namespace
 
 int k_i420_to_bgr(ck_ctx* ctx, const uint8_t* d_i420, int n, int h, int w, uint8_t* d_bgr)
@@ -94,6 +118,16 @@ int k_i420_to_bgr(ck_ctx* ctx, const uint8_t* d_i420, int n, int h, int w, uint8
         dim3 grid((w / 2 + 63) / 64, (h / 2 + 3) / 4, n);
         hipLaunchKernelGGL(i420_to_bgr_kernel<2>, grid, dim3(256), 0, ctx->stream, d_i420, h, w, d_bgr);
     }
+    CK_HIP(ctx, hipGetLastError());
+    return CK_OK;
+}
+
+int k_gray_hist(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, int* d_hist)
+{
+    CK_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)n * 256 * 4, ctx->stream));
+    int blocks = (h * w + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(gray_hist_kernel, dim3(blocks, n), dim3(256), 0, ctx->stream, d_planes, h, w, pitch, d_hist);
     CK_HIP(ctx, hipGetLastError());
     return CK_OK;
 }

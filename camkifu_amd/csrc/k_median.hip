@@ -221,7 +221,7 @@ constexpr int MT = 48;      // medians per tile edge
 struct BandTable {
     uint32_t v[5 * 64 * 4];  // [vertical band for output-row tile 0..2 | horizontal band, same / next column tile][lane][4]
 };
-constexpr BandTable make_band_table()
+constexpr BandTable make_band_table(int K)
 {
     BandTable T{};
     for (int lane = 0; lane < 64; lane++) {
@@ -232,7 +232,7 @@ constexpr BandTable make_band_table()
                 for (int e = 0; e < 4; e++) {
                     const int y_in = 16 * g + 4 * d + e;          // pass 1: k position (g, 4d+e) <-> input row
                     const int dv = y_in - (16 * t + n);
-                    if (dv >= 0 && dv <= 14) wv |= 0xFCu << (8 * e);     // -4
+                    if (dv >= 0 && dv <= K - 1) wv |= 0xFCu << (8 * e);  // -4
                 }
                 T.v[(t * 64 + lane) * 4 + d] = wv;
             }
@@ -241,12 +241,13 @@ constexpr BandTable make_band_table()
                 // pass 2: dword e of the A operand is the raw i32 of column 4g + e of column tile u + k; its byte 1
                 // carries the value.  Output column n of tile u.
                 const int dh = 16 * k + 4 * g + e - n;
-                T.v[((3 + k) * 64 + lane) * 4 + e] = (dh >= 0 && dh <= 14) ? (0x80u << 8) : 0u;     // -128
+                T.v[((3 + k) * 64 + lane) * 4 + e] = (dh >= 0 && dh <= K - 1) ? (0x80u << 8) : 0u;  // -128
             }
     }
     return T;
 }
-__device__ const BandTable g_band = make_band_table();
+template <int K>
+__device__ const BandTable g_band = make_band_table(K);
 
 __device__ __forceinline__ int imed3(int a, int b, int c)
 {
@@ -257,9 +258,13 @@ __device__ __forceinline__ int imed3(int a, int b, int c)
 
 // waves_per_eu(3): a register budget below 256 makes the compiler pick the MFMA forms that write VGPRs; with the
 // default budget the results land in AGPRs and every one of them costs a v_accvgpr_read.
-__attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void median15_mfma_kernel(
+// K = window edge (odd, 3..17: a 64-pixel input tile must cover 48 + K - 1); rank (K*K+1)/2, halo K/2.
+template <int K>
+__attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void median_mfma_kernel(
     const uint8_t* __restrict__ in, int h, int w, uint8_t* __restrict__ out, int pitch)
 {
+    static_assert(K % 2 == 1 && K >= 3 && MT + K - 1 <= 64, "window size");
+    constexpr int HK = K / 2, RANK = (K * K + 1) / 2;
     __shared__ uint32_t flags[64];
     const int lane = threadIdx.x;
     const int n = lane & 15, g = lane >> 4;
@@ -267,11 +272,11 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
     const int f = blockIdx.z / 3, c = blockIdx.z % 3;
     const uint8_t* src = in + (size_t)f * h * w * 3 + c;
 
-    // ---- load: column tile i, lane (n, g) <- column ox - 7 + 16 i + n, rows oy - 7 + 16 g + 0..15 (replicate border)
+    // ---- load: column tile i, lane (n, g) <- column ox - K/2 + 16 i + n, rows oy - K/2 + 16 g + 0..15 (replicate border)
     v4i nx[4];
-    if (ox >= 7 && ox + 56 < w && oy >= 7 && oy + 56 < h) {
+    if (ox >= HK && ox - HK + 63 < w && oy >= HK && oy - HK + 63 < h) {
         // interior tile: one per-lane offset, everything else is wave-uniform (scalar base + immediate)
-        const uint8_t* base = src + ((size_t)(oy - 7) * w + (ox - 7)) * 3;
+        const uint8_t* base = src + ((size_t)(oy - HK) * w + (ox - HK)) * 3;
         uint32_t voff = (uint32_t)((16 * g * w + n) * 3);
         asm volatile("" : "+v"(voff));          // keep it one per-lane offset: scalar base + voff + immediate per load
 #pragma unroll
@@ -291,13 +296,13 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
         int yo[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            int y = oy - 7 + 16 * g + j;
+            int y = oy - HK + 16 * g + j;
             y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
             yo[j] = y * w * 3;
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            int x = ox - 7 + 16 * i + n;
+            int x = ox - HK + 16 * i + n;
             x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
             const uint8_t* col = src + x * 3;
 #pragma unroll
@@ -308,14 +313,14 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
             }
         }
     }
-    const v4i* bt = reinterpret_cast<const v4i*>(g_band.v);
+    const v4i* bt = reinterpret_cast<const v4i*>(g_band<K>.v);
     v4i bv[3], bh[2];
 #pragma unroll
     for (int t = 0; t < 3; t++) bv[t] = bt[t * 64 + lane];
 #pragma unroll
     for (int k = 0; k < 2; k++) bh[k] = bt[(3 + k) * 64 + lane];
     const v4i zero = {0, 0, 0, 0};
-    const v4i c113 = {256 * 113, 256 * 113, 256 * 113, 256 * 113};
+    const v4i c113 = {256 * RANK, 256 * RANK, 256 * RANK, 256 * RANK};      // 113 for the 15x15 window
 
     int med[3][3][4];
 #pragma unroll
@@ -437,18 +442,30 @@ __global__ void interleaved_to_planar_kernel(const uint8_t* __restrict__ in, int
 
 }  // namespace
 
-int k_median15_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, uint8_t* d_planes, int pitch)
+int k_median_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int ksize, uint8_t* d_planes, int pitch)
 {
     TimeScope ts(ctx, "median");
 #if MED_MFMA
     dim3 grid((w + MT - 1) / MT, (h + MT - 1) / MT, n * 3);
-    hipLaunchKernelGGL(median15_mfma_kernel, grid, dim3(64), 0, ctx->stream, d_bgr, h, w, d_planes, pitch);
+#define CK_MEDIAN_CASE(KS) case KS: hipLaunchKernelGGL(median_mfma_kernel<KS>, grid, dim3(64), 0, ctx->stream, d_bgr, h, w, d_planes, pitch); break;
+    switch (ksize) {
+        CK_MEDIAN_CASE(3) CK_MEDIAN_CASE(5) CK_MEDIAN_CASE(7) CK_MEDIAN_CASE(9) CK_MEDIAN_CASE(11) CK_MEDIAN_CASE(13)
+        CK_MEDIAN_CASE(15) CK_MEDIAN_CASE(17)
+    default: return ck_fail(ctx, CK_ERR_ARG, "median window %d: odd sizes 3..17 only", ksize);
+    }
+#undef CK_MEDIAN_CASE
 #else
+    if (ksize != 15) return ck_fail(ctx, CK_ERR_ARG, "the SWAR median kernel is 15x15 only");
     dim3 grid((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H, n * 3);
     hipLaunchKernelGGL(median15_kernel, grid, dim3(64), 0, ctx->stream, d_bgr, h, w, d_planes, pitch);
 #endif
     CK_HIP(ctx, hipGetLastError());
     return CK_OK;
+}
+
+int k_median15_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, uint8_t* d_planes, int pitch)
+{
+    return k_median_planar(ctx, d_bgr, n, h, w, 15, d_planes, pitch);
 }
 
 int k_planar_to_interleaved(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, uint8_t* d_out)

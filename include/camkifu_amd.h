@@ -65,12 +65,23 @@ int  ck_timing_get(ck_ctx* ctx, const char* name, double* total_ms, int* launche
 /* ---- K1  cv2.medianBlur(frame, 15)                              board/bf_auto.py:72 */
 int ck_median15(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
                 uint8_t* out, int out_space);
+/*          cv2.medianBlur(img, ksize), ksize odd in 3..17 (13 and 7 are SfContours.get_canny's,
+ *          stone/sf_contours.py:336-337); same exact median, replicate border */
+int ck_median(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int ksize, int in_space,
+              uint8_t* out, int out_space);
 
 /* ---- K2  cv2.Canny(median, low, high)  3-channel, aperture 3, L1  board/bf_auto.py:73
  * map_out (optional, same space as edges): NMS map before hysteresis
  * (0 candidate, 1 suppressed, 2 strong). */
 int ck_canny(ck_ctx* ctx, const uint8_t* img3, int n, int h, int w, int in_space,
              int low, int high, uint8_t* edges, uint8_t* map_out, int out_space);
+
+/* ---- SfContours.get_canny(img)                 stone/sf_contours.py:332-340
+ *   median = medianBlur(medianBlur(img, 13), 7); otsu = threshold(cvtColor(median, BGR2GRAY), 12, 255, THRESH_OTSU)[0];
+ *   return Canny(median, otsu / 2, otsu)
+ * edges: n*h*w bytes {0,255}; otsu_out (nullable, host): n doubles, the Otsu levels used */
+int ck_goban_canny(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
+                   uint8_t* edges, int out_space, double* otsu_out);
 
 /* ---- K1+K2 fused pipeline: the "filter pass"                  board/bf_auto.py:72-73 */
 int ck_board_edges(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,

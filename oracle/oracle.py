@@ -62,6 +62,46 @@ def median(img, ksize=15):
     return out
 
 
+def bgr2gray(img):
+    """cv2.cvtColor(img, COLOR_BGR2GRAY) for 8-bit images: 14-bit fixed point, rounded
+    (reference call site: stone/sf_contours.py:338)"""
+    a = np.asarray(img, np.uint8).astype(np.int64)
+    return ((1868 * a[..., 0] + 9617 * a[..., 1] + 4899 * a[..., 2] + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def otsu_level(gray):
+    """the level cv2.threshold(gray, _, 255, THRESH_OTSU) returns: the library's getThreshVal_Otsu_8u restated
+    (double arithmetic, FLT_EPSILON guards, the first maximum of the between-class variance wins)"""
+    hist = np.bincount(np.asarray(gray, np.uint8).ravel(), minlength=256).astype(np.float64)
+    scale = 1.0 / gray.size
+    mu = float((np.arange(256) * hist).sum()) * scale
+    eps = float(np.finfo(np.float32).eps)
+    mu1 = q1 = 0.0
+    max_sigma, max_val = 0.0, 0
+    for i in range(256):
+        p_i = hist[i] * scale
+        mu1 *= q1
+        q1 += p_i
+        q2 = 1.0 - q1
+        if min(q1, q2) < eps or max(q1, q2) > 1.0 - eps:
+            continue
+        mu1 = (mu1 + i * p_i) / q1
+        mu2 = (mu - q1 * mu1) / q2
+        sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2)
+        if sigma > max_sigma:
+            max_sigma, max_val = sigma, i
+    return float(max_val)
+
+
+def goban_canny(img, want_otsu=False):
+    """SfContours.get_canny (stone/sf_contours.py:332-340): medianBlur 13, medianBlur 7, Otsu level of the grey
+    image, Canny(median, otsu / 2, otsu) with the thresholds floored as cv2.Canny does for the L1 gradient"""
+    m = median(median(img, 13), 7)
+    otsu = otsu_level(bgr2gray(m))
+    e = canny(m, int(np.floor(otsu / 2)), int(np.floor(otsu)))
+    return (e, otsu) if want_otsu else e
+
+
 def canny(img, low=25, high=75, want_map=False):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape[:2]

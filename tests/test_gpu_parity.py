@@ -50,6 +50,42 @@ def test_median_interior_tiles_worst_case(ck, ora):
     assert np.array_equal(ck.median15(img), ora.median(img, 15))
 
 
+@pytest.mark.parametrize("ksize", [3, 5, 7, 9, 11, 13, 17])
+def test_median_other_windows(ck, ora, ksize):
+    """the same kernel with other odd windows (SfContours.get_canny uses 13 and 7): noise, smooth, tiny"""
+    rng = np.random.default_rng(100 + ksize)
+    for (h, w) in [(90, 140), (5, 9), (49, 97)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(ck.median(img, ksize), ora.median(img, ksize)), (ksize, h, w)
+    img = _smooth_rand(rng, 130, 110)
+    assert np.array_equal(ck.median(img, ksize), ora.median(img, ksize))
+
+
+def test_median_rejects_unsupported_windows(ck):
+    img = np.zeros((20, 20, 3), np.uint8)
+    for k in (1, 4, 19):
+        with pytest.raises(RuntimeError):
+            ck.median(img, k)
+
+
+def test_goban_canny_matches_oracle(ck, ora, synth):
+    """SfContours.get_canny: median 13, median 7, Otsu level of the grey image, Canny(otsu / 2, otsu)"""
+    sc = synth.scene(480, 640, seed=12, density=0.4)
+    dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
+    goban = ora.warp_perspective(sc["frame"].numpy(), ora.get_perspective_transform(sc["corners"], dst))
+    rng = np.random.default_rng(13)
+    noisy = rng.integers(0, 256, (380, 380, 3), dtype=np.uint8)
+    noisy[100:300, 80:250] = (200, 190, 180)
+    batch = np.stack([goban, noisy, np.full((380, 380, 3), 90, np.uint8)])
+    edges, otsu = ck.goban_canny(batch, want_otsu=True)
+    for k in range(len(batch)):
+        e2, o2 = ora.goban_canny(batch[k], want_otsu=True)
+        assert otsu[k] == o2, (k, otsu[k], o2)
+        assert np.array_equal(edges[k], e2), k
+    small = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(ck.goban_canny(small), ora.goban_canny(small))
+
+
 def test_median_extremes_and_batch(ck, ora):
     rng = np.random.default_rng(11)
     imgs = np.stack([np.zeros((40, 70, 3), np.uint8), np.full((40, 70, 3), 255, np.uint8),

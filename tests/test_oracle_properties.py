@@ -377,3 +377,43 @@ def test_cnn_region_slicing(ora):
     y2 = ora.cnn_forward(W, np.stack(patches))
     for k, (i, j) in enumerate(idx):
         assert np.array_equal(y[i * 10 + j], y2[k])
+
+# ---------------------------------------------------------------- SfContours.get_canny pieces
+def test_bgr2gray_matches_float_formula_within_rounding(ora):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (40, 50, 3), dtype=np.uint8)
+    g = ora.bgr2gray(img).astype(np.float64)
+    f = 0.114 * img[..., 0] + 0.587 * img[..., 1] + 0.299 * img[..., 2]
+    assert np.abs(g - f).max() <= 0.51              # 14-bit coefficients, round to nearest
+    assert (ora.bgr2gray(np.full((2, 2, 3), 255, np.uint8)) == 255).all() and (ora.bgr2gray(np.zeros((2, 2, 3), np.uint8)) == 0).all()
+
+
+def test_otsu_level_maximises_between_class_variance(ora):
+    """independent restatement: brute force over all 256 cuts with exact class statistics"""
+    rng = np.random.default_rng(6)
+    for k in range(6):
+        a = np.clip(rng.normal(70 + 10 * k, 12, 3000), 0, 255)
+        b = np.clip(rng.normal(180 - 8 * k, 20, 2000 + 300 * k), 0, 255)
+        g = np.concatenate([a, b]).astype(np.uint8).reshape(50, -1)
+        lvl = int(ora.otsu_level(g))
+        v = g.ravel().astype(np.float64)
+        best, arg = -1.0, 0
+        for t in range(256):
+            lo, hi = v[v <= t], v[v > t]
+            if len(lo) == 0 or len(hi) == 0:
+                continue
+            s = len(lo) * len(hi) * (lo.mean() - hi.mean()) ** 2
+            if s > best * (1 + 1e-12):
+                best, arg = s, t
+        assert lvl == arg, (k, lvl, arg)
+    assert ora.otsu_level(np.full((8, 8), 77, np.uint8)) == 0.0          # one class only: nothing beats sigma = 0
+
+
+def test_goban_canny_chain_is_its_parts(ora):
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (64, 70, 3), dtype=np.uint8)
+    img[16:48, 20:50] = (30, 40, 50)
+    e, otsu = ora.goban_canny(img, want_otsu=True)
+    m = ora.median(ora.median(img, 13), 7)
+    assert otsu == ora.otsu_level(ora.bgr2gray(m))
+    assert np.array_equal(e, ora.canny(m, int(otsu // 2), int(otsu)))
