@@ -11,7 +11,7 @@ import json
 import sys
 
 STAGE = [("median15", "median", None), ("canny_nms", "canny_nms", None),
-         ("prep_rows", "ccl_prep_rows", None), ("hough_vote_kernel", "hough_vote", None),
+         ("prep_rows", "ccl_prep_rows", None), ("hough_vote", "hough_vote", None),
          ("warp_kernel", "warp", None),
          ("conv1_", "cnn_conv1", 128), ("_kernel<36, 36, 32", "cnn_conv2", 128), ("conv34_h2_kernel", "cnn_conv4", 128),
          ("_kernel<16, 16, 32", "cnn_conv3", 128), ("_kernel<14, 14, 9", "cnn_conv4", 128)]
