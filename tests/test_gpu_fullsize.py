@@ -1,0 +1,159 @@
+"""BASELINE configs 3, 4 and 5 at their real sizes.
+
+Config 3: a 256-frame 1080p batch in ONE call of each C-ABI entry point and as two 128-frame lanes
+(what bench.py launches); config 4 geometry: a 64-frame 4K call (same 2.12 GB int32 parent image);
+config 5: the bf16 classifier's labels against the ORACLE's labels on the trained weights.
+Too big for the oracle as a whole, so the checks are the size-independent ones (determinism,
+alone == in batch at the ends and at every internal chunk boundary, permutation equivariance) plus
+oracle spot checks of single frames.  One frame more than the parent image can index must come
+back as CK_ERR_CAPACITY / CK_ERR_ARG or work -- never wrap."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DST = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
+
+
+@pytest.fixture(scope="module")
+def ck():
+    from camkifu_amd import capi
+    ctx = capi.Context(0)
+    yield ctx
+    ctx.close()
+
+
+def _render_batch(synth, n, H, W, seed, distinct=9):
+    """n frames in HBM: `distinct` different positions rendered with per-frame noise seeds"""
+    import torch
+    rng = np.random.default_rng(seed)
+    corners = synth.random_corners(H, W, rng)
+    dev = torch.device("cuda:0")
+    frames = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+    for i in range(n):
+        stones = synth.random_stones(np.random.default_rng(seed + i % distinct), density=0.05 * (i % distinct))
+        frames[i] = synth.render(H, W, stones, corners, seed=seed * 7 + i, device=dev)
+    return frames, corners
+
+
+def _oracle_frame(ora, fr, M, W8):
+    e = ora.canny(ora.median(fr, 15), 25, 75)
+    res = ora.board_lines(e)
+    lab, _ = ora.decode_all(ora.cnn_predict_regions(W8, ora.warp_perspective(fr, M)))
+    return res, lab
+
+
+def test_config3_256_frames_one_call_and_two_lanes(ck, ora):
+    import torch
+    from camkifu_amd import synth
+    from camkifu_amd.stone.nn_manager import NNManager
+    n, H, W = 256, 1080, 1920
+    frames, corners = _render_batch(synth, n, H, W, seed=311)
+    W8 = NNManager.init_net()
+    ck.cnn_set_weights(W8)
+    M = ora.get_perspective_transform(corners, DST)
+
+    rec, lines = ck.board_detect(frames, raw=True)                       # ONE 256-frame call
+    labels, conf = ck.stones_detect(frames, M)
+    labels, conf = labels.cpu().numpy(), conf.cpu().numpy()
+    assert (rec["status"] == 0).all() and (rec["n_lines"] >= 3).all()
+    # determinism of the full-size call
+    rec2, lines2 = ck.board_detect(frames, raw=True)
+    assert np.array_equal(rec, rec2) and np.array_equal(lines, lines2)
+    # two 128-frame lanes (bench.py's launch shape) == the one call
+    for lo in (0, 128):
+        r, l = ck.board_detect(frames[lo:lo + 128], raw=True)
+        assert np.array_equal(r, rec[lo:lo + 128]) and np.array_equal(l, lines[lo:lo + 128]), lo
+        la, ca = ck.stones_detect(frames[lo:lo + 128], M)
+        assert np.array_equal(la.cpu().numpy(), labels[lo:lo + 128]) and np.array_equal(ca.cpu().numpy(), conf[lo:lo + 128])
+    # alone == in batch: both ends and both sides of the 128-frame chunk boundary of the classifier
+    for i in (0, 127, 128, 255):
+        r1, l1 = ck.board_detect(frames[i:i + 1], raw=True)
+        assert np.array_equal(r1[0], rec[i]) and np.array_equal(l1[0], lines[i]), i
+        la, ca = ck.stones_detect(frames[i:i + 1], M)
+        assert np.array_equal(la.cpu().numpy()[0], labels[i]) and np.array_equal(ca.cpu().numpy()[0], conf[i]), i
+    # permutation equivariance at full size
+    p = np.random.default_rng(5).permutation(n)
+    perm = torch.from_numpy(p).to(frames.device)
+    shuffled = frames[perm].contiguous()
+    recp, linesp = ck.board_detect(shuffled, raw=True)
+    assert np.array_equal(recp, rec[p]) and np.array_equal(linesp, lines[p])
+    lp, cp = ck.stones_detect(shuffled, M)
+    assert np.array_equal(lp.cpu().numpy(), labels[p]) and np.array_equal(cp.cpu().numpy(), conf[p])
+    del shuffled
+    # oracle spot checks: first, both sides of the chunk boundary, last
+    for i in (0, 127, 128, 255):
+        res, lab = _oracle_frame(ora, frames[i].cpu().numpy(), M, W8)
+        k = int(rec["n_lines"][i])
+        assert res["status"] == k and np.array_equal(res["lines"][:k], lines[i, :k]), i
+        assert res["n_contours"] == rec["n_contours"][i] and res["biggest_area"] == rec["biggest_area"][i]
+        assert np.array_equal(labels[i], lab), i
+
+
+def test_more_frames_than_the_parent_image_can_index(ck):
+    """257 frames of 1080p need a 2.13 GB int32 parent image (> 2^31 bytes): the call must either work
+    (64-bit offsets everywhere) or refuse with a status code; a wrapped offset would corrupt or fault"""
+    import torch
+    from camkifu_amd import capi, synth
+    H, W = 1080, 1920
+    one, _ = _render_batch(synth, 1, H, W, seed=99)
+    frames = one.expand(257, H, W, 3).contiguous()
+    try:
+        rec, lines = ck.board_detect(frames, raw=True)
+    except capi.CkError as err:
+        assert "error 3" in str(err) or "error 1" in str(err), err          # CK_ERR_CAPACITY / CK_ERR_ARG
+        return
+    # it worked: all 257 results must equal the single-frame result
+    r1, l1 = ck.board_detect(one, raw=True)
+    assert (rec == r1[0]).all() and (lines == l1[0][None]).all()
+
+
+def test_config4_64_frames_of_4k(ck, ora):
+    from camkifu_amd import synth
+    from camkifu_amd.stone.nn_manager import NNManager
+    n, H, W = 64, 2160, 3840
+    frames, corners = _render_batch(synth, n, H, W, seed=444, distinct=5)
+    W8 = NNManager.init_net()
+    ck.cnn_set_weights(W8)
+    M = ora.get_perspective_transform(corners, DST)
+    rec, lines = ck.board_detect(frames, raw=True)
+    labels, conf = ck.stones_detect(frames, M)
+    labels = labels.cpu().numpy()
+    rec2, lines2 = ck.board_detect(frames, raw=True)
+    assert np.array_equal(rec, rec2) and np.array_equal(lines, lines2)
+    for i in (0, 31, 63):
+        r1, l1 = ck.board_detect(frames[i:i + 1], raw=True)
+        assert np.array_equal(r1[0], rec[i]) and np.array_equal(l1[0], lines[i]), i
+    # one oracle spot check (a 4K frame takes the oracle ~10 s)
+    i = 63
+    res, lab = _oracle_frame(ora, frames[i].cpu().numpy(), M, W8)
+    k = int(rec["n_lines"][i])
+    assert res["status"] == k and np.array_equal(res["lines"][:k], lines[i, :k])
+    assert np.array_equal(labels[i], lab)
+
+
+def test_config5_bf16_labels_against_the_oracle(ck, ora):
+    """BASELINE config 5 ("stone-CNN in bf16 on MFMA") must still give bit-identical 19x19 grids: the bf16
+    mode's LABELS are compared with the ORACLE's labels (f32 scalar chain) on the trained weights, over
+    gobans of every density; zero flips is the bar.  The softmax outputs are only loosely bounded."""
+    from camkifu_amd import capi, synth
+    from camkifu_amd.stone.nn_manager import NNManager
+    W8 = NNManager.init_net()
+    ck.cnn_set_weights(W8)
+    gobans = []
+    for seed in range(12):
+        sc = synth.scene(480, 640, seed=900 + seed, density=0.05 * seed)
+        gobans.append(ora.warp_perspective(sc["frame"].numpy(), ora.get_perspective_transform(sc["corners"], DST)))
+    gobans = np.stack(gobans)
+    ck.cnn_set_mode(capi.CK_CNN_BF16)
+    try:
+        y16, l16, c16 = ck.cnn_predict(gobans)
+    finally:
+        ck.cnn_set_mode(capi.CK_CNN_DEFAULT)
+    flips = 0
+    for g in range(len(gobans)):
+        yo = ora.cnn_predict_regions(W8, gobans[g])
+        lo, co = ora.decode_all(yo)
+        flips += int((lo != l16[g]).sum())
+        assert np.abs(yo - y16[g]).max() < 0.05
+    assert flips == 0, "bf16 classifier flips %d labels against the oracle" % flips
