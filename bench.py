@@ -356,7 +356,7 @@ def main():
                 a=["%s%d,%d" % m for m in true_moves],
                 b=["%s%d,%d" % (m.color, m.y, m.x) for m in pipe.stones.controller.kifu.moves[:len(true_moves)]]).ratio(), 4),
             "stone_grid_match_pct": round(100.0 * float((labels.cpu().numpy() == truth).mean()), 3),
-            "cnn_weights": "trained on synthetic boards (tests/golden/keras.h5, Keras-1 HDF5 layout)" if os.path.isfile(GOLDEN_WEIGHTS)
+            "cnn_weights": "trained on synthetic boards (camkifu_amd/data/keras.h5, Keras-1 HDF5 layout)" if os.path.isfile(GOLDEN_WEIGHTS)
                            else "seeded random (labels meaningless)",
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -26,6 +26,10 @@ EXPORTS = [
     "ck_i420_to_bgr", "ck_get_perspective_transform", "ck_warp_perspective",
     "ck_mog2_create", "ck_mog2_apply", "ck_mog2_destroy",
     "ck_cnn_set_weights", "ck_cnn_set_mode", "ck_cnn_predict", "ck_stones_detect",
+    "ck_cnn_regions", "ck_stones_run", "ck_zone_counts", "ck_mog2_band_run",
+    "ck_ordered_hull", "ck_boardfold_create", "ck_boardfold_destroy", "ck_boardfold_reset", "ck_boardfold_step",
+    "ck_policy_create", "ck_policy_destroy", "ck_policy_run", "ck_policy_get_state", "ck_policy_set_state",
+    "ck_policy_watch",
 ]
 
 WEIGHT_ORDER = ("c1w", "c1b", "c2w", "c2b", "c3w", "c3b", "c4w", "c4b", "d1w", "d1b", "d2w", "d2b")
@@ -79,6 +83,15 @@ def lib():
         L.ck_stream.argtypes = [C.c_void_p]
         L.ck_ctx_destroy.argtypes = [C.c_void_p]
         L.ck_ctx_destroy.restype = None
+        for fn in (L.ck_boardfold_destroy, L.ck_policy_destroy):
+            fn.argtypes = [C.c_void_p]
+            fn.restype = None
+        L.ck_boardfold_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_longlong,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ck_policy_run.argtypes = [C.c_void_p, C.c_int, C.c_longlong] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p]
+        L.ck_policy_get_state.argtypes = [C.c_void_p] * 6
+        L.ck_policy_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.ck_policy_watch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_longlong]
         _lib = L
     return _lib
 
@@ -328,6 +341,57 @@ class Context:
         self._chk(lib().ck_stones_detect(self._h, p, n, h, w, sp, M.ctypes.data_as(C.c_void_p), len(M), lp, cp, osp))
         return labels, conf
 
+    # ---- ordered stones path (feeds PolicyCore) ---------------------------------------------------
+    def cnn_regions(self, goban):
+        """-> (region_label (n, 10, 10) uint8, region_conf (n, 10, 10) float64)"""
+        shp = tuple(goban.shape)
+        n = 1 if len(shp) == 3 else shp[0]
+        p, sp, keep = _in(goban)
+        rl, rlp, osp = self._out(goban, (n, 10, 10), np.uint8)
+        rc, rcp, _ = self._out(goban, (n, 10, 10), np.float64)
+        self._chk(lib().ck_cnn_regions(self._h, p, n, sp, rlp, rcp, osp))
+        return rl, rc
+
+    def stones_run(self, bgr, M, mog2=None, learning_rates=None, want_grid=False):
+        """ordered run of n consecutive frames of one stream -> dict(region_label, region_conf, fgcount[, labels, conf]);
+        fgcount is None without a background model"""
+        n, h, w = self._shape(bgr, 3)
+        p, sp, keep = _in(bgr)
+        M = np.ascontiguousarray(M, np.float64).reshape(-1, 9)
+        rl, rlp, osp = self._out(bgr, (n, 10, 10), np.uint8)
+        rc, rcp, _ = self._out(bgr, (n, 10, 10), np.float64)
+        fg, fgp, lr, lrp = None, None, None, None
+        if mog2 is not None:
+            fg, fgp, _ = self._out(bgr, (n, 19, 19), np.int32)
+            lr = np.ascontiguousarray(learning_rates, np.float64).reshape(n)
+            lrp = lr.ctypes.data_as(C.c_void_p)
+        lab, labp, cf, cfp = None, None, None, None
+        if want_grid:
+            lab, labp, _ = self._out(bgr, (n, 19, 19), np.uint8)
+            cf, cfp, _ = self._out(bgr, (n, 19, 19), np.float64)
+        self._chk(lib().ck_stones_run(self._h, p, n, h, w, sp, M.ctypes.data_as(C.c_void_p), len(M),
+                                      -1 if mog2 is None else int(mog2), lrp, rlp, rcp, fgp, labp, cfp, osp))
+        return dict(region_label=rl, region_conf=rc, fgcount=fg, labels=lab, conf=cf)
+
+    def mog2_band_run(self, handle, band, learning_rates, last_band):
+        """band (n, band_h, 380, 3) of consecutive goban images -> int32 (n, zone rows, 19) foreground counts"""
+        n, bh = int(band.shape[0]), int(band.shape[1])
+        p, sp, keep = _in(band)
+        lr = np.ascontiguousarray(learning_rates, np.float64).reshape(n)
+        out, op, osp = self._out(band, (n, (bh + 19) // 20, 19), np.int32)
+        self._chk(lib().ck_mog2_band_run(self._h, int(handle), p, n, sp, lr.ctypes.data_as(C.c_void_p), int(bool(last_band)),
+                                         op, osp))
+        return out
+
+    def zone_counts(self, mask):
+        """(n, 380, 380) or (380, 380) mask -> int32 (n, 19, 19) / (19, 19) foreground pixels per intersection zone"""
+        single = len(mask.shape) == 2
+        n = 1 if single else int(mask.shape[0])
+        p, sp, keep = _in(mask)
+        out, op, osp = self._out(mask, (19, 19) if single else (n, 19, 19), np.int32)
+        self._chk(lib().ck_zone_counts(self._h, p, n, sp, op, osp))
+        return out
+
 
 def get_perspective_transform(src4, dst4):
     """K7, host only (board/boardfinder.py:43-45)."""
@@ -339,6 +403,121 @@ def get_perspective_transform(src4, dst4):
     if rc != 0:
         raise CkError("degenerate quadrilateral")
     return M.reshape(3, 3)
+
+
+def ordered_hull(points):
+    """imgutil.get_ordered_hull: convex hull of integer (x, y) points, clockwise on screen, nearest to the origin
+    first -> list of (x, y) tuples (host only)"""
+    pts = np.ascontiguousarray(np.asarray(points).reshape(-1, 2), np.int32)
+    out, n = np.zeros((max(1, len(pts)), 2), np.int32), C.c_int32(0)
+    rc = lib().ck_ordered_hull(pts.ctypes.data_as(C.c_void_p), len(pts), out.ctypes.data_as(C.c_void_p), C.byref(n))
+    if rc != 0:
+        raise CkError("ck_ordered_hull: error %d" % rc)
+    return [(int(x), int(y)) for x, y in out[:n.value]]
+
+
+class BoardFoldCore:
+    """ck_boardfold: the ordered half of the automatic board finder (host only, no GPU needed)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        if lib().ck_boardfold_create(C.byref(self._h)) != 0:
+            raise CkError("ck_boardfold_create failed")
+        self._out = np.zeros(16, np.int32)          # found, update, n_centers, pad, centers[8], stats[2]
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ck_boardfold_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def reset(self):
+        lib().ck_boardfold_reset(self._h)
+
+    def step(self, h, w, status, lines, counter, cur_hull):
+        """-> (found, update, centers [(x, y), ...], stats (clusters, intersections) or None)"""
+        lines = np.ascontiguousarray(lines, np.float32).reshape(-1, 2)
+        hull = None if cur_hull is None else np.ascontiguousarray(cur_hull, np.int32).reshape(8)
+        o = self._out
+        base = o.ctypes.data
+        rc = lib().ck_boardfold_step(self._h, int(h), int(w), int(status), lines.ctypes.data_as(C.c_void_p), len(lines),
+                                     int(counter), None if hull is None else hull.ctypes.data_as(C.c_void_p),
+                                     C.c_void_p(base), C.c_void_p(base + 4), C.c_void_p(base + 16), C.c_void_p(base + 8),
+                                     C.c_void_p(base + 48))
+        if rc == 4:
+            raise IndexError("corner hull has fewer than 4 vertices")      # what the reference raises (bf_auto.py:206)
+        if rc != 0:
+            raise CkError("ck_boardfold_step: error %d" % rc)
+        cen = [(int(o[4 + 2 * i]), int(o[5 + 2 * i])) for i in range(int(o[2]))]
+        return bool(o[0]), bool(o[1]), cen, (None if o[12] < 0 else (int(o[12]), int(o[13])))
+
+
+class PolicyCore:
+    """ck_policy: SfNeural's emission policy over ordered runs of frames (host only, no GPU needed)."""
+    SUGGEST, BULK = 1, 2
+
+    def __init__(self, bg_init_frames=50):
+        self._h = C.c_void_p()
+        if lib().ck_policy_create(int(bg_init_frames), C.byref(self._h)) != 0:
+            raise CkError("ck_policy_create failed")
+        self._io = np.zeros(4, np.int32)            # frame, phase, kind, n_moves
+        self._moves = np.zeros((2 * 361, 3), np.int32)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ck_policy_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def run(self, first_counter, region_label, region_conf, fgcount, board_of, apply):
+        """Ordered run over n frames.  `board_of()` -> uint8 (19,19) goban as the controller holds it now;
+        `apply(kind, [(color, r, c), ...], frame_index)` executes a request; if it raises, the run stops there and
+        the rest of that frame is never done -- what an exception out of SfNeural._find means in the reference."""
+        rl = np.ascontiguousarray(region_label, np.uint8).reshape(-1, 100)
+        rc = np.ascontiguousarray(region_conf, np.float64).reshape(-1, 100)
+        n = len(rl)
+        assert len(rc) == n
+        fg = None
+        if fgcount is not None:
+            fg = np.ascontiguousarray(fgcount, np.int32).reshape(n, 361)
+        io, mv = self._io, self._moves
+        io[:] = 0
+        b = io.ctypes.data
+        while True:
+            board = np.ascontiguousarray(board_of(), np.uint8).reshape(361)
+            rcode = lib().ck_policy_run(self._h, n, int(first_counter), rl.ctypes.data_as(C.c_void_p),
+                                        rc.ctypes.data_as(C.c_void_p), None if fg is None else fg.ctypes.data_as(C.c_void_p),
+                                        board.ctypes.data_as(C.c_void_p), C.c_void_p(b), C.c_void_p(b + 4), C.c_void_p(b + 8),
+                                        mv.ctypes.data_as(C.c_void_p), len(mv), C.c_void_p(b + 12))
+            if rcode != 0:
+                raise CkError("ck_policy_run: error %d" % rcode)
+            if io[2] == 0:
+                return
+            # a request made in the first half of frame k leaves (k, 1); a lookback request leaves (k + 1, 0)
+            frame = int(io[0]) if io[1] == 1 else int(io[0]) - 1
+            apply(int(io[2]), [(int(c), int(r), int(k)) for c, r, k in mv[:io[3]]], frame)
+
+    def state(self):
+        t, hc = np.zeros((19, 19), np.uint8), np.zeros((19, 19), np.uint8)
+        he, cf, fl = np.zeros((19, 19), np.int32), np.zeros((19, 19), np.float64), np.zeros(2, np.int32)
+        lib().ck_policy_get_state(self._h, *(a.ctypes.data_as(C.c_void_p) for a in (t, hc, he, cf, fl)))
+        return dict(targets=t, heat_color=hc, heat_energy=he, heat_conf=cf, has_sampled=bool(fl[0]), recolour_seen=int(fl[1]))
+
+    def set_targets(self, targets):
+        t = np.ascontiguousarray(targets, np.uint8).reshape(19, 19)
+        lib().ck_policy_set_state(self._h, t.ctypes.data_as(C.c_void_p), -1)
+
+    def set_sampled(self, flag=True):
+        lib().ck_policy_set_state(self._h, None, int(bool(flag)))
+
+    def watch(self, r, c, color, confidence=0.0, stamp=0):
+        """start (or with color 0: drop) the watch on a prediction, as a fresh HeatPoint would"""
+        if lib().ck_policy_watch(self._h, int(r), int(c), int(color), float(confidence), int(stamp)) != 0:
+            raise CkError("ck_policy_watch: bad arguments")
 
 
 _default_ctx = {}

@@ -254,103 +254,92 @@ def file_frame_indices(nframes, fps, rate=None, start=0):
 
 
 class CaptureReaderBase:
-    """core/vmanager.py:461-525: hijacks `read`; everything else is delegated to the capture.
-    File inputs are read at `fps` frames per second of video (frames in between are skipped)."""
+    """What a manager puts between its finders and the capture: `read(caller)` is taken over, every other
+    attribute is the capture's.  A video FILE is thinned to `fps` analysed frames per second of footage with
+    the reference's arithmetic (core/vmanager.py:510-525; see file_frame_indices); other sources pass through."""
 
     def __init__(self, capture, vmanager, fps=None):
-        self.capture = capture
-        self.vmanager = vmanager
-        self.frame_rate = cvconf.file_fps if fps is None else fps
+        self.__dict__.update(capture=capture, vmanager=vmanager,
+                             frame_rate=cvconf.file_fps if fps is None else fps)
 
-    def __getattr__(self, item):
-        if item == "read":
-            if self.is_file():
-                return lambda caller=None: self.downsample(*self.read_file(caller))
-            return lambda _=None: self.downsample(*self.capture.read())
-        return getattr(self.capture, item)
+    def __getattr__(self, attr):                       # only reached for names this object does not define
+        return getattr(self.__dict__["capture"], attr)
 
     def is_file(self):
         video = getattr(getattr(self.vmanager, "controller", None), "video", None)
         return isinstance(video, str) and os.path.isfile(video)
 
-    def read_file(self, caller):
-        self.skip()
+    def advance(self):
+        """move the read position forward by the thinning stride (never beyond the last frame)"""
+        cap = self.capture
+        target = cap.get(CAP_PROP_POS_FRAMES) + max(1, cap.get(CAP_PROP_FPS) / self.frame_rate)
+        cap.set(CAP_PROP_POS_FRAMES, min(target, cap.get(CAP_PROP_FRAME_COUNT)))
+
+    skip = advance
+
+    def read(self, caller=None):
+        if self.is_file():
+            self.advance()
         return self.capture.read()
-
-    def skip(self):
-        idx = self.capture.get(CAP_PROP_POS_FRAMES)
-        idx += max(1, self.capture.get(CAP_PROP_FPS) / self.frame_rate)
-        idx = min(idx, self.capture.get(CAP_PROP_FRAME_COUNT))     # don't point after the last frame
-        self.capture.set(CAP_PROP_POS_FRAMES, idx)
-
-    def downsample(self, ret, img):
-        return ret, img
 
 
 class CaptureReader(CaptureReaderBase):
-    """core/vmanager.py:528-635: all active VidProcessors must have received the current frame
-    before the next one is read, so they all see the same sequence."""
+    """Lock-step serving for the threaded manager (what core/vmanager.py:528-635 is for): every finder that is
+    currently able to read gets frame k before anybody gets frame k+1.
+
+    Built as a generation counter under one condition variable: the reader holds (generation, frame); a
+    consumer remembers the last generation it took and sleeps on the condition while that is still the current
+    one; whoever completes the set of consumers for a generation fetches the next frame and wakes the others.
+    A consumer therefore sees every frame exactly once -- the reference's reader lets the thread served last
+    walk away with the following frame (and sometimes see it twice), a timing artefact that is not mirrored."""
 
     def __init__(self, capture, vmanager, fps=None):
         super().__init__(capture, vmanager, fps)
-        self.buffer = None
-        self.served = set()
-        self.lock = threading.Lock()
-        self.sleep_time = 0.05
-        self.unsync = False
+        self.__dict__.update(_cv=threading.Condition(), _gen=0, _frame=None, _taken={}, unsync=False,
+                             sleep_time=0.05)
 
-    def read_file(self, caller):
-        """Deviation from core/vmanager.py:556-575, noted: the reference adds the caller to `served`,
-        calls consume() and only then copies the buffer, so the thread served last triggers the next
-        read and walks away with the NEXT frame (and, `served` being cleared, may get it twice) --
-        a timing-dependent artefact.  Here the caller takes the frame it is being served first and
-        advances the capture afterwards: every processor sees every frame exactly once."""
-        self.init_buffer()
-        while not self.unsync and caller in self.served:
-            time.sleep(self.sleep_time)
-            self.consume()
-        with self.lock:
-            buf = self.buffer
-            self.served.add(caller)
-        self.consume()
-        if self.unsync:
-            buf = self.buffer
-        try:
-            return buf[0], buf[1].copy()                      # consumers may write on the image
-        except AttributeError:
-            return buf
-
-    def init_buffer(self):
-        with self.lock:
-            if self.buffer is None:
-                self.buffer = self.capture.read()
-
-    def consume(self):
-        with self.lock:
-            if self.unsync:
-                self.buffer = False, cvconf.unsynced
-                self.served.clear()
-            else:
-                served_all = True
-                for vp in self.active_processes():
-                    if vp.processor not in self.served:
-                        served_all = False
-                        break
-                if served_all:
-                    self.skip()
-                    self.buffer = self.capture.read()
-                    self.served.clear()
-                    self.vmanager.vid_progress(self.capture.get(CAP_PROP_POS_AVI_RATIO) * 100)
-
-    def active_processes(self):
-        active = []
-        for vidproc in getattr(self.vmanager, "processes", ()):
+    def _consumers(self):
+        ready = []
+        for thread in getattr(self.vmanager, "processes", ()):
             try:
-                if vidproc.ready_to_read():
-                    active.append(vidproc)
+                if thread.ready_to_read():
+                    ready.append(thread.processor)
             except AttributeError:
-                pass
-        return active
+                continue
+        return ready
+
+    def _fetch(self, first):
+        """under the lock: load the next generation"""
+        if not first:
+            self.advance()
+        self._frame = self.capture.read()
+        self._gen += 1
+        if not first:
+            self.vmanager.vid_progress(self.capture.get(CAP_PROP_POS_AVI_RATIO) * 100)
+        self._cv.notify_all()
+
+    def _maybe_turn_over(self):
+        if all(self._taken.get(c) == self._gen for c in self._consumers()):
+            self._fetch(first=False)
+
+    def read(self, caller=None):
+        if not self.is_file():
+            return self.capture.read()
+        with self._cv:
+            if self._gen == 0:
+                self._fetch(first=True)
+            while not self.unsync and self._taken.get(caller) == self._gen:
+                self._cv.wait(self.sleep_time)
+                self._maybe_turn_over()                # a finder may have stopped being ready meanwhile
+            if self.unsync:
+                return False, cvconf.unsynced
+            ok, img = self._frame
+            self._taken[caller] = self._gen
+            self._maybe_turn_over()
+        return (ok, img.copy()) if ok else (ok, img)   # consumers may write on their image
 
     def unsync_threads(self, unsync):
-        self.unsync = unsync
+        """True: wake everybody up with the `unsynced` marker (the manager is stopping its finders)"""
+        with self._cv:
+            self.unsync = bool(unsync)
+            self._cv.notify_all()

@@ -1,120 +1,125 @@
-"""VidProcessor: the frame loop every finder inherits (mirror of the reference's
-core/video.py:14-332 for the parts callers touch: execute, _doframe, interrupt, pause, next,
-ready_to_read, full_speed, total_f_processed, bindings, metadata, _show, _window_name).
-Display goes to the manager's image queue when there is one and is otherwise dropped: HighGUI
-is out of scope."""
-import collections
-import threading
+"""Frame-loop protocol of a finder.
+
+When the host application (CamKifu) is importable the drop-in finders inherit ITS loop (see
+camkifu_amd/host.py); this module is the standalone stand-in used by the headless harnesses, the tests
+and the batch tools.  It offers the attributes SURVEY 8(b) lists as touched by callers -- execute,
+_doframe, interrupt, pause, next, ready_to_read, full_speed, total_f_processed, bindings, _show,
+metadata, _window_name (reference: core/video.py:60-332) -- built on threading.Event objects rather
+than polled flags: a paused loop sleeps on an event, an interrupt wakes every wait at once.
+Display output goes to the manager's image queue if it has one; HighGUI is out of scope."""
 import time
-import traceback
+from collections import Counter, defaultdict
+from threading import Event, Thread
+from traceback import print_exc
 
 from .. import cvconf
 
 
 class VidProcessor:
-    def __init__(self, vmanager):
-        self.vmanager = vmanager
-        self.bindings = {'p': self.pause, 'q': self.interrupt, 'f': self.next}
-        self.key = None
-        self.total_f_processed = 0
-        self.frame_period = cvconf.frame_period
-        self.full_speed = False
-        self.last_read = 0.0
-        self._interruptflag = False
-        self.pausedflag = False
-        self.next_flag = False
-        self.own_images = {}
-        self.last_shown = collections.defaultdict(lambda: 0)
-        self.ignored_show = collections.defaultdict(lambda: 0)
-        self.metadata = collections.defaultdict(list)
+    RETRY_SECONDS = 2.0          # after a failed camera read
 
-    # ---- main loop ---------------------------------------------------------------------------
-    def execute(self):
-        try:
-            self._interruptflag = False
-            while not self._interrupt_mainloop():
-                self._checkpause()
-                due = self.full_speed or (self.frame_period < time.time() - self.last_read)
-                if self.ready_to_read() and due:
-                    ret, frame = self.vmanager.read(self)
-                    if ret:
-                        self.last_read = time.time()
-                        self._doframe(frame)
-                        self.total_f_processed += 1
-                    elif not (isinstance(frame, str) and frame == cvconf.unsynced):
-                        if self.terminated_video():
-                            break
-                        print("Could not read camera for {0}.".format(type(self)))
-                        time.sleep(2)
-                else:
-                    time.sleep(self.frame_period / 10)
-        except BaseException as exc:
-            self.vmanager.error_raised(self, exc)
-            traceback.print_exc()
-        finally:
-            self.vmanager.confirm_stop(self)
+    def __init__(self, manager):
+        self.vmanager, self.total_f_processed, self.full_speed = manager, 0, False
+        self.frame_period, self.metadata = cvconf.frame_period, defaultdict(list)
+        self.bindings = {"p": self.pause, "q": self.interrupt, "f": self.next}
+        self._quit, self._go, self._one = Event(), Event(), Event()      # _go is cleared while paused; _one = "next"
+        self._go.set()
+        self._read_at, self._shown_at, self.dropped_images = float("-inf"), {}, Counter()
 
-    def _interrupt_mainloop(self):
-        return self.terminated_video() or self._interruptflag
-
-    def terminated_video(self):
-        capt = getattr(self.vmanager, "capt", None)
-        if capt is None:
-            return False
-        return self.vmanager.controller.bounds[1] <= capt.progress()
+    # ------------------------------------------------------------------ to be provided by finders
+    def _doframe(self, frame):
+        raise NotImplementedError("a finder implements _doframe(frame)")
 
     def ready_to_read(self):
-        return not self._interruptflag
+        return not self._quit.is_set()
 
-    def _doframe(self, frame):
-        raise NotImplementedError("Abstract method meant to be extended")
-
-    def interrupt(self):
-        self._interruptflag = True
-
-    def pause(self, dopause=None):
-        self.pausedflag = (not self.pausedflag) if dopause is None else bool(dopause)
-
-    def next(self):
-        self.next_flag = True
-
-    def _checkpause(self):
-        while self.pausedflag and not self._interruptflag:
-            if self.next_flag:
-                self.next_flag = False
-                break
-            time.sleep(0.05)
-
-    # ---- display (queue only) ------------------------------------------------------------------
     def _window_name(self):
         return type(self).__name__
 
-    def _show(self, img, name=None, frame=True, latency=True, thread=False, loc=None, max_frequ=2):
+    # ------------------------------------------------------------------ loop
+    def execute(self):
+        vm = self.vmanager
+        self._quit.clear()
+        try:
+            while not (self._quit.is_set() or self._video_over()):
+                self._hold_while_paused()
+                if not (self.ready_to_read() and self._is_due()):
+                    self._quit.wait(self.frame_period / 10)
+                    continue
+                ok, frame = vm.read(self)
+                if ok:
+                    self._read_at = time.monotonic()
+                    self._doframe(frame)
+                    self._count_frame()
+                elif isinstance(frame, str) and frame == cvconf.unsynced:
+                    continue                                  # the reader let go of its consumers: ask again
+                elif self._video_over():
+                    break
+                else:
+                    print("%s: no frame from the input, retrying" % type(self).__name__)
+                    self._quit.wait(self.RETRY_SECONDS)
+        except BaseException as failure:                      # the manager stops everything (core/video.py:115-120)
+            vm.error_raised(self, failure)
+            print_exc()
+        finally:
+            vm.confirm_stop(self)
+
+    def _count_frame(self):
+        self.total_f_processed = self.total_f_processed + 1
+
+    def _is_due(self):
+        return self.full_speed or time.monotonic() - self._read_at > self.frame_period
+
+    def _video_over(self):
+        capt = getattr(self.vmanager, "capt", None)
+        return capt is not None and capt.progress() >= self.vmanager.controller.bounds[1]
+
+    terminated_video = _video_over
+
+    def _hold_while_paused(self):
+        while not (self._go.is_set() or self._quit.is_set()):
+            if self._one.is_set():
+                self._one.clear()
+                return
+            self._go.wait(0.05)
+
+    # ------------------------------------------------------------------ controls (key bindings)
+    def interrupt(self):
+        self._quit.set()
+        self._go.set()
+
+    def pause(self, dopause=None):
+        want = self._go.is_set() if dopause is None else bool(dopause)
+        (self._go.clear if want else self._go.set)()
+
+    @property
+    def pausedflag(self):
+        return not self._go.is_set()
+
+    def next(self):
+        self._one.set()
+
+    # ------------------------------------------------------------------ display
+    def _show(self, img, name=None, loc=None, max_frequ=2, **_ignored):
+        """hand `img` to the manager's image queue, at most `max_frequ` times per second per window"""
         name = name or self._window_name()
-        q = getattr(self.vmanager, "imqueue", None)
-        if q is None:
-            self.metadata.clear()
-            return
-        now = time.time()
-        if 1 / max_frequ < now - self.last_shown[name]:
+        sink = getattr(self.vmanager, "imqueue", None)
+        now = time.monotonic()
+        if sink is not None and now - self._shown_at.get(name, float("-inf")) > 1.0 / max_frequ:
             try:
-                q.put_nowait((name, img, self, loc))
-                self.own_images[name] = img
-                self.last_shown[name] = now
+                sink.put_nowait((name, img, self, loc))
+                self._shown_at[name] = now
             except Exception:
-                self.ignored_show[name] += 1
-        self.metadata.clear()
+                self.dropped_images[name] += 1
+        self.metadata = defaultdict(list)
 
 
-class VisionThread(threading.Thread):
-    """Daemon-thread wrapper of a VidProcessor (core/video.py:335-355): run() is the processor's
-    execute(); every other attribute is delegated to the processor."""
+class VisionThread(Thread):
+    """one daemon thread per finder; unknown attributes resolve on the finder itself"""
 
-    def __init__(self, processor):
-        super().__init__(name=processor.__class__.__name__)
-        self.daemon = True
-        self.processor = processor
-        self.run = processor.execute
+    def __init__(self, finder):
+        super().__init__(name=type(finder).__name__, daemon=True, target=finder.execute)
+        self.__dict__["processor"] = finder
 
-    def __getattr__(self, item):
-        return getattr(self.processor, item)
+    def __getattr__(self, attr):
+        return getattr(self.__dict__["processor"], attr)

@@ -1,224 +1,197 @@
-"""Vision managers: finder registry/reflection (core/vmanager.py:16-198 `VManagerBase`), the
-multi-threaded `VManager` with lock-step file reading (core/vmanager.py:201-458) and the sequential
-headless driver of the reference's tests (test/objects/vmanager_test.py `VManagerSeq`).
-Frames come from core/capture.py: an in-memory array, a .npy file or an uncompressed .y4m file."""
-import importlib
-import os
-import threading
-import time
+"""Headless vision managers -- only what the harnesses and tests need around the finders.
+
+The reference's managers (core/vmanager.py) own the capture, pick the finder classes by name and run
+them; the drop-in finders of this package are meant to be registered with THAT manager unchanged
+(INTEGRATION.md).  Standalone, this module supplies the same seams: `(module, class)` registration
+resolved by `VManagerBase._reflect` (core/vmanager.py:163-198), `read(caller)`, `error_raised`,
+`confirm_stop`, `board_finder` / `stones_finder` / `capt` / `controller` / `imqueue` / `current_video`,
+a threaded manager (one daemon thread per finder, frames served in lock step) and the sequential
+driver of the reference's test harness (test/objects/vmanager_test.py)."""
+from importlib import import_module
+from threading import Event, Thread
 
 from .. import cvconf
-from .capture import ArrayCapture, CaptureReader, CaptureReaderBase, open_capture     # noqa: F401  (ArrayCapture re-exported)
+from .capture import ArrayCapture, CaptureReader, CaptureReaderBase, open_capture     # noqa: F401  (re-exported)
 from .video import VisionThread
 
 
-class VManagerBase(threading.Thread):
+def resolve_finder(name, registry):
+    """`registry`: [(module path, class name), ...].  The default is the first entry whose module imports;
+    `name` picks another importable entry; "None" (as a name, or as the only usable entry) means no finder."""
+    usable = []
+    if name == "None":
+        return None
+    for module_path, class_name in registry:
+        if class_name == "None":
+            continue
+        try:
+            usable.append((class_name, getattr(import_module(module_path), class_name)))
+        except ImportError as why:
+            print("finder %s not available: %s" % (class_name, why))
+            continue
+        if class_name == name:
+            return usable[-1][1]
+    return usable[0][1] if usable else None
+
+
+class VManagerBase(Thread):
+    _reflect = staticmethod(resolve_finder)
+    reader_class = CaptureReaderBase
+
     def __init__(self, controller, imqueue=None, bf=None, sf=None):
-        threading.Thread.__init__(self, name="Vision")
-        self.controller = controller
-        self.punch_controller()
-        self.imqueue = imqueue
-        self.capt = None
-        self.current_video = None
-        self.bf_class = self._reflect(bf, cvconf.bfinders)
-        self.sf_class = self._reflect(sf, cvconf.sfinders)
-        self.board_finder = None
-        self.stones_finder = None
-        self.full_speed = False
+        super().__init__(name="Vision", daemon=True)
+        self.controller, self.imqueue = controller, imqueue
+        self.capt = self.current_video = None
+        self.board_finder = self.stones_finder = None
+        self.bf_class, self.sf_class = resolve_finder(bf, cvconf.bfinders), resolve_finder(sf, cvconf.sfinders)
+        self.full_speed, self.error = False, None
+        # the controller calls back into the vision side for user corrections and single-stepping
+        controller.corrected = self.corrected
+        controller.next = self.next
 
-    def punch_controller(self):
-        self.controller.corrected = self.corrected
-        self.controller.next = self.next
-
+    # ---- capture ------------------------------------------------------------------------------
     def init_capt(self):
-        self.current_video = self.controller.video
-        if self.capt is not None:
-            self.capt.release()
-        self.capt = self._get_capture()
-        if self.capt is not None:
-            # arrays and files are read as fast as the finders go; only a live camera is rate limited
-            self.full_speed = True
-            self.capt.seek(self.controller.bounds[0])
+        old, self.capt = self.capt, None
+        if old is not None:
+            old.release()
+        self.current_video = video = self.controller.video
+        source = open_capture(video)
+        if not source.isOpened():
+            print("cannot open %r: %s" % (video, getattr(source, "error", "")))
+            return
+        self.capt = self.reader_class(source, self)
+        self.full_speed = True                       # files / arrays: as fast as the finders go
+        self.capt.seek(self.controller.bounds[0])
 
-    def _get_capture(self):
-        """the capture for controller.video; a file path gets the frame-skipping reader (file_fps)"""
-        cap = open_capture(self.controller.video)
-        if not cap.isOpened():
-            print("Could not open video: {}".format(getattr(cap, "error", self.controller.video)))
-            return None
-        return CaptureReaderBase(cap, self)
+    def read(self, finder):
+        return self.capt.read(finder)
 
-    def error_raised(self, processor, error):
-        print("{} terminating due to {} in {}.".format(type(self).__name__, type(error).__name__,
-                                                       type(processor).__name__))
+    def vid_progress(self, percent):
+        """progress listeners (a GUI) hook in here"""
+
+    # ---- finders ------------------------------------------------------------------------------
+    def finders(self):
+        return [p for p in (self.board_finder, self.stones_finder) if p is not None]
+
+    def next(self):
+        for p in self.finders():
+            p.next()
+
+    def corrected(self, wrong, right):
+        """a user correction on the goban: (removed move or None, added move or None)"""
+        sf = self.stones_finder
+        if sf is not None:
+            sf.corrected(wrong, right)
+
+    def error_raised(self, finder, error):
+        print("%s stops: %s in %s" % (type(self).__name__, type(error).__name__, type(finder).__name__))
         self.error = error
         self.interrupt()
 
-    def read(self, caller):
-        return self.capt.read(caller)
-
-    def next(self):
-        for p in (self.board_finder, self.stones_finder):
-            if p is not None:
-                p.next()
-
-    def corrected(self, err_move, exp_move):
-        if self.stones_finder is not None:
-            self.stones_finder.corrected(err_move, exp_move)
-
-    def confirm_stop(self, process):
-        pass
-
-    def vid_progress(self, progress):
-        pass
-
-    def interrupt(self):
-        raise NotImplementedError
+    def confirm_stop(self, finder):
+        """a finder's loop has ended"""
 
     def stop_processing(self):
-        raise NotImplementedError
+        for p in self.finders():
+            p.interrupt()
 
-    @staticmethod
-    def _reflect(name, classes):
-        """first importable (module, class) entry is the default; `name` selects another one"""
-        if name == "None":
-            return None
-        chosen = None
-        for m, c in classes:
-            if c == "None":
-                continue
-            try:
-                importlib.import_module(m)
-            except ImportError as err:
-                print("Can't load {}: {}".format(c, err))
-                continue
-            if chosen is None:
-                chosen = (m, c)
-            if c == name:
-                chosen = (m, c)
-                break
-        if chosen is None:
-            return None
-        return getattr(importlib.import_module(chosen[0]), chosen[1])
+    def interrupt(self):
+        VManagerBase.stop_processing(self)
 
 
 class VManager(VManagerBase):
-    """Multi-threaded manager (core/vmanager.py:201-458, headless part): one daemon thread per finder;
-    when the input is a file both finders receive the same frames in lock step (CaptureReader)."""
+    """threads: the manager polls, creates each finder once a capture exists and runs it on its own
+    daemon thread; over a file the reader hands every frame to all running finders before moving on"""
+    reader_class = CaptureReader
+    POLL_SECONDS = 0.02
 
     def __init__(self, controller, imqueue=None, bf=None, sf=None, active=True):
-        super().__init__(controller, imqueue=imqueue, bf=bf, sf=sf)
-        self.daemon = True
-        self.processes = []
-        self._interrupt_flag = False
-        self.active = active
-        self.hasrun = False
-        self.error = None
-
-    def _get_capture(self):
-        cap = open_capture(self.controller.video)
-        if not cap.isOpened():
-            print("Could not open video: {}".format(getattr(cap, "error", self.controller.video)))
-            return None
-        return CaptureReader(cap, self)
-
-    def next(self):
-        for proc in self.processes:
-            proc.next()
+        VManagerBase.__init__(self, controller, imqueue, bf, sf)
+        self.processes, self.active, self.hasrun = [], active, False      # processes: VisionThreads still running
+        self._over = Event()
 
     def run(self):
         self.init_capt()
-        while not self._interrupt_flag:
-            if self.active:
-                self.check_video()
-                if self.capt is not None:
-                    self.check_bf()
-                    self.check_sf()
-            time.sleep(0.02)
+        while not self._over.is_set():
+            self._poll()
+            self._over.wait(self.POLL_SECONDS)
             self.hasrun = True
 
-    def interrupt(self):
-        self.stop_processing()
-        self._interrupt_flag = True
-
-    def stop_processing(self):
-        for proc in list(self.processes):
-            proc.interrupt()
-        try:
-            self.capt.unsync_threads(True)        # release threads a CaptureReader keeps sleeping
-        except AttributeError:
-            pass
-
-    def check_video(self):
-        if self.current_video is not self.controller.video and self.current_video != self.controller.video:
+    def _poll(self):
+        if not self.active:
+            return
+        wanted = self.controller.video
+        if wanted is not self.current_video and wanted != self.current_video:
             self.stop_processing()
             self.init_capt()
-            self.board_finder = None
-            self.stones_finder = None
+            self.board_finder = self.stones_finder = None
             self.controller.pipe("video_changed")
+        if self.capt is not None:
+            self._ensure("board_finder", self.bf_class)
+            self._ensure("stones_finder", self.sf_class)
 
-    def check_bf(self):
-        if self.board_finder is None and self.bf_class is not None:
-            self.board_finder = self.bf_class(self)
-            self._spawn(self.board_finder)
+    def _ensure(self, slot, cls):
+        if cls is None or getattr(self, slot) is not None:
+            return
+        finder = cls(self)
+        setattr(self, slot, finder)
+        thread = VisionThread(finder)
+        self.processes.append(thread)
+        self._lock_step(True)
+        thread.start()
 
-    def check_sf(self):
-        if self.stones_finder is None and self.sf_class is not None:
-            self.stones_finder = self.sf_class(self)
-            self._spawn(self.stones_finder)
+    def _lock_step(self, on):
+        release = getattr(self.capt, "unsync_threads", None)
+        if release is not None:
+            release(not on)
 
     def is_processing(self):
-        return len(self.processes).__bool__()
+        return len(self.processes) > 0
 
-    def confirm_stop(self, process):
-        for vt in list(self.processes):
-            if vt.processor is process:
-                self.processes.remove(vt)
+    def next(self):
+        for t in self.processes:
+            t.next()
 
-    def _spawn(self, process):
-        vt = VisionThread(process)
-        self.processes.append(vt)
-        try:
-            self.capt.unsync_threads(False)       # processes wait for each other again when reading frames
-        except AttributeError:
-            pass
-        vt.start()
+    def confirm_stop(self, finder):
+        self.processes = [t for t in self.processes if t.processor is not finder]
+
+    def stop_processing(self):
+        for t in list(self.processes):
+            t.interrupt()
+        self._lock_step(False)                       # nobody may stay asleep inside the reader
+
+    def interrupt(self):
+        self._over.set()
+        VManager.stop_processing(self)
 
 
 class VManagerSeq(VManagerBase):
-    """Board detection until a transform exists, then stones detection to the end of the video;
-    everything on the caller's thread."""
+    """caller's thread only: the board finder runs until it has a transform, then the stones finder runs
+    to the end of the video"""
 
     def __init__(self, controller=None, bf=None, sf=None):
-        super().__init__(controller, bf=bf, sf=sf)
-        self.error = None
-        self._stop = False
+        VManagerBase.__init__(self, controller, None, bf, sf)
+        self._cancelled = False
 
     def run(self):
-        self.init_capt()
-        self.board_finder = self.bf_class(self)
-        self.board_finder.full_speed = True
-        self.stones_finder = self.sf_class(self)
-        self.stones_finder.full_speed = True
-        bf = self.board_finder
-        orig = bf._doframe
+        VManagerBase.init_capt(self)
+        board, stones = self.bf_class(self), self.sf_class(self)
+        self.board_finder, self.stones_finder = board, stones
+        board.full_speed = stones.full_speed = True
+        per_frame = board._doframe
 
-        def until_found(frame):
-            orig(frame)
-            if bf.mtx is not None:
-                bf.interrupt()
-        bf._doframe = until_found
-        bf.execute()
-        bf._doframe = orig
-        if self._stop or bf.mtx is None:
-            return
-        self.stones_finder.execute()
-
-    def interrupt(self):
-        self.stop_processing()
+        def stop_once_located(frame):
+            per_frame(frame)
+            if board.mtx is not None:
+                board.interrupt()
+        board._doframe = stop_once_located
+        try:
+            board.execute()
+        finally:
+            board._doframe = per_frame
+        if board.mtx is not None and not self._cancelled:
+            stones.execute()
 
     def stop_processing(self):
-        self._stop = True
-        for p in (self.board_finder, self.stones_finder):
-            if p is not None:
-                p.interrupt()
+        self._cancelled = True
+        VManagerBase.stop_processing(self)

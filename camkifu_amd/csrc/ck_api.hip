@@ -128,6 +128,7 @@ void ck_ctx_destroy(ck_ctx* ctx)
     DevBuf* bufs[] = { &ctx->in_stage, &ctx->in_stage2, &ctx->planes, &ctx->edges, &ctx->map, &ctx->labels,
                        &ctx->labels2, &ctx->ghost, &ctx->misc, &ctx->bflag, &ctx->comp, &ctx->lists, &ctx->pts, &ctx->accum, &ctx->peaks,
                        &ctx->goban, &ctx->act0, &ctx->act1, &ctx->act2, &ctx->ybuf, &ctx->lblbuf, &ctx->confbuf,
+                       &ctx->rlblbuf, &ctx->rconfbuf, &ctx->fgcbuf,
                        &ctx->out_stage, &ctx->mats,
                        &ctx->cnn.c1w, &ctx->cnn.c1b, &ctx->cnn.c2w, &ctx->cnn.c2b, &ctx->cnn.c3w, &ctx->cnn.c3b,
                        &ctx->cnn.c4w, &ctx->cnn.c4b, &ctx->cnn.d1w, &ctx->cnn.d1b, &ctx->cnn.d2w, &ctx->cnn.d2b,
@@ -433,12 +434,18 @@ int ck_cnn_set_mode(ck_ctx* ctx, int mode)
     return CK_OK;
 }
 
-static int cnn_predict_dev(ck_ctx* ctx, const uint8_t* d_goban, int n, float* y, uint8_t* labels, double* conf, int out_space)
+// where the region outputs of a call go (all optional)
+struct RegionOut { uint8_t* label = nullptr; double* conf = nullptr; };
+
+static int cnn_predict_dev(ck_ctx* ctx, const uint8_t* d_goban, int n, float* y, uint8_t* labels, double* conf, int out_space,
+                           RegionOut ro = RegionOut())
 {
     if (!ctx->cnn.set) return ck_fail(ctx, CK_ERR_STATE, "ck_cnn_set_weights has not been called");
     CK_TRY(ck_ensure(ctx, ctx->ybuf, (size_t)n * 8100 * sizeof(float)));
     CK_TRY(ck_ensure(ctx, ctx->lblbuf, (size_t)n * 361));
     CK_TRY(ck_ensure(ctx, ctx->confbuf, (size_t)n * 361 * sizeof(double)));
+    CK_TRY(ck_ensure(ctx, ctx->rlblbuf, (size_t)n * 100));
+    CK_TRY(ck_ensure(ctx, ctx->rconfbuf, (size_t)n * 100 * sizeof(double)));
     if (ctx->cnn_mode == CK_CNN_F16X2) {
         // Safety net of the split-precision mode: an activation beyond the fp16 range (|x| > 65000; never seen with
         // 8-bit images and sane weights) would turn into inf.  The kernels raise a flag in host-mapped memory, which
@@ -448,10 +455,14 @@ static int cnn_predict_dev(ck_ctx* ctx, const uint8_t* d_goban, int n, float* y,
             CK_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->cnn_flag_dev, ctx->cnn_flag_host, 0));
         }
         *ctx->cnn_flag_host = 0;
-        CK_TRY(k_cnn_predict(ctx, d_goban, n, (float*)ctx->ybuf.p, (uint8_t*)ctx->lblbuf.p, (double*)ctx->confbuf.p, ctx->cnn_flag_dev));
+        CK_TRY(k_cnn_predict(ctx, d_goban, n, (float*)ctx->ybuf.p, (uint8_t*)ctx->lblbuf.p, (double*)ctx->confbuf.p, ctx->cnn_flag_dev,
+                             (uint8_t*)ctx->rlblbuf.p, (double*)ctx->rconfbuf.p));
     } else {
-        CK_TRY(k_cnn_predict(ctx, d_goban, n, (float*)ctx->ybuf.p, (uint8_t*)ctx->lblbuf.p, (double*)ctx->confbuf.p));
+        CK_TRY(k_cnn_predict(ctx, d_goban, n, (float*)ctx->ybuf.p, (uint8_t*)ctx->lblbuf.p, (double*)ctx->confbuf.p, nullptr,
+                             (uint8_t*)ctx->rlblbuf.p, (double*)ctx->rconfbuf.p));
     }
+    if (ro.label) CK_TRY(ck_from_device(ctx, ro.label, ctx->rlblbuf.p, (size_t)n * 100, out_space));
+    if (ro.conf) CK_TRY(ck_from_device(ctx, ro.conf, ctx->rconfbuf.p, (size_t)n * 100 * sizeof(double), out_space));
     if (y) CK_TRY(ck_from_device(ctx, y, ctx->ybuf.p, (size_t)n * 8100 * sizeof(float), out_space));
     if (labels) CK_TRY(ck_from_device(ctx, labels, ctx->lblbuf.p, (size_t)n * 361, out_space));
     if (conf) CK_TRY(ck_from_device(ctx, conf, ctx->confbuf.p, (size_t)n * 361 * sizeof(double), out_space));
@@ -460,12 +471,13 @@ static int cnn_predict_dev(ck_ctx* ctx, const uint8_t* d_goban, int n, float* y,
 
 // synchronise; if the split-precision kernels flagged a value outside the fp16 range, recompute the batch with
 // the f32 kernels (the goban images are still in place) and deliver again
-static int cnn_finish(ck_ctx* ctx, const uint8_t* d_goban, int n, float* y, uint8_t* labels, double* conf, int out_space)
+static int cnn_finish(ck_ctx* ctx, const uint8_t* d_goban, int n, float* y, uint8_t* labels, double* conf, int out_space,
+                      RegionOut ro = RegionOut())
 {
     CK_TRY(finish(ctx));
     if (ctx->cnn_mode == CK_CNN_F16X2 && ctx->cnn_flag_host && *(volatile int*)ctx->cnn_flag_host) {
         ctx->cnn_mode = CK_CNN_FP32;
-        const int rc = cnn_predict_dev(ctx, d_goban, n, y, labels, conf, out_space);
+        const int rc = cnn_predict_dev(ctx, d_goban, n, y, labels, conf, out_space, ro);
         ctx->cnn_mode = CK_CNN_F16X2;
         ctx->cnn_fallbacks++;
         if (rc) return rc;
@@ -498,6 +510,81 @@ int ck_stones_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int i
     CK_TRY(k_warp(ctx, (const uint8_t*)d_in, n, h, w, d_minv, m_count, 380, (uint8_t*)ctx->goban.p));
     CK_TRY(cnn_predict_dev(ctx, (const uint8_t*)ctx->goban.p, n, nullptr, labels, conf, out_space));
     return cnn_finish(ctx, (const uint8_t*)ctx->goban.p, n, nullptr, labels, conf, out_space);
+}
+
+int ck_cnn_regions(ck_ctx* ctx, const uint8_t* goban, int n, int in_space, uint8_t* region_label, double* region_conf,
+                   int out_space)
+{
+    if (!ctx) return CK_ERR_ARG;
+    if (!goban || n <= 0 || !region_label || !region_conf) return ck_fail(ctx, CK_ERR_ARG, "NULL argument or n <= 0");
+    CK_HIP(ctx, hipSetDevice(ctx->device));
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, goban, (size_t)n * 380 * 380 * 3, in_space, ctx->in_stage, &d_in));
+    RegionOut ro; ro.label = region_label; ro.conf = region_conf;
+    CK_TRY(cnn_predict_dev(ctx, (const uint8_t*)d_in, n, nullptr, nullptr, nullptr, out_space, ro));
+    return cnn_finish(ctx, (const uint8_t*)d_in, n, nullptr, nullptr, nullptr, out_space, ro);
+}
+
+int ck_stones_run(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space, const double* M, int m_count,
+                  int mog2_handle, const double* learning_rates, uint8_t* region_label, double* region_conf,
+                  int32_t* fgcount, uint8_t* labels, double* conf, int out_space)
+{
+    CK_TRY(check_img(ctx, bgr, n, h, w));
+    if (!region_label || !region_conf) return ck_fail(ctx, CK_ERR_ARG, "region outputs are NULL");
+    const bool bg = mog2_handle >= 0;
+    if (bg && (mog2_handle >= (int)ctx->mog2.size() || !ctx->mog2[mog2_handle].alive))
+        return ck_fail(ctx, CK_ERR_ARG, "bad mog2 handle %d", mog2_handle);
+    if (bg && (!learning_rates || !fgcount)) return ck_fail(ctx, CK_ERR_ARG, "a background model needs learning_rates and fgcount");
+    if (bg && (ctx->mog2[mog2_handle].h != 380 || ctx->mog2[mog2_handle].w != 380))
+        return ck_fail(ctx, CK_ERR_ARG, "the background model of a stones run is 380x380");
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, bgr, (size_t)n * h * w * 3, in_space, ctx->in_stage, &d_in));
+    const double* d_minv;
+    CK_TRY(upload_minv(ctx, M, m_count, n, &d_minv));
+    CK_TRY(ck_ensure(ctx, ctx->goban, (size_t)n * 380 * 380 * 3));
+    CK_TRY(k_warp(ctx, (const uint8_t*)d_in, n, h, w, d_minv, m_count, 380, (uint8_t*)ctx->goban.p));
+    if (bg) {
+        int32_t* d_cnt = fgcount;
+        if (out_space == CK_HOST) { CK_TRY(ck_ensure(ctx, ctx->fgcbuf, (size_t)n * 361 * sizeof(int32_t))); d_cnt = (int32_t*)ctx->fgcbuf.p; }
+        CK_TRY(k_mog2_run(ctx, ctx->mog2[mog2_handle], (const uint8_t*)ctx->goban.p, n, learning_rates, d_cnt, nullptr, 379, 379));
+        if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, fgcount, d_cnt, (size_t)n * 361 * sizeof(int32_t), CK_HOST));
+    }
+    RegionOut ro; ro.label = region_label; ro.conf = region_conf;
+    CK_TRY(cnn_predict_dev(ctx, (const uint8_t*)ctx->goban.p, n, nullptr, labels, conf, out_space, ro));
+    return cnn_finish(ctx, (const uint8_t*)ctx->goban.p, n, nullptr, labels, conf, out_space, ro);
+}
+
+int ck_mog2_band_run(ck_ctx* ctx, int handle, const uint8_t* band, int n, int in_space, const double* learning_rates,
+                     int last_band, int32_t* counts, int out_space)
+{
+    if (!ctx) return CK_ERR_ARG;
+    if (handle < 0 || handle >= (int)ctx->mog2.size() || !ctx->mog2[handle].alive)
+        return ck_fail(ctx, CK_ERR_ARG, "bad mog2 handle %d", handle);
+    if (!band || !learning_rates || !counts || n <= 0) return ck_fail(ctx, CK_ERR_ARG, "NULL argument or n <= 0");
+    CK_HIP(ctx, hipSetDevice(ctx->device));
+    Mog2State& st = ctx->mog2[handle];
+    const size_t zones = (size_t)((st.h + 19) / 20) * ((st.w + 19) / 20);
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, band, (size_t)n * st.h * st.w * 3, in_space, ctx->in_stage, &d_in));
+    int32_t* d_cnt = counts;
+    if (out_space == CK_HOST) { CK_TRY(ck_ensure(ctx, ctx->fgcbuf, (size_t)n * zones * sizeof(int32_t))); d_cnt = (int32_t*)ctx->fgcbuf.p; }
+    CK_TRY(k_mog2_run(ctx, st, (const uint8_t*)d_in, n, learning_rates, d_cnt, nullptr, last_band ? st.h - 1 : -1, st.w - 1));
+    if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, counts, d_cnt, (size_t)n * zones * sizeof(int32_t), CK_HOST));
+    return finish(ctx);
+}
+
+int ck_zone_counts(ck_ctx* ctx, const uint8_t* mask, int n, int in_space, int32_t* counts, int out_space)
+{
+    if (!ctx) return CK_ERR_ARG;
+    if (!mask || !counts || n <= 0) return ck_fail(ctx, CK_ERR_ARG, "NULL argument or n <= 0");
+    CK_HIP(ctx, hipSetDevice(ctx->device));
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, mask, (size_t)n * 380 * 380, in_space, ctx->in_stage2, &d_in));
+    int32_t* d_cnt = counts;
+    if (out_space == CK_HOST) { CK_TRY(ck_ensure(ctx, ctx->fgcbuf, (size_t)n * 361 * sizeof(int32_t))); d_cnt = (int32_t*)ctx->fgcbuf.p; }
+    CK_TRY(k_zone_counts(ctx, (const uint8_t*)d_in, n, 380, d_cnt));
+    if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, counts, d_cnt, (size_t)n * 361 * sizeof(int32_t), CK_HOST));
+    return finish(ctx);
 }
 
 int ck_mog2_create(ck_ctx* ctx, int h, int w, int* handle)

@@ -68,7 +68,7 @@ struct ck_ctx {
     DevBuf peaks;
     DevBuf goban;        // n*380*380*3
     DevBuf act0, act1, act2;   // cnn activations
-    DevBuf ybuf, lblbuf, confbuf;
+    DevBuf ybuf, lblbuf, confbuf, rlblbuf, rconfbuf, fgcbuf;
     DevBuf out_stage;
     DevBuf mats;
     void* host_pinned = nullptr;
@@ -137,9 +137,12 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
                   const int* d_canny_border_flag = nullptr);
 // d_nonfinite (nullable): set to 1 when a softmax came out inf / NaN
 int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int n, float* d_y, uint8_t* d_labels, double* d_conf,
-                  int* d_nonfinite = nullptr);
+                  int* d_nonfinite = nullptr, uint8_t* d_rlabel = nullptr, double* d_rconf = nullptr);
 int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space);
 int k_mog2_apply(ck_ctx* ctx, Mog2State& st, const uint8_t* d_img, double lr, uint8_t* d_fg);
+int k_mog2_run(ck_ctx* ctx, Mog2State& st, const uint8_t* d_gobans, int n, const double* learning_rates,
+               int32_t* d_fgcount, uint8_t* d_last_fg, int skip_row, int skip_col);
+int k_zone_counts(ck_ctx* ctx, const uint8_t* d_mask, int n, int side, int32_t* d_fgcount);
 
 // host geometry (ck_host_geom.cpp)
 void ck_invert3x3(const double* s, double* d);

@@ -1360,7 +1360,8 @@ __global__ __launch_bounds__(64) void fc2_softmax_kernel(const float* __restrict
 // later region wins: cell (r, c) takes its value from region (I(r), I(c)) with I(17) = I(18) = 9.
 namespace {
 __global__ __launch_bounds__(128) void decode_kernel(const float* __restrict__ y, uint8_t* __restrict__ labels,
-                                                     double* __restrict__ conf, int nframes, int* __restrict__ nonfinite)
+                                                     double* __restrict__ conf, int nframes, int* __restrict__ nonfinite,
+                                                     uint8_t* __restrict__ region_label, double* __restrict__ region_conf)
 {
     __shared__ int lab[100];
     __shared__ double cf[100];
@@ -1376,6 +1377,10 @@ __global__ __launch_bounds__(128) void decode_kernel(const float* __restrict__ y
         }
         lab[t] = label;
         cf[t] = (double)yy[label] / s;
+        // the regions themselves (NNCache.predict_4_stones / predict_stone read them, nn_cache.py:16-31): where
+        // region 8 and region 9 overlap the 19x19 grid below only keeps region 9's answer
+        if (region_label) region_label[(size_t)f * 100 + t] = (uint8_t)label;
+        if (region_conf) region_conf[(size_t)f * 100 + t] = cf[t];
         if (nonfinite && !(s - s == 0.0)) *nonfinite = 1;      // inf / NaN somewhere in this softmax
     }
     __syncthreads();
@@ -1566,7 +1571,7 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
 }
 
 int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, uint8_t* d_labels, double* d_conf,
-                  int* d_nonfinite)
+                  int* d_nonfinite, uint8_t* d_rlabel, double* d_rconf)
 {
     // convolutions run in chunks of frames so the activation scratch stays bounded; the dense
     // tail runs once over the whole batch (its 32-patch MFMA tiles need many waves in flight)
@@ -1623,7 +1628,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
                            (const uint16_t*)q4_all, (const uint16_t*)W.d1w_bf.p, (const float*)W.d1b.p, hb, np);
         hipLaunchKernelGGL(fc2_softmax_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float*)hb,
                            (const float*)W.d2w.p, (const float*)W.d2b.p, d_y, np);
-        hipLaunchKernelGGL(decode_kernel, dim3(nframes), dim3(128), 0, ctx->stream, (const float*)d_y, d_labels, d_conf, nframes, d_nonfinite);
+        hipLaunchKernelGGL(decode_kernel, dim3(nframes), dim3(128), 0, ctx->stream, (const float*)d_y, d_labels, d_conf, nframes, d_nonfinite, d_rlabel, d_rconf);
         CK_HIP(ctx, hipGetLastError());
         return CK_OK;
     }
@@ -1705,7 +1710,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
                            (const float*)p4_all, (const float*)W.d1w.p, (const float*)W.d1b.p, h1, np);
         hipLaunchKernelGGL(fc2_softmax_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float*)h1,
                            (const float*)W.d2w.p, (const float*)W.d2b.p, d_y, np);
-        hipLaunchKernelGGL(decode_kernel, dim3(nframes), dim3(128), 0, ctx->stream, (const float*)d_y, d_labels, d_conf, nframes, d_nonfinite);
+        hipLaunchKernelGGL(decode_kernel, dim3(nframes), dim3(128), 0, ctx->stream, (const float*)d_y, d_labels, d_conf, nframes, d_nonfinite, d_rlabel, d_rconf);
         CK_HIP(ctx, hipGetLastError());
     }
     return CK_OK;

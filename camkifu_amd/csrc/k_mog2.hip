@@ -14,34 +14,53 @@ namespace {
 
 constexpr int NMIX = 5;
 
-__global__ __launch_bounds__(256) void mog2_kernel(const uint8_t* __restrict__ img, int npx,
-                                                   float* __restrict__ gw_, float* __restrict__ gv_,
-                                                   float* __restrict__ mean_, uint8_t* __restrict__ nmodes_,
-                                                   float alphaT, float prune, uint8_t* __restrict__ fg)
+// the per-pixel mixture, held in registers while a pixel is being updated
+struct Mix {
+    float gw[NMIX], gv[NMIX], mean[NMIX][3];
+    int nmodes;
+};
+
+__device__ __forceinline__ void mix_load(Mix& m, const float* __restrict__ gw_, const float* __restrict__ gv_,
+                                         const float* __restrict__ mean_, const uint8_t* __restrict__ nmodes_, int npx, int px)
+{
+    m.nmodes = nmodes_[px];
+#pragma unroll
+    for (int k = 0; k < NMIX; k++) {
+        if (k < m.nmodes) {
+            m.gw[k] = gw_[(size_t)k * npx + px];
+            m.gv[k] = gv_[(size_t)k * npx + px];
+#pragma unroll
+            for (int c = 0; c < 3; c++) m.mean[k][c] = mean_[((size_t)k * 3 + c) * npx + px];
+        } else {
+            m.gw[k] = 0.f; m.gv[k] = 0.f; m.mean[k][0] = m.mean[k][1] = m.mean[k][2] = 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void mix_store(const Mix& m, float* __restrict__ gw_, float* __restrict__ gv_,
+                                          float* __restrict__ mean_, uint8_t* __restrict__ nmodes_, int npx, int px)
+{
+#pragma unroll
+    for (int k = 0; k < NMIX; k++) {
+        gw_[(size_t)k * npx + px] = m.gw[k];
+        gv_[(size_t)k * npx + px] = m.gv[k];
+#pragma unroll
+        for (int c = 0; c < 3; c++) mean_[((size_t)k * 3 + c) * npx + px] = m.mean[k][c];
+    }
+    nmodes_[px] = (uint8_t)m.nmodes;
+}
+
+// one frame's update of one pixel (Zivkovic's update with the library defaults); returns "background"
+__device__ __forceinline__ bool mix_update(Mix& m, const float data[3], float alphaT, float prune)
 {
 #pragma clang fp contract(off)
-    const int px = blockIdx.x * blockDim.x + threadIdx.x;
-    if (px >= npx) return;
     const float Tb = 16.f, Tg = 9.f, TB = 0.9f;
     const float varInit = 15.f, varMin = 4.f, varMax = 75.f;
     const float alpha1 = 1.f - alphaT;
-
-    float gw[NMIX], gv[NMIX], mean[NMIX][3];
-    int nmodes = nmodes_[px];
-#pragma unroll
-    for (int k = 0; k < NMIX; k++) {
-        if (k < nmodes) {
-            gw[k] = gw_[(size_t)k * npx + px];
-            gv[k] = gv_[(size_t)k * npx + px];
-#pragma unroll
-            for (int c = 0; c < 3; c++) mean[k][c] = mean_[((size_t)k * 3 + c) * npx + px];
-        } else {
-            gw[k] = 0.f; gv[k] = 0.f; mean[k][0] = mean[k][1] = mean[k][2] = 0.f;
-        }
-    }
-    float data[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) data[c] = (float)img[(size_t)px * 3 + c];
+    float (&gw)[NMIX] = m.gw;
+    float (&gv)[NMIX] = m.gv;
+    float (&mean)[NMIX][3] = m.mean;
+    int nmodes = m.nmodes;
 
     bool background = false, fitsPDF = false;
     float totalWeight = 0.f;
@@ -121,33 +140,153 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t* __restrict__ i
             }
         }
     }
+    m.nmodes = nmodes;
+    return background;
+}
+
+__global__ __launch_bounds__(256) void mog2_kernel(const uint8_t* __restrict__ img, int npx,
+                                                   float* __restrict__ gw_, float* __restrict__ gv_,
+                                                   float* __restrict__ mean_, uint8_t* __restrict__ nmodes_,
+                                                   float alphaT, float prune, uint8_t* __restrict__ fg)
+{
+    const int px = blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= npx) return;
+    Mix m;
+    mix_load(m, gw_, gv_, mean_, nmodes_, npx, px);
+    float data[3];
 #pragma unroll
-    for (int k = 0; k < NMIX; k++) {
-        gw_[(size_t)k * npx + px] = gw[k];
-        gv_[(size_t)k * npx + px] = gv[k];
-#pragma unroll
-        for (int c = 0; c < 3; c++) mean_[((size_t)k * 3 + c) * npx + px] = mean[k][c];
-    }
-    nmodes_[px] = (uint8_t)nmodes;
+    for (int c = 0; c < 3; c++) data[c] = (float)img[(size_t)px * 3 + c];
+    const bool background = mix_update(m, data, alphaT, prune);
+    mix_store(m, gw_, gv_, mean_, nmodes_, npx, px);
     fg[px] = background ? 0 : 255;
+}
+
+// An ORDERED RUN of n frames of one stream in one launch (the batch pipeline's shape).  A workgroup owns one
+// 20x20-pixel block of the 380x380 goban = the zone of one intersection (StonesFinder.getrect, stonesfinder.py:412-450;
+// the zones of the last row / column stop at pixel 379: that pixel is updated but not counted); a thread owns a pixel,
+// keeps its mixture in registers across the whole run (state traffic: once per run instead of once per frame) and
+// prefetches the next frame's pixel while updating with the current one.  What leaves the kernel per frame is the
+// number of foreground pixels of the zone -- all SfNeural.is_agitated ever asks of the mask (sf_neural.py:178-180):
+// wave ballots, one LDS add per wave and frame, no global atomics.
+constexpr int ZONE = 20, ZTHREADS = 448;     // 400 pixels, 7 waves
+// The image may be a horizontal BAND of the goban (multi-GPU: the background model is sharded by pixel, each rank
+// keeps a band of intersection rows): h x w pixels, zones of 20 x 20, skip_row / skip_col = the pixel row / column
+// that is updated but not counted (379 of the full image; -1 for a band that does not hold it).
+__global__ __launch_bounds__(ZTHREADS) void mog2_run_kernel(const uint8_t* __restrict__ gobans, int nframes, int h, int w,
+                                                            int skip_row, int skip_col,
+                                                            float* __restrict__ gw_, float* __restrict__ gv_,
+                                                            float* __restrict__ mean_, uint8_t* __restrict__ nmodes_,
+                                                            const float2* __restrict__ rates, int32_t* __restrict__ fgcount,
+                                                            uint8_t* __restrict__ last_fg)
+{
+    extern __shared__ int zcount[];                     // one counter per frame
+    const int zcols = (w + ZONE - 1) / ZONE, nzones = gridDim.x;
+    const int cr = blockIdx.x / zcols, cc = blockIdx.x % zcols, t = threadIdx.x;
+    const int y = cr * ZONE + t / ZONE, x = cc * ZONE + t % ZONE;
+    const bool live = t < ZONE * ZONE && y < h && x < w;
+    const bool counted = live && y != skip_row && x != skip_col;
+    for (int f = t; f < nframes; f += ZTHREADS) zcount[f] = 0;
+    __syncthreads();
+    const int npx = h * w, px = y * w + x;
+    Mix m;
+    float nxt[3] = { 0.f, 0.f, 0.f };
+    if (live) {
+        mix_load(m, gw_, gv_, mean_, nmodes_, npx, px);
+#pragma unroll
+        for (int c = 0; c < 3; c++) nxt[c] = (float)gobans[(size_t)px * 3 + c];
+    }
+    bool background = true;
+    for (int f = 0; f < nframes; f++) {
+        float data[3] = { nxt[0], nxt[1], nxt[2] };
+        if (live && f + 1 < nframes) {
+            const uint8_t* q = gobans + ((size_t)(f + 1) * npx + px) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) nxt[c] = (float)q[c];
+        }
+        const float2 r = rates[f];
+        if (live) background = mix_update(m, data, r.x, r.y);
+        const unsigned long long fgmask = __ballot(counted && !background);
+        if ((t & 63) == 0 && fgmask) atomicAdd(&zcount[f], __popcll(fgmask));
+    }
+    if (live) {
+        mix_store(m, gw_, gv_, mean_, nmodes_, npx, px);
+        if (last_fg) last_fg[px] = background ? 0 : 255;
+    }
+    __syncthreads();
+    for (int f = t; f < nframes; f += ZTHREADS) fgcount[(size_t)f * nzones + blockIdx.x] = zcount[f];
+}
+
+// box sums of a foreground mask over the 361 zones (the per-frame finder's form of the same counts)
+__global__ __launch_bounds__(ZTHREADS) void zone_count_kernel(const uint8_t* __restrict__ mask, int nframes, int side,
+                                                              int32_t* __restrict__ fgcount)
+{
+    __shared__ int acc;
+    const int cells = (side + ZONE - 1) / ZONE;
+    const int f = blockIdx.y, cr = blockIdx.x / cells, cc = blockIdx.x % cells, t = threadIdx.x;
+    const int y = cr * ZONE + t / ZONE, x = cc * ZONE + t % ZONE;
+    const bool counted = t < ZONE * ZONE && y < side && x < side && !(cr == cells - 1 && y == side - 1) &&
+                         !(cc == cells - 1 && x == side - 1);
+    if (t == 0) acc = 0;
+    __syncthreads();
+    const bool on = counted && mask[(size_t)f * side * side + (size_t)y * side + x] != 0;
+    const unsigned long long b = __ballot(on);
+    if ((t & 63) == 0 && b) atomicAdd(&acc, __popcll(b));
+    __syncthreads();
+    if (t == 0) fgcount[(size_t)f * (cells * cells) + blockIdx.x] = acc;
 }
 
 }  // namespace
 
+// learning rate -> (alphaT, prune) exactly as one apply() call derives them; advances the model's frame count
+static void mog2_rate(Mog2State& st, double learning_rate, float* alphaT, float* prune)
+{
+    const int history = 500;
+    ++st.nframes;
+    const int lim = 2 * st.nframes < history ? 2 * st.nframes : history;
+    const double lr = (learning_rate >= 0 && st.nframes > 1) ? learning_rate : 1. / lim;
+    *alphaT = (float)lr;
+    *prune = (float)(-lr * 0.05f);
+}
+
+int k_mog2_run(ck_ctx* ctx, Mog2State& st, const uint8_t* d_gobans, int n, const double* learning_rates,
+               int32_t* d_fgcount, uint8_t* d_last_fg, int skip_row, int skip_col)
+{
+    TimeScope ts(ctx, "mog2");
+    if (n > 8192) return ck_fail(ctx, CK_ERR_CAPACITY, "mog2 run: %d frames in one run (max 8192)", n);
+    std::vector<float> rates((size_t)n * 2);
+    for (int f = 0; f < n; f++) {
+        if (learning_rates[f] >= 1) return ck_fail(ctx, CK_ERR_ARG, "mog2 run: learning rate >= 1 (model reset) inside a run");
+        mog2_rate(st, learning_rates[f], &rates[2 * (size_t)f], &rates[2 * (size_t)f + 1]);
+    }
+    CK_TRY(ck_ensure(ctx, ctx->mats, rates.size() * sizeof(float)));
+    CK_HIP(ctx, hipMemcpyAsync(ctx->mats.p, rates.data(), rates.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));                 // `rates` is a local
+    const int zones = ((st.h + ZONE - 1) / ZONE) * ((st.w + ZONE - 1) / ZONE);
+    hipLaunchKernelGGL(mog2_run_kernel, dim3(zones), dim3(ZTHREADS), (size_t)n * sizeof(int), ctx->stream,
+                       d_gobans, n, st.h, st.w, skip_row, skip_col, (float*)st.weight.p, (float*)st.variance.p, (float*)st.mean.p,
+                       (uint8_t*)st.nmodes.p, (const float2*)ctx->mats.p, d_fgcount, d_last_fg);
+    CK_HIP(ctx, hipGetLastError());
+    return CK_OK;
+}
+
+int k_zone_counts(ck_ctx* ctx, const uint8_t* d_mask, int n, int side, int32_t* d_fgcount)
+{
+    const int cells = (side + ZONE - 1) / ZONE;
+    hipLaunchKernelGGL(zone_count_kernel, dim3(cells * cells, n), dim3(ZTHREADS), 0, ctx->stream, d_mask, n, side, d_fgcount);
+    CK_HIP(ctx, hipGetLastError());
+    return CK_OK;
+}
+
 int k_mog2_apply(ck_ctx* ctx, Mog2State& st, const uint8_t* d_img, double learning_rate, uint8_t* d_fg)
 {
     TimeScope ts(ctx, "mog2");
-    const int history = 500;
     const int npx = st.h * st.w;
     if (learning_rate >= 1) {
         CK_HIP(ctx, hipMemsetAsync(st.nmodes.p, 0, (size_t)npx, ctx->stream));
         st.nframes = 0;
     }
-    ++st.nframes;
-    const int lim = 2 * st.nframes < history ? 2 * st.nframes : history;
-    const double lr = (learning_rate >= 0 && st.nframes > 1) ? learning_rate : 1. / lim;
-    const float alphaT = (float)lr;
-    const float prune = (float)(-lr * 0.05f);
+    float alphaT, prune;
+    mog2_rate(st, learning_rate, &alphaT, &prune);
     hipLaunchKernelGGL(mog2_kernel, dim3((npx + 255) / 256), dim3(256), 0, ctx->stream, d_img, npx,
                        (float*)st.weight.p, (float*)st.variance.p, (float*)st.mean.p, (uint8_t*)st.nmodes.p,
                        alphaT, prune, d_fg);

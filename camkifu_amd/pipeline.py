@@ -1,26 +1,34 @@
-"""Fast video-file processing: batches of frames through the stateless GPU core, sharded over
-the GPUs of one node, one RCCL gather of fixed-size per-frame records, then the ordered host
-fold that carries the reference's temporal logic.
+"""Fast video-file processing: batches of frames through the stateless GPU core, sharded over the GPUs of
+one node, fixed-size per-frame records gathered over RCCL, then the ORDERED fold on rank 0.
 
-What shards and what does not: per frame, K1..K6 (frame -> Hough lines) and, given
-a transform, K8 + K10..K12 (frame -> 19x19 labels) are stateless, so frame f of a batch goes to
-rank f mod world.  Line accumulation over 4 frames, corner clustering, the hold-off after a hit
-and the move-emission policy are stateful and are replayed in frame order on the gathered records.
-There is no data-path collective besides the gather: frames never cross xGMI.
-"""
+What shards and what does not.  Per frame, K1..K6 (frame -> Hough lines) and, given a
+transform, K8 + K10..K12 (frame -> the classifier's answer for its 100 regions) are stateless: frame f of a
+batch goes to rank f mod world and never leaves its GPU.  Stateful, and therefore replayed in frame order on the
+gathered records by ONE rank (the library's ck_boardfold_step / ck_policy_run, the very code the per-frame
+finders call): 4-frame line accumulation, corner clustering, the hold-off after a hit, and the stones policy
+(full assessment, agitation targets, colour-ratio veto, lookback).  The board transform the fold arrives at is
+broadcast back (72 bytes) for the next batch.
+
+The background model (K9, MOG2) is per-pixel state over TIME, so it cannot follow the frame sharding; it shards
+by PIXEL instead: with world > 1 every rank keeps the mixtures of a band of intersection rows, receives that
+band of every goban image of the batch in one all-to-all (xGMI), runs the band through the whole batch in frame
+order (ck_mog2_band_run) and contributes its foreground counts to the gather.  With world == 1 the whole chain
+is one call (ck_stones_run)."""
 import numpy as np
 
-from . import cvconf
+from . import capi, cvconf
 from .golib_shim import gsize, E, B, W
+from .stone import nn_manager as nm
 
-LMAX = 64                                   # Hough lines kept per frame record
-REC_LABELS = 0
-REC_CONF = 368                              # 8-byte aligned
-REC_HDR = REC_CONF + 361 * 8                # status, n_contours, n_lines, pad : 4 x int32
-REC_AREA = REC_HDR + 16                     # biggest_area float64
-REC_LINES = REC_AREA + 8                    # LMAX x (rho, theta) float32
-REC_BYTES = REC_LINES + LMAX * 8            # = 3792
-_COLORS = (E, B, W)
+LMAX = 64                                    # Hough lines carried per frame record (more are flagged, not fatal)
+FLAG_LINES_CUT, FLAG_FAILED = 1, 2
+
+REC = np.dtype([("status", "<i4"), ("n_contours", "<i4"), ("n_lines", "<i4"), ("flags", "<i4"),
+                ("biggest_area", "<f8"), ("lines", "<f4", (LMAX, 2)),
+                ("region_conf", "<f8", (10, 10)), ("region_label", "u1", (10, 10)), ("pad", "u1", (4,))])
+REC_BYTES = REC.itemsize
+assert REC_BYTES % 8 == 0
+_SYMBOL = (E, B, W)
 
 
 def shard_indices(n, rank, world):
@@ -28,105 +36,107 @@ def shard_indices(n, rank, world):
     return np.arange(rank, n, world)
 
 
-def pack_records(board, labels, conf):
-    """board: list of per-frame dicts from Context.board_detect; labels (n,19,19) u8; conf (n,19,19) f64
-    -> (n, REC_BYTES) uint8"""
-    n = len(board)
-    rec = np.zeros((n, REC_BYTES), np.uint8)
+def band_rows(world):
+    """intersection rows [a, b) whose background model lives on each rank (19 rows dealt as evenly as possible)"""
+    cuts = np.linspace(0, gsize, world + 1).round().astype(int)
+    return [(int(cuts[k]), int(cuts[k + 1])) for k in range(world)]
+
+
+def pack_records(board, region_label, region_conf, failed=False):
+    """board: (structured BOARD_DTYPE array, lines (n, cap, 2)) as Context.board_detect(raw=True) returns them, or a
+    list of per-frame dicts; region_label (n, 10, 10) u8; region_conf (n, 10, 10) f64 -> REC array (n,).
+    Never raises on content: a frame with more than LMAX lines keeps the first LMAX (OpenCV's order = most votes
+    first) and is flagged, so that no rank can fail before a collective the others are already waiting in."""
+    if isinstance(board, (list, tuple)) and (len(board) == 0 or isinstance(board[0], dict)):
+        res = np.zeros(len(board), capi.BOARD_DTYPE)
+        lines = np.zeros((len(board), LMAX, 2), np.float32)
+        for f, b in enumerate(board):
+            res[f] = (b["status"], b["n_contours"], b["n_lines"], 0, b["biggest_area"])
+            k = min(int(b["n_lines"]), LMAX, len(b["lines"]))
+            lines[f, :k] = np.asarray(b["lines"], np.float32).reshape(-1, 2)[:k]
+    else:
+        res, lines = board
+    n = len(res)
+    rec = np.zeros(n, REC)
     if n == 0:
         return rec
-    rec[:, REC_LABELS:REC_LABELS + 361] = np.asarray(labels, np.uint8).reshape(n, 361)
-    rec[:, REC_CONF:REC_CONF + 361 * 8] = np.ascontiguousarray(conf, np.float64).reshape(n, 361).view(np.uint8)
-    for f, b in enumerate(board):
-        if b["n_lines"] > LMAX:
-            raise ValueError("frame record holds %d Hough lines, %d found" % (LMAX, b["n_lines"]))
-        hdr = np.array([b["status"], b["n_contours"], b["n_lines"], 0], np.int32)
-        rec[f, REC_HDR:REC_HDR + 16] = hdr.view(np.uint8)
-        rec[f, REC_AREA:REC_AREA + 8] = np.array([b["biggest_area"]], np.float64).view(np.uint8)
-        k = b["n_lines"]
-        if k:
-            rec[f, REC_LINES:REC_LINES + 8 * k] = np.ascontiguousarray(b["lines"][:k], np.float32).reshape(-1).view(np.uint8)
+    for name in ("status", "n_contours", "n_lines", "biggest_area"):
+        rec[name] = res[name]
+    rec["flags"] = np.where(res["n_lines"] > LMAX, FLAG_LINES_CUT, 0) | (FLAG_FAILED if failed else 0)
+    kept = np.minimum(res["n_lines"], LMAX)
+    width = min(LMAX, lines.shape[1])
+    live = np.arange(width)[None, :] < kept[:, None]
+    rec["lines"][:, :width] = np.where(live[..., None], lines[:, :width], np.float32(0))
+    rec["region_label"] = np.asarray(region_label, np.uint8).reshape(n, 10, 10)
+    rec["region_conf"] = np.asarray(region_conf, np.float64).reshape(n, 10, 10)
     return rec
 
 
-def pack_records_raw(res, lines, labels, conf):
-    """vectorised pack_records for Context.board_detect(raw=True) output"""
-    n = len(res)
-    if (res["n_lines"] > LMAX).any():
-        raise ValueError("frame record holds %d Hough lines, %d found" % (LMAX, int(res["n_lines"].max())))
-    rec = np.zeros((n, REC_BYTES), np.uint8)
-    rec[:, REC_LABELS:REC_LABELS + 361] = np.asarray(labels, np.uint8).reshape(n, 361)
-    rec[:, REC_CONF:REC_CONF + 361 * 8] = np.ascontiguousarray(conf, np.float64).reshape(n, 361).view(np.uint8)
-    hdr = np.stack([res["status"], res["n_contours"], res["n_lines"], np.zeros(n, np.int32)], 1).astype(np.int32)
-    rec[:, REC_HDR:REC_HDR + 16] = hdr.view(np.uint8).reshape(n, 16)
-    rec[:, REC_AREA:REC_AREA + 8] = np.ascontiguousarray(res["biggest_area"], np.float64).view(np.uint8).reshape(n, 8)
-    keep = np.arange(LMAX)[None, :] < res["n_lines"][:, None]               # lines beyond n_lines are zeroed
-    ln = np.where(keep[..., None], np.ascontiguousarray(lines[:, :LMAX], np.float32), np.float32(0))
-    rec[:, REC_LINES:REC_LINES + LMAX * 8] = np.ascontiguousarray(ln).view(np.uint8).reshape(n, LMAX * 8)
-    return rec
+def grid_of(region_label, region_conf=None):
+    """(n, 10, 10) region labels -> the (n, 19, 19) grid NNCache.predict_all_stones builds (later regions win on
+    row / column 17); with region_conf also the per-intersection confidences"""
+    lab = np.asarray(region_label)
+    n = lab.shape[0]
+    cell_region = np.minimum(np.arange(gsize) // nm.STEP, nm.SPLIT - 1)
+    cell_region[gsize - nm.STEP:] = nm.SPLIT - 1
+    local = np.arange(gsize) - nm.REGION_START[cell_region]
+    digit = local[:, None] * nm.STEP + local[None, :]
+    per_cell = lab[:, cell_region[:, None], cell_region[None, :]]
+    grid = nm.DIGITS[per_cell, np.broadcast_to(digit, (n, gsize, gsize))]
+    if region_conf is None:
+        return grid
+    return grid, np.asarray(region_conf)[:, cell_region[:, None], cell_region[None, :]]
 
 
-def unpack_record(rec):
-    hdr = rec[REC_HDR:REC_HDR + 16].view(np.int32)
-    k = int(hdr[2])
-    return dict(status=int(hdr[0]), n_contours=int(hdr[1]), n_lines=k,
-                biggest_area=float(rec[REC_AREA:REC_AREA + 8].view(np.float64)[0]),
-                lines=rec[REC_LINES:REC_LINES + 8 * k].view(np.float32).reshape(k, 2).copy(),
-                labels=rec[REC_LABELS:REC_LABELS + 361].reshape(19, 19).copy(),
-                conf=rec[REC_CONF:REC_CONF + 361 * 8].view(np.float64).reshape(19, 19).copy())
+class _Group:
+    """the few collectives the pipeline needs, on whatever backend torch.distributed was initialised with
+    (nccl = RCCL over xGMI on GPUs, gloo on CPU); world == 1 needs no process group at all"""
 
+    def __init__(self, rank, world, device):
+        self.rank, self.world, self.device = rank, world, device
 
-def unpack_records(rec):
-    """vectorised view of an (n, REC_BYTES) record array -> dict of arrays (lines stay packed:
-    use lines[f, :n_lines[f]])"""
-    n = len(rec)
-    hdr = np.ascontiguousarray(rec[:, REC_HDR:REC_HDR + 16]).view(np.int32).reshape(n, 4)
-    return dict(status=hdr[:, 0], n_contours=hdr[:, 1], n_lines=hdr[:, 2],
-                biggest_area=np.ascontiguousarray(rec[:, REC_AREA:REC_AREA + 8]).view(np.float64).reshape(n),
-                lines=np.ascontiguousarray(rec[:, REC_LINES:REC_LINES + LMAX * 8]).view(np.float32).reshape(n, LMAX, 2),
-                labels=rec[:, REC_LABELS:REC_LABELS + 361].reshape(n, 19, 19),
-                conf=np.ascontiguousarray(rec[:, REC_CONF:REC_CONF + 361 * 8]).view(np.float64).reshape(n, 19, 19))
+    def _t(self, a):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(self.device) if self.device is not None else t
 
+    def all_gather_rows(self, local, per):
+        """each rank contributes `per` rows (padded with zeros) -> (world, per, ...) on every rank"""
+        import torch
+        import torch.distributed as dist
+        buf = np.zeros((per,) + local.shape[1:], local.dtype)
+        buf[:len(local)] = local
+        flat = self._t(buf.view(np.uint8).reshape(per, -1))
+        out = torch.empty((self.world * per, flat.shape[1]), dtype=torch.uint8, device=flat.device)
+        dist.all_gather_into_tensor(out, flat)
+        return out.cpu().numpy().reshape(self.world, per, -1).view(local.dtype).reshape((self.world, per) + local.shape[1:])
 
-def gather_records(local, n_total, rank, world, device=None):
-    """One all-gather of this rank's records; returns the (n_total, REC_BYTES) array in frame order.
-    `torch.distributed` must be initialised when world > 1 (backend nccl = RCCL on GPUs, gloo on CPU)."""
-    if world == 1:
-        return local
-    import torch
-    import torch.distributed as dist
-    per = (n_total + world - 1) // world                       # ranks with fewer frames pad
-    buf = torch.zeros((per, REC_BYTES), dtype=torch.uint8, device=device)
-    if len(local):
-        buf[:len(local)] = torch.from_numpy(local).to(buf.device)
-    out = torch.empty((world * per, REC_BYTES), dtype=torch.uint8, device=buf.device)
-    dist.all_gather_into_tensor(out, buf)
-    out = out.cpu().numpy().reshape(world, per, REC_BYTES)
-    full = np.zeros((n_total, REC_BYTES), np.uint8)
-    for r in range(world):
-        idx = shard_indices(n_total, r, world)
-        full[idx] = out[r, :len(idx)]
-    return full
+    def broadcast_array(self, a, src=0):
+        import torch.distributed as dist
+        t = self._t(a)
+        dist.broadcast(t, src)
+        return t.cpu().numpy()
 
-
-class _Shape:
-    """what BoardFinderAuto._detect needs from a frame once the image chain has run: its shape"""
-
-    def __init__(self, h, w):
-        self.shape = (h, w, 3)
+    def all_to_all_bands(self, send_parts, recv_sizes):
+        """send_parts[d]: torch uint8 tensor for rank d; recv_sizes[s]: bytes rank s sends here (both sides can
+        work them out from the batch size) -> list of what every rank sent here"""
+        import torch
+        import torch.distributed as dist
+        send = torch.cat([p.reshape(-1) for p in send_parts])
+        recv = torch.empty(int(sum(recv_sizes)), dtype=torch.uint8, device=send.device)
+        dist.all_to_all_single(recv, send, [int(r) for r in recv_sizes], [int(p.numel()) for p in send_parts])
+        return list(torch.split(recv, [int(r) for r in recv_sizes]))
 
 
 class BoardFold:
-    """Ordered replay of BoardFinderAuto's temporal logic on per-frame records.  The wall-clock
-    hold-off after a hit (bf_auto.py:43-49, 10 s) becomes a frame count at the file read rate."""
+    """Ordered replay of the board finder on per-frame records: BoardFinderAuto._detect is called with the record in
+    place of the GPU call.  The 10 s wall-clock hold-off after a hit (bf_auto.py:43-49) is a frame count here."""
 
     def __init__(self, h, w, refresh_frames=None):
         from .board.bf_auto import BoardFinderAuto
-
-        class _VM:
-            imqueue = None
-        self.finder = BoardFinderAuto(_VM(), ctx=False)        # ctx=False: records only, no GPU calls
-        self.frame = _Shape(h, w)
+        manager = type("FoldOnly", (), {"imqueue": None})()
+        self.finder = BoardFinderAuto(manager)
+        self.frame = np.zeros((h, w, 0), np.uint8)          # what _detect needs of a frame once the image chain ran: its shape
         self.refresh_frames = 10 * cvconf.file_fps if refresh_frames is None else refresh_frames
         self.hold = 0
 
@@ -135,143 +145,231 @@ class BoardFold:
         return self.finder.mtx
 
     def step(self, rec):
+        """rec: one REC row (or a dict with status / n_lines / lines ...)"""
         f = self.finder
         if self.hold > 0:
             self.hold -= 1
         else:
+            k = min(int(rec["n_lines"]), LMAX, len(rec["lines"]))
             f.corners.frame = self.frame
-            if f._detect(self.frame, core=rec):
-                from . import capi
-                f.mtx = capi.get_perspective_transform(np.array(f.corners.hull, np.float32), f.transform_dst)
-                self.hold = self.refresh_frames
+            hit = f._detect(self.frame, record=dict(status=int(rec["status"]), n_lines=k, lines=np.asarray(rec["lines"])[:k]))
+            if hit:
+                try:
+                    f.mtx = capi.get_perspective_transform(np.asarray(f.corners.hull, np.float32), f.transform_dst)
+                    self.hold = self.refresh_frames
+                except (capi.CkError, TypeError, ValueError):
+                    f.mtx = None                             # degenerate quadrilateral: keep looking
         f.total_f_processed += 1
         return f.mtx
 
+    def run(self, recs):
+        k, n = 0, len(recs)
+        while k < n:
+            if self.hold > 0:                                # nothing is looked at during the hold-off
+                skip = min(self.hold, n - k)
+                self.hold -= skip
+                self.finder.total_f_processed += skip
+                k += skip
+                continue
+            self.step(recs[k])
+            k += 1
+        return self.mtx
+
 
 class StonesFold:
-    """Per-frame full-board assessment (NNCache.predict_all_stones + SfNeural.predict_all's
-    acceptance rule: colour != E and confidence > 0.6) pushed to the controller with
-    StonesFinder.bulk_update semantics."""
+    """Ordered replay of SfNeural on per-frame records through the SAME policy object the per-frame finder uses
+    (capi.PolicyCore -> ck_policy_run), requests applied to the controller with StonesFinder's sink semantics.
+    Python is only entered for frames that emit something."""
 
-    MIN_CONFIDENCE = 0.6
-
-    def __init__(self, controller):
+    def __init__(self, controller, bg_init_frames=50):
+        from .stone.stonesfinder import StoneSink
         self.controller = controller
-        self.cur = None                        # cached goban as uint8 (19,19): 0 E, 1 B, 2 W
-        # prisoners the rule engine took off the goban but the camera may still show: (r, c) -> label.
-        # They are not suggested again until the intersection has been seen empty or recoloured.
-        self.prisoners = {}
+        self.sink = StoneSink(lambda: self.controller)
+        self.policy = capi.PolicyCore(bg_init_frames)
+        self.bg_init_frames = bg_init_frames
+        self.frames_seen = 0                                 # = SfNeural.total_f_processed
+        self.refused = []
 
-    def resync(self):
-        """re-read the goban from the controller (once per batch: somebody else may edit it)"""
-        st = self.controller.get_stones()
-        self.cur = np.zeros((gsize, gsize), np.uint8)
-        self.cur[st == B] = 1
-        self.cur[st == W] = 2
-
-    def step(self, labels, conf):
-        from .golib_shim import Move, NP_TYPE
-        if self.cur is None:
-            self.resync()
-        change = (labels != 0) & (conf > self.MIN_CONFIDENCE) & (labels != self.cur)
-        if self.prisoners:
-            for (r, c), lab in list(self.prisoners.items()):
-                if labels[r, c] == lab:
-                    change[r, c] = False                     # still lying on the board: not a new stone
-                else:
-                    del self.prisoners[(r, c)]               # taken away (or replaced): watch over
-        if not change.any():
-            return []
-        moves = []
-        for r, c in np.argwhere(change):          # raster order, like the reference's double loop
-            r, c = int(r), int(c)
-            color = _COLORS[labels[r, c]]
-            if self.cur[r, c] != 0:
-                moves.append(Move(NP_TYPE, (E, r, c)))       # clear first, then recolour
-            moves.append(Move(NP_TYPE, (color, r, c)))
-            self.cur[r, c] = labels[r, c]
-        if getattr(self.controller, "rules", None) is None:
-            self.controller.pipe("bulk", moves)
-        else:
-            # one instruction per stone so the prisoners of each can be taken off the cached goban
-            for mv in moves:
-                self.controller.pipe("bulk", [mv])
-                for col, cx, cy in (self.controller.last_captured if mv.color != E else ()):
-                    self.prisoners[(cy, cx)] = 1 if col == B else 2
-                    self.cur[cy, cx] = 0
-        self.controller.pipe("auto_save")
-        return moves
-
-    def step_batch(self, labels, conf):
-        """ordered fold of a whole batch; frames whose accepted labels equal the cached goban are
-        skipped without touching Python per frame -> list of per-frame move lists"""
-        if self.cur is None:
-            self.resync()
-        n = len(labels)
-        acc = np.where(conf > self.MIN_CONFIDENCE, labels, 0)           # accepted colour or 0
-        # a frame can only emit moves if it differs from the goban as left by its predecessor;
-        # cheap superset: differs from the previous frame's accepted labels or from the cache
-        prev = np.concatenate([self.cur[None], acc[:-1]])
-        cand = ((acc != prev) & (acc != 0)).reshape(n, -1).any(1)
+    def run(self, region_label, region_conf, fgcount):
+        """-> per-frame lists of (kind, [(colour, r, c), ...]) requests, in frame order"""
+        n = len(region_label)
         out = [[] for _ in range(n)]
-        for f in np.flatnonzero(cand | (np.arange(n) == 0)):
-            out[f] = self.step(labels[f], conf[f])
+
+        def apply(kind, moves, k):
+            named = [(_SYMBOL[col], r, c) for col, r, c in moves]
+            out[k].append((kind, named))
+            from .core.exceptions import DeletedError
+            try:
+                if kind == capi.PolicyCore.SUGGEST:
+                    self.sink.suggest(*named[0], doprint=False)
+                else:
+                    self.sink.bulk_update(named)
+            except DeletedError as locked:                   # no user, no deletion watch in a batch run: cannot happen
+                self.refused.append(locked)
+        self.policy.run(self.frames_seen, region_label, region_conf, fgcount, self.sink.board_codes, apply)
+        self.frames_seen += n
         return out
 
 
-class FastFilePipeline:
-    """compute(frames, mtx) -> (board list, labels, conf) is the stateless per-shard core; by
-    default it is the HIP context (ck_board_detect + ck_stones_detect)."""
+def learning_rates(first, n, bg_init_frames):
+    """the background model's rate for stones-frames first .. first + n - 1 (stonesfinder.py:171-176)"""
+    return np.where(first + np.arange(n) < bg_init_frames, 0.01, 0.005)
 
-    def __init__(self, h, w, controller, ctx=None, rank=0, world=1, device=None, compute=None, ctx_board=None):
-        """ctx runs the stones path; ctx_board (optional second context = second HIP stream) lets the
-        board path run concurrently on its own host thread, as the reference's two finder threads do"""
+
+class FastFilePipeline:
+    """process_batch(my_frames, n_total): this rank's shard of a batch -> (on rank 0) the requests the fold emitted.
+
+    `compute(frames, mtx, learning_rates)` is the per-shard GPU core; by default ck_board_detect + ck_stones_run on
+    two contexts (= two HIP streams, two host threads, as the reference's two finder threads).  It returns
+    (board, region_label, region_conf, fgcount or None, gobans or None); `gobans` (device tensor n x 380 x 380 x 3) is
+    only needed when world > 1, for the pixel-sharded background model."""
+
+    def __init__(self, h, w, controller, ctx=None, rank=0, world=1, device=None, compute=None, ctx_board=None,
+                 bg_init_frames=50, band_model=None):
         self.h, self.w = h, w
-        self.rank, self.world, self.device = rank, world, device
-        self.ctx = ctx
-        self.ctx_board = ctx_board
+        self.rank, self.world = rank, world
+        self.group = _Group(rank, world, device)
+        self.ctx, self.ctx_board = ctx, ctx_board
         self._pool = None
         self.compute = compute or self._gpu_compute
         self.board = BoardFold(h, w)
-        self.stones = StonesFold(controller)
+        self.stones = StonesFold(controller, bg_init_frames)
+        self.bg_init_frames, self.stone_frames = bg_init_frames, 0      # frames the stones path has seen (every rank counts)
+        self.mtx = None                                       # what every rank warps with (rank 0's fold, broadcast)
         self.frames_done = 0
+        self._mog2 = None
+        self.band = band_rows(world)[rank]
+        self.band_model = band_model                          # callable(gobans_band (n, rows, 380, 3), rates) -> counts (n, band, 19)
+        self.errors = []
 
-    def _gpu_compute(self, frames, mtx):
-        if self.ctx_board is not None and mtx is not None:
+    # ---- per-shard GPU core -----------------------------------------------------------------------------
+    def _gpu_compute(self, frames, mtx, rates):
+        bctx = self.ctx_board or self.ctx
+        if len(frames) == 0:
+            return (np.zeros(0, capi.BOARD_DTYPE), np.zeros((0, LMAX, 2), np.float32)), np.zeros((0, 10, 10), np.uint8), \
+                np.zeros((0, 10, 10)), None, None
+        if mtx is None:
+            board = bctx.board_detect(frames, cap=LMAX, raw=True)
+            return board, np.zeros((len(frames), 10, 10), np.uint8), np.zeros((len(frames), 10, 10)), None, None
+        fut = None
+        if self.ctx_board is not None:
             if self._pool is None:
                 from concurrent.futures import ThreadPoolExecutor
                 self._pool = ThreadPoolExecutor(1)
-            fut = self._pool.submit(self.ctx_board.board_detect, frames, -1, LMAX)
-            labels, conf = self.ctx.stones_detect(frames, mtx)
-            board = fut.result()
+            fut = self._pool.submit(bctx.board_detect, frames, -1, LMAX, True)
+        gobans = None
+        if self.world == 1:
+            if self._mog2 is None:
+                self._mog2 = self.ctx.mog2_create(380, 380)
+            out = self.ctx.stones_run(frames, mtx, mog2=self._mog2, learning_rates=rates)
+            fg = out["fgcount"]
         else:
-            board = (self.ctx_board or self.ctx).board_detect(frames, cap=LMAX)
-            if mtx is None:
-                n = len(board)
-                return board, np.zeros((n, 19, 19), np.uint8), np.zeros((n, 19, 19), np.float64)
-            labels, conf = self.ctx.stones_detect(frames, mtx)
-        if hasattr(labels, "cpu"):
-            labels, conf = labels.cpu().numpy(), conf.cpu().numpy()
-        return board, labels, conf
+            gobans = self.ctx.warp_perspective(frames, mtx)
+            rl, rc = self.ctx.cnn_regions(gobans)
+            out, fg = dict(region_label=rl, region_conf=rc), None
+        board = fut.result() if fut is not None else bctx.board_detect(frames, cap=LMAX, raw=True)
+        as_np = lambda t: t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t)     # noqa: E731
+        return board, as_np(out["region_label"]), as_np(out["region_conf"]), (None if fg is None else as_np(fg)), gobans
 
+    # ---- pixel-sharded background model (world > 1) -------------------------------------------------------
+    def _band_counts(self, gobans, n_total, rates):
+        """all-to-all of goban bands, this rank's band through the whole batch in frame order -> its counts
+        (n_total, band rows, 19)"""
+        import torch
+        bands = band_rows(self.world)
+        px = [(20 * a, min(20 * b, 380)) for a, b in bands]
+        if gobans is None:
+            gobans = torch.zeros((0, 380, 380, 3), dtype=torch.uint8, device=self.group.device or "cpu")
+        if not hasattr(gobans, "numel"):
+            gobans = torch.from_numpy(np.ascontiguousarray(gobans))
+            if self.group.device is not None:
+                gobans = gobans.to(self.group.device)
+        lo, hi = px[self.rank]
+        expect = [len(shard_indices(n_total, src, self.world)) * (hi - lo) * 380 * 3 for src in range(self.world)]
+        parts = self.group.all_to_all_bands([gobans[:, a:b].contiguous() for a, b in px], expect)
+        full = torch.empty((n_total, hi - lo, 380, 3), dtype=torch.uint8, device=parts[0].device)
+        for src, part in enumerate(parts):
+            idx = shard_indices(n_total, src, self.world)
+            full[torch.as_tensor(idx, device=full.device)] = part.reshape(len(idx), hi - lo, 380, 3)
+        counts = self._band_model()(full, rates)
+        counts = counts.cpu().numpy() if hasattr(counts, "cpu") else np.asarray(counts)
+        return counts.astype(np.int32).reshape(n_total, bands[self.rank][1] - bands[self.rank][0], gsize)
+
+    def _band_model(self):
+        if self.band_model is None:
+            a, b = self.band
+            handle = self.ctx.mog2_create(min(20 * b, 380) - 20 * a, 380)
+            last = b == gsize
+
+            def run(band_gobans, rates):
+                return self.ctx.mog2_band_run(handle, band_gobans, rates, last_band=last)
+            self.band_model = run
+        return self.band_model
+
+    # ---- one batch --------------------------------------------------------------------------------------
     def process_batch(self, my_frames, n_total):
-        """my_frames: this rank's shard (frames rank, rank+world, ... of the batch).  The transform
-        used for the stones path is the one known at the start of the batch (board assumed fixed
-        within a batch; it is re-estimated by the fold for the next one).  Returns the per-frame
-        move lists emitted by the fold (identical on every rank)."""
-        mtx = self.board.mtx
-        board, labels, conf = self.compute(my_frames, mtx)
-        rec = pack_records(board, labels, conf)
-        full = gather_records(rec, n_total, self.rank, self.world, self.device)
-        return self.fold(full, mtx is not None)
+        """my_frames: frames rank, rank + world, ... of the batch.  The transform used for the stones path is the one
+        known when the batch starts.  Returns the fold's per-frame request lists on rank 0, None elsewhere."""
+        mtx = self.mtx
+        rates = learning_rates(self.stone_frames, n_total, self.bg_init_frames) if mtx is not None else np.zeros(n_total)
+        mine = shard_indices(n_total, self.rank, self.world)
+        failed = False
+        try:
+            board, rl, rc, fg, gobans = self.compute(my_frames, mtx, rates[mine])
+        except Exception as why:                              # never leave the other ranks alone in a collective
+            self.errors.append(why)
+            failed, fg, gobans = True, None, None
+            board = (np.zeros(len(mine), capi.BOARD_DTYPE), np.zeros((len(mine), LMAX, 2), np.float32))
+            rl, rc = np.zeros((len(mine), 10, 10), np.uint8), np.zeros((len(mine), 10, 10))
+        rec = pack_records(board, rl, rc, failed=failed)
+        if self.world == 1:
+            full, counts = rec, fg
+        else:
+            per = (n_total + self.world - 1) // self.world
+            got = self.group.all_gather_rows(rec, per)
+            full = np.zeros(n_total, REC)
+            for r in range(self.world):
+                idx = shard_indices(n_total, r, self.world)
+                full[idx] = got[r, :len(idx)]
+            counts = None
+            if mtx is not None:
+                mine_counts = self._band_counts(gobans, n_total, rates)                   # (n_total, rows, 19)
+                widest = max(b - a for a, b in band_rows(self.world))
+                slab = np.zeros((1, n_total, widest, gsize), np.int32)
+                slab[0, :, :mine_counts.shape[1]] = mine_counts
+                allc = self.group.all_gather_rows(slab, 1)[:, 0]                         # (world, n_total, widest, 19)
+                counts = np.concatenate([allc[r, :, :b - a] for r, (a, b) in enumerate(band_rows(self.world))], 1)
+        if (full["flags"] & FLAG_FAILED).any():
+            raise RuntimeError("a rank failed in the GPU core of this batch: %s" % (self.errors[-1:] or "see its log"))
+        emitted = None
+        if self.rank == 0:
+            emitted = self.fold(full, counts, mtx is not None)
+            new = self.board.mtx
+        if self.world > 1:
+            wire = np.zeros(10)
+            if self.rank == 0 and new is not None:
+                wire[0], wire[1:] = 1.0, np.asarray(new, np.float64).reshape(9)
+            wire = self.group.broadcast_array(wire, 0)
+            self.mtx = wire[1:].reshape(3, 3).copy() if wire[0] else None
+        else:
+            self.mtx = new
+        self.frames_done += n_total
+        if mtx is not None:
+            self.stone_frames += n_total
+        return emitted
+
+    def fold(self, full, counts, have_mtx=True):
+        """ordered replay of both finders on the gathered records of one batch (rank 0)"""
+        self.board.run(full)
+        if not have_mtx:
+            return [[] for _ in range(len(full))]
+        return self.stones.run(full["region_label"], full["region_conf"], counts)
 
     def process_y4m(self, capture, batch=256, file_fps=None, torch_device=None):
-        """Fast processing of a video file (README "Fast video file processing"; frame selection as
-        CaptureReaderBase.skip, core/vmanager.py:511-525).  `capture` is a core.capture.Y4MCapture: the
-        frames to analyse are dealt to the ranks batch by batch (frame k of a batch -> rank k mod world),
-        each rank uploads ITS frames as I420 (1.5 B/px through a reused pinned buffer) and converts them
-        to BGR in HBM (ck_i420_to_bgr), then the batch goes through process_batch.
-        Returns the concatenated per-frame move lists."""
+        """Fast processing of a video file (README "Fast video file processing"; frame selection as the reference's
+        file reader, core/vmanager.py:510-525).  The frames to analyse are dealt to the ranks batch by batch; each rank
+        uploads ITS frames as I420 (1.5 B/px through a reused pinned buffer), converts them in HBM (ck_i420_to_bgr)
+        and the batch goes through process_batch.  Returns the concatenated request lists (rank 0)."""
         import torch
         from .core.capture import file_frame_indices
         idx = file_frame_indices(len(capture), capture.fps, file_fps)
@@ -281,33 +379,13 @@ class FastFilePipeline:
             chunk = idx[b0:b0 + batch]
             mine = [chunk[k] for k in shard_indices(len(chunk), self.rank, self.world)]
             if pinned is None:
-                cap_rows = len(shard_indices(batch, 0, self.world))
-                pinned = torch.empty((cap_rows, capture.fsize), dtype=torch.uint8).pin_memory()
+                pinned = torch.empty((len(shard_indices(batch, 0, self.world)), capture.fsize), dtype=torch.uint8).pin_memory()
             raw = capture.read_raw_batch(mine, out=pinned.numpy())
             if len(mine):
                 frames = self.ctx.i420_to_bgr(raw, capture.h, capture.w, to_device=dev)
             else:
                 frames = torch.empty((0, capture.h, capture.w, 3), dtype=torch.uint8, device=dev)
-            emitted.extend(self.process_batch(frames, len(chunk)))
-        return emitted
-
-    def fold(self, full, have_mtx=True):
-        """ordered replay of the temporal logic on the gathered records of one batch"""
-        u = unpack_records(full)
-        n = len(full)
-        self.stones.resync()
-        f = 0
-        while f < n:
-            if self.board.hold > 0:                    # hold-off after a hit: nothing to look at
-                skip = min(self.board.hold, n - f)
-                self.board.hold -= skip
-                self.board.finder.total_f_processed += skip
-                f += skip
-                continue
-            k = int(u["n_lines"][f])
-            self.board.step(dict(status=int(u["status"][f]), n_contours=int(u["n_contours"][f]), n_lines=k,
-                                 biggest_area=float(u["biggest_area"][f]), lines=u["lines"][f, :k]))
-            f += 1
-        emitted = self.stones.step_batch(u["labels"], u["conf"]) if have_mtx else [[] for _ in range(n)]
-        self.frames_done += n
+            out = self.process_batch(frames, len(chunk))
+            if out is not None:
+                emitted.extend(out)
         return emitted

@@ -1,57 +1,47 @@
-"""NNCache: per-frame memo of the classifier's outputs (mirror of the reference's
-stone/nn_cache.py:8-58).  The reference runs one batch-1 Keras predict per 40x40 patch; here the
-first request of a frame runs all 100 patches in ONE GPU call (K10..K12) and the rest are reads."""
+"""NNCache: one frame's classifier answers, asked for once.
+
+The reference memoises one batch-1 Keras predict per 40x40 patch (stone/nn_cache.py:8-58).  Here the first
+question about a frame runs all 100 patches in ONE GPU call (ck_cnn_regions, K10..K12) that returns what every
+query of the class boils down to -- per region its argmax label and max(y)/sum(y) -- and the three
+predict_* methods are table lookups on that."""
 import numpy as np
 
 from ..golib_shim import gsize
+from . import nn_manager as nm
 
 
 class NNCache:
     def __init__(self, nn_manager, img, ctx):
-        assert img.shape[0:2] == nn_manager.canonical_shape
-        self.manager = nn_manager
-        self.img = img
-        self.ctx = ctx
-        self._y = None                       # (100, 81) softmax outputs, filled on first use
+        if tuple(img.shape[:2]) != tuple(nn_manager.canonical_shape):
+            raise ValueError("goban image must be %s, got %s" % (nn_manager.canonical_shape, img.shape))
+        self.manager, self.img, self.ctx = nn_manager, img, ctx
+        self._regions = None
 
-    def _all_y(self):
-        if self._y is None:
-            y, _, _ = self.ctx.cnn_predict(self.img)
-            self._y = y[0]
-        return self._y
-
-    def predict_y(self, i, j):
-        return self._all_y()[i * self.manager.split + j]
-
-    def predict_all_y(self):
-        return self._all_y().reshape(self.manager.split, self.manager.split, -1)
-
-    @staticmethod
-    def _confidence(y):
-        tot = 0.0                            # python sum() over float32 scalars: float64, in order
-        for v in y:
-            tot = tot + float(v)
-        return float(max(y)) / tot
+    def regions(self):
+        """-> (labels uint8 (10, 10), confidences float64 (10, 10)) of this frame"""
+        if self._regions is None:
+            lab, conf = self.ctx.cnn_regions(self.img)
+            self._regions = np.asarray(lab)[0], np.asarray(conf)[0]
+        return self._regions
 
     def predict_4_stones(self, i, j):
-        y = self.predict_y(i, j)
-        rs, re, cs, ce = self.manager._subregion(i, j)
-        stones = self.manager.compute_stones(int(np.argmax(y))).reshape((re - rs, ce - cs))
-        return stones, self._confidence(y)
+        lab, conf = self.regions()
+        return nm.SYMBOLS[nm.DIGITS[lab[i, j]]].reshape(nm.STEP, nm.STEP), float(conf[i, j])
 
     def predict_stone(self, r, c):
-        i, j = self.manager.get_region_indices(r, c)
-        y = self.predict_y(i, j)
-        stones = self.manager.compute_stones(int(np.argmax(y)))
-        step = self.manager.step
-        return stones[step * (r % step) + c % step], self._confidence(y)
+        # NB: the region is (r // 2, c // 2) and the entry 2 * (r % 2) + c % 2 of its four stones, which on row / column
+        # 18 is the region's FIRST row / column -- the reference's arithmetic (nn_cache.py:16-23), kept as it is
+        lab, conf = self.regions()
+        i, j = r // nm.STEP, c // nm.STEP
+        return nm.SYMBOLS[nm.DIGITS[lab[i, j], nm.STEP * (r % nm.STEP) + c % nm.STEP]], float(conf[i, j])
 
     def predict_all_stones(self):
-        stones = np.ndarray((gsize, gsize, 2), dtype=object)
-        for i in range(self.manager.split):
-            for j in range(self.manager.split):
-                rs, re, cs, ce = self.manager._subregion(i, j)
-                square, confidence = self.predict_4_stones(i, j)
-                stones[rs:re, cs:ce, 0] = square
-                stones[rs:re, cs:ce, 1] = confidence
-        return stones
+        """(19, 19, 2) object array [colour, confidence]; regions are laid down in raster order, so on row / column
+        17 the last region's answer stands"""
+        lab, conf = self.regions()
+        out = np.empty((gsize, gsize, 2), dtype=object)
+        for i, rs in enumerate(nm.REGION_START):
+            for j, cs in enumerate(nm.REGION_START):
+                out[rs:rs + nm.STEP, cs:cs + nm.STEP, 0] = nm.SYMBOLS[nm.DIGITS[lab[i, j]]].reshape(nm.STEP, nm.STEP)
+                out[rs:rs + nm.STEP, cs:cs + nm.STEP, 1] = float(conf[i, j])
+        return out

@@ -1,56 +1,73 @@
-"""NNManager: patch geometry, base-3 label codec and the classifier itself (mirror of the
-inference side of the reference's stone/nn_manager.py:29-131, 216-298, 360-382).  The Keras
-model becomes a weight dictionary handed to the HIP library (K10..K12); training and the
-labelling GUI are out of scope."""
-import math
+"""NNManager: region geometry, the base-3 label codec and the classifier's weights -- the inference side of the
+reference's stone/nn_manager.py (29-131, 216-298, 360-382) under the same method names, built on small lookup
+tables instead of per-call loops.  The Keras model is a dictionary of twelve float32 arrays handed to the HIP
+library (K10..K12, ck_cnn_set_weights); training and the labelling GUI are out of scope.
+
+Tables (gsize 19, 10 x 10 regions of 2 x 2 intersections, the last region pulled back onto rows 17-18):
+    REGION_START[i]  first row (or column) of region i            0, 2, ..., 16, 17
+    DIGITS[label]    the four base-3 digits of a label, least significant first = intersections
+                     (0,0) (0,1) (1,0) (1,1) of the region         nn_manager.py:236-254
+    PATCH_ORIGIN[i]  first pixel of region i's 40-pixel window     0, 40, ..., 320, 340
+"""
 import os
 import threading
 
 import numpy as np
 
-from .. import capi, cvconf
+from .. import cvconf
 from ..golib_shim import gsize, E, B, W
 
-colors = {E: 0, B: 1, W: 2}
-rcolors = {0: E, 1: B, 2: W}
-# The trained model file (reference: KERAS_MODEL_FILE = cvconf.train_dir + "/model/keras.h5",
-# stone/nn_manager.py:22).  The author's file cannot be fetched here; the repository ships a classifier
-# trained on the synthetic renderer (tools/train_cnn.py) in the same Keras-1 HDF5 layout.
-KERAS_MODEL_FILE = os.environ.get("CAMKIFU_KERAS_MODEL") or os.path.join(
-    os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "keras.h5")
+SPLIT = 10
+STEP = (gsize + 1) // SPLIT
+NB_CLASSES = 3 ** (STEP * STEP)
+REGION_START = np.minimum(np.arange(SPLIT) * STEP, gsize - STEP)
+DIGITS = ((np.arange(NB_CLASSES)[:, None] // 3 ** np.arange(STEP * STEP)[None, :]) % 3).astype(np.uint8)
+SYMBOLS = np.array([E, B, W], dtype=object)
+CODE = {E: 0, B: 1, W: 2}
+CELL_PX = cvconf.canonical_size // gsize
+PATCH_ORIGIN = REGION_START * CELL_PX
+PATCH_SIDE = STEP * CELL_PX
+
+# The trained model file.  The reference downloads the author's keras.h5 into its training directory
+# (stone/nn_manager.py:22, 65-90); that file cannot be fetched here, so the package ships a classifier trained on the
+# synthetic renderer (tools/train_cnn.py) in the same Keras-1 HDF5 layout.  $CAMKIFU_KERAS_MODEL overrides the path.
+PACKAGED_MODEL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "keras.h5")
+KERAS_MODEL_FILE = os.environ.get("CAMKIFU_KERAS_MODEL") or PACKAGED_MODEL
 GOLDEN_WEIGHTS = KERAS_MODEL_FILE
 
 
+class ModelMissing(FileNotFoundError):
+    pass
+
+
 class NNManager:
-    _network = None          # weight dict, shared like the reference's lazily created Keras model
-    _netlock = threading.RLock()
-    _depth = 3
+    _network = None                  # the weights, loaded once per process like the reference's lazily built model
+    _guard = threading.RLock()
 
     def __init__(self):
-        self.canonical_shape = (cvconf.canonical_size, cvconf.canonical_size)
-        self.split = 10
-        self.step = (gsize + 1) // self.split
-        self.nb_classes = 3 ** (int((gsize + 1) / self.split) ** 2)
-        x0, x1, y0, y1 = self._get_rect_nn(*self._subregion(0, 0))
-        self.r_width = y1 - y0
-        self.c_width = x1 - x0
+        self.canonical_shape = (cvconf.canonical_size,) * 2
+        self.split, self.step, self.nb_classes = SPLIT, STEP, NB_CLASSES
+        self.r_width = self.c_width = PATCH_SIDE
         self.c_indices = None
 
-    @staticmethod
-    def get_net(download=False):
-        with NNManager._netlock:
-            if NNManager._network is None:
-                NNManager._network = NNManager.init_net()
-            return NNManager._network
+    # ---- model ---------------------------------------------------------------------------------
+    @classmethod
+    def get_net(cls, download=False):
+        with cls._guard:
+            if cls._network is None:
+                cls._network = cls.init_net()
+            return cls._network
 
     @staticmethod
-    def init_net(download=False):
-        """weights in Keras-1 'tf' layout: the model file when present (stone/nn_manager.py:65-73 loads it
-        with keras.models.load_model; here stone/keras1.py + h5lite read it), else create_net():
-        seeded He-normal"""
+    def init_net(download=False, allow_random=False):
+        """the twelve weight arrays (Keras-1 'tf' layout) from KERAS_MODEL_FILE.  A missing file is an error -- a
+        classifier with random weights reads garbage -- unless seeded random weights are asked for explicitly
+        (numerics tests use them)."""
         if os.path.isfile(KERAS_MODEL_FILE):
             return NNManager.load_model(KERAS_MODEL_FILE)
-        return NNManager.create_net()
+        if allow_random:
+            return NNManager.create_net()
+        raise ModelMissing("stone classifier model not found: %s (set CAMKIFU_KERAS_MODEL)" % KERAS_MODEL_FILE)
 
     @staticmethod
     def load_model(path):
@@ -59,68 +76,49 @@ class NNManager:
 
     @staticmethod
     def create_net():
+        """the architecture of nn_manager.py:277-298 with seeded He-normal weights (untrained)"""
         from .. import synth
         return synth.cnn_weights()
 
+    # ---- geometry --------------------------------------------------------------------------------
     def _subregion(self, i, j):
-        assert 0 <= i < self.split and 0 <= j < self.split
-        step = self.step
-        rs, re = i * step, (i + 1) * step
-        if gsize - rs < step:
-            rs, re = gsize - step, gsize
-        cs, ce = j * step, (j + 1) * step
-        if gsize - cs < step:
-            cs, ce = gsize - step, gsize
-        return rs, re, cs, ce
+        """(row start, row end, col start, col end) of region (i, j), ends exclusive"""
+        rs, cs = int(REGION_START[i]), int(REGION_START[j])
+        return rs, rs + STEP, cs, cs + STEP
 
     def get_region_indices(self, r, c):
-        return r // self.step, c // self.step
+        return r // STEP, c // STEP
 
     def getrect(self, r, c, re=0, ce=0):
-        x0 = int(r * self.canonical_shape[0] / gsize)
-        y0 = int(c * self.canonical_shape[1] / gsize)
-        re = (re + 1) if 0 < re else (r + 1)
-        ce = (ce + 1) if 0 < ce else (c + 1)
-        return x0, y0, int(re * self.canonical_shape[0] / gsize), int(ce * self.canonical_shape[1] / gsize)
+        """pixel box (x0, y0, x1, y1) of intersections r..re, c..ce (inclusive; 0 = just r / c) in the canonical image"""
+        last_r, last_c = (re if re > 0 else r), (ce if ce > 0 else c)
+        return r * CELL_PX, c * CELL_PX, (last_r + 1) * CELL_PX, (last_c + 1) * CELL_PX
 
     def _get_rect_nn(self, rs, re, cs, ce):
-        x0, y0, _, _ = self.getrect(rs, cs)
-        _, _, x1, y1 = self.getrect(re - 1, ce - 1)
-        if hasattr(self, 'c_width'):
-            if x1 - x0 != self.c_width:
-                x0 = x1 - self.c_width
-            if y1 - y0 != self.r_width:
-                y0 = y1 - self.r_width
-        return x0, x1, y0, y1
+        """(x0, x1, y0, y1) of the classifier's window for a block of intersections: always PATCH_SIDE wide,
+        anchored at the block's far edge"""
+        x1, y1 = re * CELL_PX, ce * CELL_PX
+        return x1 - PATCH_SIDE, x1, y1 - PATCH_SIDE, y1
 
     def _get_x(self, i, j, img):
-        x0, x1, y0, y1 = self._get_rect_nn(*self._subregion(i, j))
-        return img[x0:x1, y0:y1]
+        a, b = int(PATCH_ORIGIN[i]), int(PATCH_ORIGIN[j])
+        return img[a:a + PATCH_SIDE, b:b + PATCH_SIDE]
 
+    # ---- codec -----------------------------------------------------------------------------------
     @staticmethod
     def compute_label(rs, re, cs, ce, stones):
-        label = 0
-        for r in range(rs, re):
-            for c in range(cs, ce):
-                label += colors[stones[r, c]] * 3 ** ((r - rs) * (ce - cs) + (c - cs))
-        return label
+        block = np.asarray(stones)[rs:re, cs:ce].reshape(-1)
+        return int(sum(CODE[s] * 3 ** k for k, s in enumerate(block)))
 
     @staticmethod
-    def compute_stones(label, dimension=4):
-        k = label
-        stones = np.ndarray(dimension, dtype=object)
-        for i in reversed(range(dimension)):
-            digit = int(k / (3 ** i))
-            stones[i] = rcolors[digit]
-            k %= 3 ** i
-        return stones
+    def compute_stones(label, dimension=STEP * STEP):
+        if dimension == STEP * STEP:
+            return SYMBOLS[DIGITS[int(label)]]
+        return SYMBOLS[(int(label) // 3 ** np.arange(dimension)) % 3]
 
     def class_indices(self):
+        """[intersection k, colour, :] = the labels that put that colour on that intersection (27 each)"""
         if self.c_indices is None:
-            dimension = int(math.log(self.nb_classes, 3))
-            table = [NNManager.compute_stones(c, dimension) for c in range(self.nb_classes)]
-            self.c_indices = np.ndarray((dimension, 3, self.nb_classes // 3), dtype=np.uint8)
-            for d in range(dimension):
-                for stone, ci in colors.items():
-                    self.c_indices[d, ci] = [c for c in range(self.nb_classes) if table[c][d] == stone]
+            per_colour = [[np.flatnonzero(DIGITS[:, k] == col) for col in range(3)] for k in range(STEP * STEP)]
+            self.c_indices = np.array(per_colour, np.uint8)
         return self.c_indices

@@ -1,10 +1,17 @@
-"""StonesFinder base class (mirror of the hot-path part of the reference's
-stone/stonesfinder.py:95-176, 250-349, 412-450, 950-981).
+"""Standalone protocol base of a stones finder: the straightened goban image, the background model, the result
+sink and the grid geometry a finder builds on (contract: reference stone/stonesfinder.py:95-176, 250-349,
+412-450, 950-981).
 
-_doframe = K8 warpPerspective(frame, board_finder.mtx, (380, 380)) -> K9 MOG2 background model
--> _learn -> _find(goban_img); both image stages run on the GPU through the C-ABI.  Results go
-to the controller through suggest / remove / bulk_update in numpy (row, col) coordinates.
-Line-based emptiness checks and grid learning are "next" rows."""
+    frame --K8 ck_warp_perspective(board_finder.mtx)--> goban_img 380x380x3
+          --K9 ck_mog2_apply--> foreground mask --> _learn() (user corrections) --> _find(goban_img)
+
+Pieces, each usable on its own (the batch pipeline's fold uses the sink without a finder):
+    PosGrid        pixel position of the 361 intersections, and the zone (rectangle) around each as one table
+    DeletionWatch  intersections the user emptied: averaged appearance, refusal of new stones until it changes
+    StoneSink      (colour, row, col) decisions -> controller instructions "append" / "delete" / "bulk" / "auto_save"
+    StonesFinder   the per-frame protocol: _doframe, ready_to_read, _find (abstract), suggest / remove / bulk_update,
+                   getrect, get_foreground, corrected, is_empty, get_stones
+Coordinates handed to suggest / remove / bulk_update are numpy (row, col)."""
 import queue
 
 import numpy as np
@@ -15,190 +22,262 @@ from ..core.video import VidProcessor
 from ..golib_shim import gsize, E, B, W, Move, NP_TYPE
 
 correc_size = 10
+_CODE = {E: 0, B: 1, W: 2}
+
+
+class PosGrid:
+    """`mtx[i, j]` = (x, y) pixel of intersection (i, j) in the canonical image: cell centres, 10 + 20 k at the
+    default size.  `zones(cursor)` is the (19, 19, 4) table of rectangles (x0, y0, x1, y1) the reference computes one
+    at a time in StonesFinder.getrect: bounded halfway (cursor 1.0) towards the diagonal neighbours, mirrored at the
+    first line, stopping one pixel short of the image at the last."""
+
+    def __init__(self, size):
+        self.size = size
+        half = size / gsize / 2
+        line = (half * (gsize - 1 - np.arange(gsize)) + (size - half) * np.arange(gsize)) / (gsize - 1)
+        self.mtx = np.stack(np.meshgrid(line, line, indexing="ij"), -1).astype(np.int16)
+        self.adjust_vect, self.adjust_contribs = np.zeros(2, np.float32), 0
+        self._zones = {}
+
+    def zones(self, cursor=1.0):
+        key = (float(cursor), self.mtx.tobytes())
+        hit = self._zones.get(key)
+        if hit is None:
+            p = self.mtx.astype(np.int16)
+            before = np.roll(p, (1, 1), (0, 1)).copy()                       # mtx[r - 1, c - 1] (index -1 wraps, as in Python)
+            after = p[np.minimum(np.arange(gsize) + 1, gsize - 1)][:, np.minimum(np.arange(gsize) + 1, gsize - 1)].copy()
+            before[0, :, 0] = -p[0, :, 0]
+            before[:, 0, 1] = -p[:, 0, 1]
+            after[-1, :, 0] = 2 * self.size - p[-1, :, 0] - 2
+            after[:, -1, 1] = 2 * self.size - p[:, -1, 1] - 2
+            w = cursor / 2
+            lo = np.maximum(0, (w * before + (1 - w) * p).astype(np.int64))  # astype truncates toward zero like int()
+            hi = np.minimum(self.size, ((1 - w) * p + w * after).astype(np.int64))
+            hit = np.concatenate([lo, hi], -1)
+            self._zones = {key: hit}
+        return hit
+
+
+class DeletionWatch:
+    """The user took a stone off (or moved it): that intersection is watched.  Over the next `samples` frames in which
+    its zone is not entirely foreground the zone's pixels are averaged; from then on a stone is only accepted there
+    once the zone differs from that average by 40 grey levels per pixel (all channels summed).
+    reference: stonesfinder.py:178-245."""
+
+    def __init__(self, shape, samples=50):
+        self.samples = samples
+        self.left = np.full((gsize, gsize), -1, np.int32)        # frames still to sample; -1 = not watched
+        self.saved_bg = np.zeros(tuple(shape) + (3,), np.float32)
+
+    def start(self, r, c):
+        self.left[r, c] = self.samples
+
+    def watched(self):
+        return {(int(r), int(c)): int(self.left[r, c]) for r, c in np.argwhere(self.left >= 0)}
+
+    def sample(self, goban_img, fg, zones):
+        for r, c in np.argwhere(self.left > 0):
+            x0, y0, x1, y1 = zones[r, c]
+            # reference quirk kept: `np.sum(fg[zone] < 0.1 * area)` counts the pixels BELOW the bound, so the zone is
+            # sampled as soon as one of its pixels is background
+            if fg is None or (fg[x0:x1, y0:y1] < 0.1 * (x1 - x0) * (y1 - y0)).any():
+                self.saved_bg[x0:x1, y0:y1] += goban_img[x0:x1, y0:y1] / self.samples
+                self.left[r, c] -= 1
+
+    def check(self, r, c, goban_img, zones):
+        """raises DeletedError while (r, c) is locked; forgets the watch once the zone has changed enough"""
+        state = self.left[r, c]
+        if state < 0:
+            return
+        if state > 0:
+            raise DeletedError(((r, c),), "The zone has been marked as deleted too recently.")
+        x0, y0, x1, y1 = zones[r, c]
+        delta = self.saved_bg[x0:x1, y0:y1] - goban_img[x0:x1, y0:y1]
+        if np.sum(np.absolute(delta)) / (delta.shape[0] * delta.shape[1]) < 40:
+            raise DeletedError(((r, c),), "The zone has not changed enough since last deletion.")
+        print("previously user-deleted location: {} now unlocked".format((r, c)))
+        self.left[r, c] = -1
+
+
+class StoneSink:
+    """What a finder decides -> what the controller is told.  `guard(r, c)` may raise DeletedError to veto a stone."""
+
+    def __init__(self, controller_of, guard=None):
+        self._controller_of, self._guard = controller_of, guard
+
+    @property
+    def controller(self):
+        return self._controller_of()
+
+    def is_empty(self, r, c):
+        return self.controller.is_empty_blocking(c, r)
+
+    def get_stones(self):
+        return self.controller.get_stones()
+
+    def board_codes(self):
+        """the goban as uint8 (19, 19): 0 empty, 1 black, 2 white"""
+        stones = self.get_stones()
+        return (stones == B).astype(np.uint8) + 2 * (stones == W).astype(np.uint8)
+
+    def _vet(self, r, c):
+        if self._guard is not None:
+            self._guard(r, c)
+
+    def suggest(self, color, r, c, doprint=True):
+        self._vet(r, c)
+        stone = Move(NP_TYPE, (color, r, c))
+        if doprint:
+            print(stone)
+        ctl = self.controller
+        ctl.pipe("append", stone)
+        ctl.pipe("auto_save")
+
+    def remove(self, r, c):
+        if self.is_empty(r, c):
+            raise AssertionError("Can't remove stone from empty intersection.")
+        gone = Move(NP_TYPE, ("", r, c))
+        self.controller.pipe("delete", gone.x, gone.y)
+
+    def bulk_update(self, tuples):
+        """several changes as ONE controller instruction: E empties, B / W places (recolouring = empty, then place;
+        an identical stone already there is skipped).  Vetoed places are left out and reported together afterwards."""
+        ctl, batch, refused = self.controller, [], []
+        for color, r, c in tuples:
+            occupied = not self.is_empty(r, c)
+            if color == E:
+                if occupied:
+                    batch.append(Move(NP_TYPE, (E, r, c)))
+                continue
+            if color not in (B, W):
+                continue
+            if occupied and ctl.locate(c, r).color == color:
+                continue
+            try:
+                self._vet(r, c)
+            except DeletedError as veto:
+                if occupied:
+                    batch.append(Move(NP_TYPE, (E, r, c)))           # the clearing half still goes out
+                refused.append(veto)
+                continue
+            if occupied:
+                batch.append(Move(NP_TYPE, (E, r, c)))
+            batch.append(Move(NP_TYPE, (color, r, c)))
+        if batch:
+            ctl.pipe("bulk", batch)
+            ctl.pipe("auto_save")
+        if refused:
+            raise DeletedError(refused, message="Bulk_update:warning: All non-conflicting locations have been sent.")
 
 
 class StonesFinder(VidProcessor):
-    def __init__(self, vmanager, learn_bg=True, ctx=None):
-        super().__init__(vmanager)
-        self.ctx = ctx if ctx is not None else capi.Context(getattr(vmanager, "device", 0))
-        self.goban_img = None
-        self.canonical_shape = (cvconf.canonical_size, cvconf.canonical_size)
-        self._posgrid = PosGrid(cvconf.canonical_size)
-        self.intersections = None
-        self._fg = None
-        if learn_bg:
-            self.bg_model = self.ctx.mog2_create(*self.canonical_shape)
-            video = getattr(self.vmanager, "current_video", None)
-            is_img = isinstance(video, str) and video.lower().endswith((".png", ".jpg"))
-            self.bg_init_frames = 0 if is_img else 50
-        # (quite primal) "learning" attributes, see _learn()
+    def __init__(self, manager, learn_bg=True, ctx=None):
+        VidProcessor.__init__(self, manager)
+        self.ctx = ctx if ctx is not None else capi.Context(getattr(manager, "device", 0))
+        side = cvconf.canonical_size
+        self.canonical_shape, self.goban_img, self.intersections, self._fg = (side, side), None, None, None
+        self._posgrid = PosGrid(side)
+        self.watch = DeletionWatch(self.canonical_shape)
         self.corrections = queue.Queue(correc_size)
-        self.saved_bg = np.zeros(self.canonical_shape + (3,), dtype=np.float32)
-        self.deleted = {}
-        self.nb_del_samples = 50
+        self.sink = StoneSink(lambda: self.vmanager.controller, self._check_dels)
+        if learn_bg:
+            self.bg_model = self.ctx.mog2_create(side, side)
+            video = getattr(manager, "current_video", None)
+            still = isinstance(video, str) and video.lower().endswith((".png", ".jpg"))
+            self.bg_init_frames = 0 if still else 50
+
+    # ---- per frame -------------------------------------------------------------------------------
+    def ready_to_read(self):
+        bf = getattr(self.vmanager, "board_finder", None)
+        return VidProcessor.ready_to_read(self) and getattr(bf, "mtx", None) is not None
 
     def _doframe(self, frame):
         self.intersections = None
-        transform = None
-        if self.vmanager.board_finder is not None:
-            transform = self.vmanager.board_finder.mtx
-        if transform is not None:
-            self.goban_img = self.ctx.warp_perspective(frame, transform, cvconf.canonical_size)   # K8
-            self._learn_bg()
-            self._learn()
-            self._find(self.goban_img)
-
-    def ready_to_read(self):
-        try:
-            return super().ready_to_read() and self.vmanager.board_finder.mtx is not None
-        except AttributeError:
-            return False
+        bf = self.vmanager.board_finder
+        mtx = None if bf is None else bf.mtx
+        if mtx is None:
+            return
+        self.goban_img = self.ctx.warp_perspective(frame, mtx, cvconf.canonical_size)           # K8
+        self._learn_bg()
+        self._learn()
+        self._find(self.goban_img)
 
     def _find(self, goban_img):
-        raise NotImplementedError("Abstract method meant to be extended")
+        raise NotImplementedError("a stones finder implements _find(goban_img)")
 
     def _learn_bg(self):
         if hasattr(self, "bg_model"):
-            learning = 0.01 if self.total_f_processed < self.bg_init_frames else 0.005
-            self._fg = self.ctx.mog2_apply(self.bg_model, self.goban_img, learning)          # K9
-
-    def _learn(self):
-        """User corrections (stonesfinder.py:178-222).  A deletion (or a moved stone) puts the emptied
-        intersection under watch: its pixels are averaged over nb_del_samples calm frames into
-        saved_bg, and _check_dels refuses new suggestions there until the zone looks different."""
-        unprocessed = []
-        try:
-            while True:
-                err, exp = self.corrections.get_nowait()
-                if exp is None:
-                    self.deleted[(err.y, err.x)] = self.nb_del_samples      # Move.x / Move.y are image coordinates
-                elif err is not None and (err.x, err.y) != (exp.x, exp.y):
-                    self.deleted[(err.y, err.x)] = self.nb_del_samples      # a stone has been moved
-                else:
-                    unprocessed.append((err, exp))                          # a missed stone: left to subclasses
-        except queue.Empty:
-            pass
-        for (r, c), nb_left in self.deleted.items():
-            if nb_left:
-                fg = self.get_foreground()
-                x0, y0, x1, y1 = self.getrect(r, c)
-                # reference quirk kept: the comparison sits INSIDE the sum (count of pixels below the
-                # bound), so the zone is sampled unless every pixel of it is foreground
-                if fg is None or np.sum(fg[x0:x1, y0:y1] < 0.1 * (x1 - x0) * (y1 - y0)):
-                    self.saved_bg[x0:x1, y0:y1] += self.goban_img[x0:x1, y0:y1] / self.nb_del_samples
-                    self.deleted[(r, c)] = nb_left - 1
-        if 0 < len(unprocessed):
-            raise CorrectionWarning(unprocessed, message="Unhandled corrections")
+            rate = 0.01 if self.total_f_processed < self.bg_init_frames else 0.005
+            self._fg = self.ctx.mog2_apply(self.bg_model, self.goban_img, rate)                  # K9
 
     def get_foreground(self):
         return self._fg
 
-    def _check_dels(self, r, c):
-        """stonesfinder.py:223-245: has this intersection been deleted by the user recently?"""
-        try:
-            nb_samples_left = self.deleted[(r, c)]
-        except KeyError:
-            return
-        if 0 == nb_samples_left:                       # only check when sampling has completed
-            x0, y0, x1, y1 = self.getrect(r, c)
-            diff = self.saved_bg[x0:x1, y0:y1] - self.goban_img[x0:x1, y0:y1]
-            if np.sum(np.absolute(diff)) / (diff.shape[0] * diff.shape[1]) < 40:
-                raise DeletedError(((r, c),), "The zone has not changed enough since last deletion.")
-            print("previously user-deleted location: {} now unlocked".format((r, c)))
-            del self.deleted[(r, c)]
-        else:
-            raise DeletedError(((r, c),), "The zone has been marked as deleted too recently.")
-
-    # ---- result sink ---------------------------------------------------------------------------
-    def suggest(self, color, r, c, doprint=True):
-        self._check_dels(r, c)
-        move = Move(NP_TYPE, (color, r, c))
-        if doprint:
-            print(move)
-        self.vmanager.controller.pipe("append", move)
-        self.vmanager.controller.pipe("auto_save")
-
-    def remove(self, r, c):
-        assert not self.is_empty(r, c), "Can't remove stone from empty intersection."
-        move = Move(NP_TYPE, ("", r, c))
-        self.vmanager.controller.pipe("delete", move.x, move.y)
-
-    def bulk_update(self, tuples):
-        moves, del_errors = [], []
-        for color, r, c in tuples:
-            if color == E:
-                if not self.is_empty(r, c):
-                    moves.append(Move(NP_TYPE, (color, r, c)))
-            elif color in (B, W):
-                if not self.is_empty(r, c):
-                    existing = self.vmanager.controller.locate(c, r)
-                    if color != existing.color:
-                        moves.append(Move(NP_TYPE, (E, r, c)))      # clear first, then recolour
-                    else:
-                        continue
-                try:
-                    self._check_dels(r, c)
-                    moves.append(Move(NP_TYPE, (color, r, c)))
-                except DeletedError as de:
-                    del_errors.append(de)
-        if moves:
-            self.vmanager.controller.pipe("bulk", moves)
-            self.vmanager.controller.pipe("auto_save")
-        if del_errors:
-            raise DeletedError(del_errors, message="Bulk_update:warning: All non-conflicting locations have been sent.")
-
+    # ---- user corrections ------------------------------------------------------------------------
     def corrected(self, err_move, exp_move):
         try:
             self.corrections.put_nowait((err_move, exp_move))
         except queue.Full:
             print("Corrections queue full (%s), ignoring %s -> %s" % (correc_size, err_move, exp_move))
 
+    def _learn(self):
+        """drain the corrections: a deletion (or the origin of a moved stone) goes under watch; anything else cannot be
+        learnt from here and is reported (CorrectionWarning) after this frame's sampling"""
+        leftover = []
+        while True:
+            try:
+                wrong, right = self.corrections.get_nowait()
+            except queue.Empty:
+                break
+            moved = wrong is not None and right is not None and (wrong.x, wrong.y) != (right.x, right.y)
+            if right is None or moved:
+                self.watch.start(wrong.y, wrong.x)                 # Move.x is the column, Move.y the row
+            else:
+                leftover.append((wrong, right))
+        self.watch.sample(self.goban_img, self.get_foreground(), self._posgrid.zones())
+        if leftover:
+            raise CorrectionWarning(leftover, message="Unhandled corrections")
+
+    def _check_dels(self, r, c):
+        self.watch.check(r, c, self.goban_img, self._posgrid.zones())
+
+    @property
+    def deleted(self):
+        return self.watch.watched()
+
+    @property
+    def saved_bg(self):
+        return self.watch.saved_bg
+
+    @property
+    def nb_del_samples(self):
+        return self.watch.samples
+
+    @nb_del_samples.setter
+    def nb_del_samples(self, n):
+        self.watch.samples = n
+
+    # ---- results ---------------------------------------------------------------------------------
+    def suggest(self, color, r, c, doprint=True):
+        self.sink.suggest(color, r, c, doprint)
+
+    def remove(self, r, c):
+        self.sink.remove(r, c)
+
+    def bulk_update(self, tuples):
+        self.sink.bulk_update(tuples)
+
     def is_empty(self, r, c):
-        return self.vmanager.controller.is_empty_blocking(c, r)
+        return self.sink.is_empty(r, c)
 
     def get_stones(self):
-        return self.vmanager.controller.get_stones()
+        return self.sink.get_stones()
 
-    # ---- grid geometry ---------------------------------------------------------------------------
+    # ---- geometry --------------------------------------------------------------------------------
     def getrect(self, r, c, cursor=1.0):
-        """pixel rectangle (x0, y0, x1, y1) around intersection (r, c); the last row/column
-        ends at 379 (reference: stonesfinder.py:412-450)"""
-        assert isinstance(cursor, float)
-        g = self._posgrid
-        p = g.mtx[r][c]
-        before = g.mtx[r - 1][c - 1].copy()
-        after = g.mtx[min(r + 1, gsize - 1)][min(c + 1, gsize - 1)].copy()
-        if r == 0:
-            before[0] = -p[0]
-        elif r == gsize - 1:
-            after[0] = 2 * g.size - p[0] - 2
-        if c == 0:
-            before[1] = -p[1]
-        elif c == gsize - 1:
-            after[1] = 2 * g.size - p[1] - 2
-        w = cursor / 2
-        x0 = max(0, int(w * before[0] + (1 - w) * p[0]))
-        y0 = max(0, int(w * before[1] + (1 - w) * p[1]))
-        x1 = min(g.size, int((1 - w) * p[0] + w * after[0]))
-        y1 = min(g.size, int((1 - w) * p[1] + w * after[1]))
-        return x0, y0, x1, y1
+        if not isinstance(cursor, float):
+            raise TypeError("cursor must be a float in ]0, 2[")
+        return tuple(int(v) for v in self._posgrid.zones(cursor)[r, c])
 
     def _window_name(self):
         return "camkifu.stone.stonesfinder.StonesFinder"
-
-
-class PosGrid:
-    """pixel position of each goban intersection in the canonical image: (10 + 20 i, 10 + 20 j)"""
-
-    def __init__(self, size):
-        self.size = size
-        self.mtx = np.zeros((gsize, gsize, 2), dtype=np.int16)
-        start = size / gsize / 2
-        end = size - start
-        for i in range(gsize):
-            xi = (start * (gsize - 1 - i) + end * i) / (gsize - 1)
-            for j in range(gsize):
-                self.mtx[i][j][0] = xi
-                self.mtx[i][j][1] = (start * (gsize - 1 - j) + end * j) / (gsize - 1)
-        self.adjust_vect = np.zeros(2, dtype=np.float32)
-        self.adjust_contribs = 0

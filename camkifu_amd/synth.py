@@ -80,8 +80,9 @@ def homography(src, dst):
     return np.append(x, 1.0).reshape(3, 3)
 
 
-def render(h, w, stones, corners, seed=SEED, noise=3.0, device="cpu"):
-    """-> uint8 tensor (h, w, 3) BGR on `device`."""
+def render(h, w, stones, corners, seed=SEED, noise=3.0, device="cpu", hand=None):
+    """-> uint8 tensor (h, w, 3) BGR on `device`.  hand = (row, col): a player's hand and forearm reaching from the
+    bottom edge of the board over that intersection (skin-coloured, about three cells wide)."""
     dev = torch.device(device)
     g = torch.Generator(device=dev)
     g.manual_seed(int(seed))
@@ -117,6 +118,12 @@ def render(h, w, stones, corners, seed=SEED, noise=3.0, device="cpu"):
     col = st[iv, iu]              # stones[row=v][col=u]
     img[disc & (col == B)] = 25.0
     img[disc & (col == W)] = 230.0
+    if hand is not None:
+        hr, hc = float(hand[0]), float(hand[1])
+        palm = (u - hc) ** 2 + (v - hr) ** 2 < 1.7 ** 2
+        arm = ((u - hc).abs() < 1.2) & (v > hr) & (v < GSIZE + 3.0)
+        skin = torch.tensor([135.0, 160.0, 205.0], device=dev)
+        img[palm | arm] = skin * (1.0 + 0.04 * torch.sin(3.0 * (u + v)))[palm | arm][:, None]
     if noise > 0:
         img += torch.randn((h, w, 3), generator=g, device=dev) * noise
     return img.clamp_(0, 255).round_().to(torch.uint8)
@@ -153,10 +160,46 @@ def video(nframes, h, w, seed=SEED, device="cpu", new_stone_every=5, noise=3.0):
     return torch.stack(frames), corners, grids, moves
 
 
+def film(nframes, h, w, seed=SEED, device="cpu", density=0.25, quiet=52, move_every=40, hand_frames=12, noise=3.0):
+    """A fixed camera over a game in progress, with the players' hands: the position at the start holds random
+    stones; after `quiet` frames a move is played every `move_every` frames -- a hand covers the point for
+    `hand_frames` frames, and when it leaves the new stone is there.  That is what SfNeural's steady state needs to
+    see a move (foreground agitation, then calm: sf_neural.py:72-154).
+    -> frames uint8 (n,h,w,3) tensor on `device`, corners, truth (n,19,19) uint8 = stones actually on the board in each
+    frame, moves [(color, r, c, frame at which the stone is first visible)]"""
+    rng = np.random.default_rng(seed)
+    corners = random_corners(h, w, rng)
+    stones = random_stones(rng, density)
+    frames = torch.empty((nframes, h, w, 3), dtype=torch.uint8, device=device)
+    truth = np.zeros((nframes, GSIZE, GSIZE), np.uint8)
+    moves, color, pending = [], B, None
+    for f in range(nframes):
+        k = f - quiet
+        hand = None
+        if k >= 0:
+            phase = k % move_every
+            if phase == 0:
+                while True:
+                    r, c = (int(v) for v in rng.integers(2, GSIZE - 2, 2))
+                    if stones[r, c] == E:
+                        break
+                pending = (color, r, c)
+                color = W if color == B else B
+            if pending is not None and phase < hand_frames:
+                hand = pending[1:]
+            elif pending is not None:
+                stones[pending[1], pending[2]] = pending[0]
+                moves.append(pending + (f,))
+                pending = None
+        frames[f] = render(h, w, stones, corners, seed=seed * 31 + f, noise=noise, device=device, hand=hand)
+        truth[f] = stones
+    return frames, corners, truth, moves
+
+
 def cnn_weights(seed=SEED, as_torch=False, device="cpu"):
     """He-normal synthetic weights in Keras-1 'tf' layout; conv1 is scaled by 1/128 because the
     reference feeds raw 0..255 pixels (nn_cache.py:47-51) and random weights have no reason to
-    compensate for it.  Replaced by the trained model when tests/golden/keras.h5 exists (NNManager.init_net)."""
+    compensate for it.  Replaced by the trained model when camkifu_amd/data/keras.h5 exists (NNManager.init_net)."""
     from .capi import WEIGHT_SHAPES, WEIGHT_ORDER
     rng = np.random.default_rng(seed)
     Wt = {}

@@ -144,6 +144,80 @@ int ck_stones_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int i
                      const double* M, int m_count, uint8_t* labels, double* conf,
                      int out_space);
 
+/* ---- the classifier's answers per REGION: what NNCache.predict_4_stones / predict_stone read (stone/nn_cache.py:16-31).
+ * region_label: n*100 argmax labels (0..80, region (i, j) at i*10+j); region_conf: n*100 doubles max(y)/sum(y). */
+int ck_cnn_regions(ck_ctx* ctx, const uint8_t* goban, int n, int in_space,
+                   uint8_t* region_label, double* region_conf, int out_space);
+
+/* ---- an ORDERED RUN of the stones path over n consecutive frames of one stream, one call:
+ *      K8 warp -> K9 MOG2 in frame order -> K10..K12            stone/stonesfinder.py:123-176 + sf_neural.py:37-55
+ * mog2_handle < 0: no background model (fgcount untouched).  learning_rates: host, n doubles (0.01 during the
+ * first bg_init_frames frames, 0.005 afterwards: stonesfinder.py:171-176).  fgcount: n*361 int32, the number of
+ * foreground pixels of the frame's MOG2 mask inside StonesFinder.getrect(r, c) -- what SfNeural.is_agitated sums
+ * (sf_neural.py:178-180).  labels / conf (n*361, as ck_stones_detect) may be NULL.  Feeds ck_policy_run. */
+int ck_stones_run(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
+                  const double* M, int m_count, int mog2_handle, const double* learning_rates,
+                  uint8_t* region_label, double* region_conf, int32_t* fgcount,
+                  uint8_t* labels, double* conf, int out_space);
+
+/* ---- K9 sharded by PIXEL for multi-GPU batches: the model `handle` (ck_mog2_create(band_h, 380)) holds a horizontal band
+ * of the goban image (a whole number of 20-pixel intersection rows; the last band is the one that ends at pixel row
+ * 379).  band: n x band_h x 380 x 3, the band of n consecutive goban images in frame order; counts: n x (band_h/20
+ * rounded up) x 19 int32 foreground pixels per intersection zone, the same numbers ck_stones_run gives for those rows. */
+int ck_mog2_band_run(ck_ctx* ctx, int handle, const uint8_t* band, int n, int in_space,
+                     const double* learning_rates, int last_band, int32_t* counts, int out_space);
+
+/* ---- the 361 box sums of SfNeural.mark_targets / select_targets as one reduction   stone/sf_neural.py:72-83, 129-154
+ * mask: n x 380 x 380 (non-zero = foreground); counts: n*361 int32 (pixels per getrect zone). */
+int ck_zone_counts(ck_ctx* ctx, const uint8_t* mask, int n, int in_space, int32_t* counts, int out_space);
+
+/* ======================================================================================================
+ * Ordered (stateful) halves of the two finders -- host only, no GPU needed.  The per-frame finders call
+ * them once per frame, the batch pipeline's fold calls them over the gathered per-frame records; the
+ * arithmetic is the reference's Python float arithmetic restated operation for operation.
+ * ====================================================================================================== */
+
+/* ---- BoardFinderAuto._detect after the image chain: 4-frame line accumulation, group_intersections,
+ *      connect_clusters, updt_corners                     board/bf_auto.py:76-102, 143-217; core/imgutil.py:38-68, 216-288, 464-530
+ * status/lines/n_lines: this frame's result of ck_board_detect; frame_counter: VidProcessor.total_f_processed;
+ * cur_hull: the 4 corners known so far (8 ints, x y) or NULL (GobanCorners.hull is None).
+ * Out: *found (the return value of _detect), *update (corners must be replaced by `centers`),
+ * centers (up to 4 x y pairs, hull-ordered), *n_centers, stats[2] = {clusters, intersections} or -1 when the
+ * frame did not reach the grouping step.  CK_ERR_STATE: the reference would raise here (3-vertex hull indexed as 4). */
+/* imgutil.get_ordered_hull (core/imgutil.py:236-288): convex hull of n integer points, clockwise on screen,
+ * starting at the vertex nearest the image origin; out holds up to n x y pairs */
+int  ck_ordered_hull(const int32_t* pts, int n, int32_t* out, int32_t* n_out);
+typedef struct ck_boardfold ck_boardfold;
+int  ck_boardfold_create(ck_boardfold** out);
+void ck_boardfold_destroy(ck_boardfold* bf);
+int  ck_boardfold_reset(ck_boardfold* bf);
+int  ck_boardfold_step(ck_boardfold* bf, int h, int w, int status, const float* lines, int n_lines,
+                       long long frame_counter, const int32_t* cur_hull, int32_t* found, int32_t* update,
+                       int32_t* centers, int32_t* n_centers, int32_t* stats);
+
+/* ---- SfNeural._find after the classifier: predict_all / mark_targets / select_targets / predict_moves /
+ *      get_color_ratio / lookback / HeatPoint                                  stone/sf_neural.py:37-244
+ * Runs frames [*frame_io, n) of an ordered run.  Per frame: region_label (100 argmax labels 0..80, region (i, j)
+ * at i*10+j), region_conf (100 x max(y)/sum(y)), fgcount (361 foreground-pixel counts of the MOG2 mask over
+ * StonesFinder.getrect(r, c); NULL = nothing moves), first_counter = total_f_processed of frame 0 of the run.
+ * board: the goban as the controller holds it NOW (361 bytes, 0 E / 1 B / 2 W).
+ * The call returns either with *frame_io == n (run finished, *kind == 0) or with a request the caller must apply
+ * before calling again with the updated board: *kind 1 = StonesFinder.suggest (one triple), 2 = bulk_update;
+ * moves = *n_moves triples (color, row, col); *frame_io / *phase_io say where to resume (pass them back unchanged;
+ * start a run with 0 / 0).  cap >= 722 triples. */
+typedef struct ck_policy ck_policy;
+int  ck_policy_create(int bg_init_frames, ck_policy** out);
+void ck_policy_destroy(ck_policy* p);
+int  ck_policy_run(ck_policy* p, int n, long long first_counter, const uint8_t* region_label,
+                   const double* region_conf, const int32_t* fgcount, const uint8_t* board,
+                   int32_t* frame_io, int32_t* phase_io, int32_t* kind, int32_t* moves, int cap, int32_t* n_moves);
+/* inspection / test hooks: any out pointer may be NULL.  targets 361 B, heat_color 361 B (0 = no watched prediction),
+ * heat_energy 361 int32, heat_conf 361 doubles, flags[2] = {has_sampled, recolour events seen} */
+int  ck_policy_get_state(const ck_policy* p, uint8_t* targets, uint8_t* heat_color, int32_t* heat_energy,
+                         double* heat_conf, int32_t* flags);
+int  ck_policy_set_state(ck_policy* p, const uint8_t* targets, int has_sampled /* <0: keep */);
+int  ck_policy_watch(ck_policy* p, int r, int c, int color /*0 drops it*/, double confidence, long long stamp);
+
 #ifdef __cplusplus
 }
 #endif

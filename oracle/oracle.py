@@ -285,6 +285,31 @@ def decode_all(y):
     return labels, conf
 
 
+def decode_regions(y):
+    """per region: label = argmax(y) (first maximum) and confidence = max(y) / sum(y), the sum running over the 81
+    values in index order in float64 (NNCache.predict_4_stones / predict_stone, nn_cache.py:16-31)"""
+    y = np.ascontiguousarray(y, np.float32).reshape(100, 81)
+    lab = np.argmax(y, axis=1).astype(np.uint8)
+    conf = np.zeros(100, np.float64)
+    for t in range(100):
+        tot = 0.0
+        for v in y[t]:
+            tot = tot + float(v)
+        conf[t] = float(y[t, lab[t]]) / tot
+    return lab, conf
+
+
+def zone_counts(mask):
+    """foreground pixels of a 380x380 mask per StonesFinder.getrect(r, c) zone -> int32 (19, 19):
+    np.sum(fg[x0:x1, y0:y1]) / 255 of SfNeural.is_agitated (sf_neural.py:178-180)"""
+    out = np.zeros((GSIZE, GSIZE), np.int32)
+    for r in range(GSIZE):
+        for c in range(GSIZE):
+            x0, y0, x1, y1 = sf_getrect(r, c)
+            out[r, c] = int(np.count_nonzero(mask[x0:x1, y0:y1]))
+    return out
+
+
 # ---- pure-python restatements of the codec / geometry helpers (pinned by the reference's
 # ---- own known-answer tests, tests/golden/reference_known_answers.json) ------------------
 

@@ -11,12 +11,14 @@ class OracleCtx:
         self.weights = None
         self._mog = {}
 
-    def board_detect(self, frames, hough_thresh=-1, cap=1024):
-        frames = np.asarray(frames)
-        if frames.ndim == 3:
-            frames = frames[None]
+    @staticmethod
+    def _batch(a, nd):
+        a = np.asarray(a)
+        return a[None] if a.ndim == nd else a
+
+    def board_detect(self, frames, hough_thresh=-1, cap=1024, raw=False):
         out = []
-        for fr in frames:
+        for fr in self._batch(frames, 3):
             o = ora.board_lines(ora.canny(ora.median(fr, 15), 25, 75),
                                 hough_thresh=None if hough_thresh < 0 else hough_thresh, cap=cap)
             st = {-1: 1, -2: 2}.get(o["status"], 0)
@@ -25,7 +27,10 @@ class OracleCtx:
         return out
 
     def warp_perspective(self, frame, M, dsize=380):
-        return ora.warp_perspective(np.asarray(frame), M, (dsize, dsize))
+        frame = np.asarray(frame)
+        if frame.ndim == 4:
+            return np.stack([ora.warp_perspective(f, M, (dsize, dsize)) for f in frame])
+        return ora.warp_perspective(frame, M, (dsize, dsize))
 
     def mog2_create(self, h=380, w=380):
         k = len(self._mog)
@@ -35,15 +40,31 @@ class OracleCtx:
     def mog2_apply(self, handle, img, lr):
         return self._mog[handle].apply(img, lr)
 
+    def mog2_band_run(self, handle, band, learning_rates, last_band):
+        band = np.asarray(band)
+        out = np.zeros((len(band), (band.shape[1] + 19) // 20, 19), np.int32)
+        for f, img in enumerate(band):
+            fg = self._mog[handle].apply(np.ascontiguousarray(img), float(learning_rates[f]))
+            padded = np.zeros((out.shape[1] * 20, 380), np.uint8)
+            padded[:fg.shape[0]] = fg
+            padded[:, 379] = 0
+            if last_band:
+                padded[fg.shape[0] - 1] = 0
+            out[f] = (padded != 0).reshape(out.shape[1], 20, 19, 20).sum((1, 3))
+        return out
+
+    def zone_counts(self, mask):
+        mask = np.asarray(mask)
+        if mask.ndim == 2:
+            return ora.zone_counts(mask)
+        return np.stack([ora.zone_counts(m) for m in mask])
+
     def cnn_set_weights(self, weights):
         self.weights = {k: np.asarray(v, np.float32) for k, v in weights.items()}
 
     def cnn_predict(self, goban, want_y=True):
-        g = np.asarray(goban)
-        if g.ndim == 3:
-            g = g[None]
         ys, ls, cs = [], [], []
-        for x in g:
+        for x in self._batch(goban, 3):
             y = ora.cnn_predict_regions(self.weights, x)
             lab, cf = ora.decode_all(y)
             ys.append(y)
@@ -51,9 +72,25 @@ class OracleCtx:
             cs.append(cf)
         return (np.stack(ys), np.stack(ls), np.stack(cs)) if want_y else (np.stack(ls), np.stack(cs))
 
+    def cnn_regions(self, goban):
+        labs, confs = [], []
+        for x in self._batch(goban, 3):
+            lab, cf = ora.decode_regions(ora.cnn_predict_regions(self.weights, x))
+            labs.append(lab.reshape(10, 10))
+            confs.append(cf.reshape(10, 10))
+        return np.stack(labs), np.stack(confs)
+
     def stones_detect(self, frames, M):
-        frames = np.asarray(frames)
-        if frames.ndim == 3:
-            frames = frames[None]
-        gob = np.stack([self.warp_perspective(f, M) for f in frames])
+        gob = np.stack([self.warp_perspective(f, M) for f in self._batch(frames, 3)])
         return self.cnn_predict(gob, want_y=False)
+
+    def stones_run(self, frames, M, mog2=None, learning_rates=None, want_grid=False):
+        gob = np.stack([self.warp_perspective(f, M) for f in self._batch(frames, 3)])
+        rl, rc = self.cnn_regions(gob)
+        fg = None
+        if mog2 is not None:
+            fg = np.stack([ora.zone_counts(self._mog[mog2].apply(g, float(lr))) for g, lr in zip(gob, learning_rates)])
+        out = dict(region_label=rl, region_conf=rc, fgcount=fg, labels=None, conf=None)
+        if want_grid:
+            out["labels"], out["conf"] = self.cnn_predict(gob, want_y=False)
+        return out

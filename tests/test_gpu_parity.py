@@ -362,27 +362,36 @@ def _real(device=0):
 
 
 def test_fast_file_pipeline_on_gpu(ck, synth):
-    """batch path: records from the HIP core folded in order == records from the oracle folded"""
+    """batch path on a filmed game (hands, new stones): board records, region answers and foreground counts from
+    the HIP core, folded in order == the same from the oracle, folded -- and the game record is the game"""
     from camkifu_amd import pipeline
     from camkifu_amd.controller import ControllerHeadless
+    from camkifu_amd.stone.nn_manager import NNManager
     from .stub_ctx import OracleCtx
-    rng = np.random.default_rng(8)
-    corners = synth.random_corners(480, 640, rng)
-    stones = synth.random_stones(rng, density=0.3)
-    frames = np.stack([synth.render(480, 640, stones, corners, seed=300 + f).numpy() for f in range(12)])
-    W = synth.cnn_weights()
+    frames, corners, truth, moves = synth.film(100, 480, 640, seed=8, quiet=8, move_every=30, hand_frames=12)
+    frames = frames.numpy()
+    W = NNManager.init_net()
     ck.cnn_set_weights(W)
     octx = OracleCtx()
     octx.cnn_set_weights(W)
     outs = []
     for ctx in (ck, octx):
         ctrl = ControllerHeadless()
-        pipe = pipeline.FastFilePipeline(480, 640, ctrl, ctx=ctx)
-        e1 = pipe.process_batch(frames, len(frames))       # finds the board
-        e2 = pipe.process_batch(frames, len(frames))       # reads the stones with that transform
-        outs.append((pipe.board.mtx, ctrl.kifu.to_sgf(), [[repr(m) for m in mv] for mv in e1 + e2]))
+        pipe = pipeline.FastFilePipeline(480, 640, ctrl, ctx=ctx, bg_init_frames=6)
+        found = pipe.process_batch(frames[:8], 8)            # finds the board (nothing to say about stones yet)
+        emitted = []
+        for b0 in range(0, 100, 23):                         # ragged batches over the whole film
+            emitted += pipe.process_batch(frames[b0:b0 + 23], len(frames[b0:b0 + 23]))
+        outs.append((pipe.board.mtx, ctrl.kifu.to_sgf(), emitted, pipe.stones.policy.state()["targets"]))
+        assert all(not req for req in found)
     assert outs[0][0] is not None and np.array_equal(outs[0][0], outs[1][0])
-    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2] and np.array_equal(outs[0][3], outs[1][3])
+    # the record: the position of the first assessed frame in raster order, then the moves that were played
+    sym = "EBW"
+    first = [(sym[truth[6][r, c]], r, c) for r in range(19) for c in range(19) if truth[6][r, c]]
+    played = [(sym[col], r, c) for col, r, c, f in moves if f + 12 < 100]
+    flat = [m for per_frame in outs[0][2] for kind, ms in per_frame for m in ms]
+    assert flat[:len(first)] == first and flat[len(first):len(first) + len(played)] == played and len(played) >= 2
 
 
 def test_cnn_bf16_mode_close_to_fp32(ck, ora, synth):
@@ -492,11 +501,11 @@ def test_y4m_file_through_the_pipeline(ck, ora, synth, tmp_path):
     idx = cap.file_frame_indices(len(c), c.fps)
     assert idx == list(range(6, 100, 7))
     ctrl = ControllerHeadless()
-    pipe = pipeline.FastFilePipeline(480, 640, ctrl, ctx=ck)
+    pipe = pipeline.FastFilePipeline(480, 640, ctrl, ctx=ck, bg_init_frames=2)
     pipe.process_y4m(c, batch=7)
     # same frames, decoded on the CPU, fed as BGR
     ctrl2 = ControllerHeadless()
-    pipe2 = pipeline.FastFilePipeline(480, 640, ctrl2, ctx=ck)
+    pipe2 = pipeline.FastFilePipeline(480, 640, ctrl2, ctx=ck, bg_init_frames=2)
     dec = np.stack([ora.i420_to_bgr(np.asarray(c.read_raw_batch([i])[0]), 480, 640) for i in idx])
     for b0 in range(0, len(idx), 7):
         pipe2.process_batch(dec[b0:b0 + 7], len(dec[b0:b0 + 7]))

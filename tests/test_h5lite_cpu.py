@@ -54,7 +54,7 @@ def test_rejects_what_it_does_not_read(tmp_path):
 
 
 def test_keras1_model_file_loads_like_the_reference_expects():
-    """tests/golden/keras.h5 has the layout Keras 1.2 model.save() writes (root attrs, model_weights group,
+    """camkifu_amd/data/keras.h5 has the layout Keras 1.2 model.save() writes (root attrs, model_weights group,
     layer_names / weight_names, 'tf' kernels); NNManager.init_net loads it as the reference loads keras.h5"""
     layers = keras1.read_layer_weights(KERAS_MODEL_FILE)
     assert [n for n, _ in layers] == ["convolution2d_1", "convolution2d_2", "convolution2d_3", "convolution2d_4",

@@ -8,6 +8,7 @@ import numpy as np
 
 from camkifu_amd.core import imgutil
 from camkifu_amd.stone.nn_manager import NNManager
+from oracle import ora_logic as ol
 from camkifu_amd.stone.stonesfinder import PosGrid, StonesFinder
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -20,45 +21,65 @@ def _t(lst):
 
 def test_cyclic_permute_doctests():
     for case in GOLD["cyclic_permute"]:
-        assert imgutil.cyclic_permute(_t(case["in"])) == _t(case["out"])
+        assert ol.cyclic_permute(_t(case["in"])) == _t(case["out"])
 
 
 def test_get_ordered_hull_doctests():
+    """the reference's doctests, through the product (C++ ck_ordered_hull) and through the oracle"""
     for case in GOLD["get_ordered_hull"]:
         assert imgutil.get_ordered_hull(_t(case["in"])) == _t(case["out"])
+        assert ol.ordered_hull(_t(case["in"])) == _t(case["out"])
     # a point inside the quadrilateral, duplicates and collinear points do not survive
     pts = [(5, 367), (126, 96), (514, 92), (638, 364), (300, 200), (126, 96), (320, 94)]
-    assert len(imgutil.get_ordered_hull(pts)) == 4
+    assert len(imgutil.get_ordered_hull(pts)) == 4 and imgutil.get_ordered_hull(pts) == ol.ordered_hull(pts)
     assert len(imgutil.get_ordered_hull([(0, 0), (5, 5), (10, 10), (3, 3)])) == 2
+    rng = np.random.default_rng(4)
+    for _ in range(200):
+        pts = [tuple(int(v) for v in p) for p in rng.integers(0, 40, (int(rng.integers(1, 12)), 2))]
+        assert imgutil.get_ordered_hull(pts) == ol.ordered_hull(pts), pts
 
 
 def test_norm_doctest():
     g = GOLD["norm"]
     assert "{:.6f}".format(imgutil.norm(g["p1"], g["p2"])) == g["fmt6"]
+    assert "{:.6f}".format(ol.norm(g["p1"], g["p2"])) == g["fmt6"]
 
 
 def test_segment_helpers():
-    s = imgutil.segment_from_hough((100.0, 0.0), (480, 640))         # vertical line x = 100
-    assert s.coords == (100, 640, 100, -640)
-    assert abs(s.theta - math.pi / 2) < 1e-12
-    h = imgutil.segment_from_hough((50.0, math.pi / 2), (480, 640))  # horizontal line y = 50
+    """the oracle's restatement of the segment helpers (the C++ fold is compared with it in test_fold_cpu.py)"""
+    s = ol.seg_from_hough(100.0, 0.0, 480, 640)                      # vertical line x = 100
+    assert s == (100, 640, 100, -640)
+    assert abs(ol.seg_theta(s) - math.pi / 2) < 1e-12
+    h = ol.seg_from_hough(50.0, math.pi / 2, 480, 640)               # horizontal line y = 50
     # int() truncation of 50 -/+ 640*cos(pi/2) (= 50 -/+ 4e-14): the reference quirk parity keeps
-    assert h.coords[1] == 50 and h.coords[3] == 49
-    assert abs(s.line_angle(h) - math.pi / 2) < 2e-3
-    assert s.intersection(imgutil.Segment((0, 50, 640, 50))) == (100, 50)
-    assert s.intersection(imgutil.Segment((200, 0, 200, 10))) is None
+    assert h[1] == 50 and h[3] == 49
+    assert abs(ol.line_angle(s, h) - math.pi / 2) < 2e-3
+    assert ol.intersection(s, (0, 50, 640, 50)) == (100, 50)
+    assert ol.intersection(s, (200, 0, 200, 10)) is None
     # truncation toward zero, not rounding
-    d = imgutil.segment_from_hough((10.7, 0.3), (100, 100))
+    d = ol.seg_from_hough(10.7, 0.3, 100, 100)
     x0, y0 = math.cos(0.3) * 10.7, math.sin(0.3) * 10.7
-    assert d.coords[0] == int(x0 - 100 * math.sin(0.3)) and d.coords[1] == int(y0 + 100 * math.cos(0.3))
+    assert d[0] == int(x0 - 100 * math.sin(0.3)) and d[1] == int(y0 + 100 * math.cos(0.3))
 
 
 def test_connect_clusters_uses_x_only():
     groups = [[(10, 0)], [(11, 500)], [(300, 0)]]
-    imgutil.connect_clusters(groups, 25)
+    ol.BoardLogic.connect_clusters(groups, 25)
     assert len(groups) == 2            # (10,0) and (11,500) merge although 500 px apart in y
-    assert imgutil.within_margin((5, 5), (0, 0, 10, 10), 1)
-    assert not imgutil.within_margin((0, 5), (0, 0, 10, 10), 0)
+
+
+def test_goban_corners_bookkeeping():
+    from camkifu_amd.board.boardfinder import GobanCorners
+    gc = GobanCorners()
+    gc.frame = np.zeros((480, 640, 3), np.uint8)
+    for p in [(126, 96), (514, 92), (520, 100), (638, 364), (5, 367)]:
+        gc.submit(p)                   # (520, 100) is closer than 480 / 5 to (514, 92): rejected while filling up
+    assert gc.is_ready() and gc.hull == [(126, 96), (514, 92), (638, 364), (5, 367)]
+    gc.submit((630, 370))              # complete: the nearest corner is replaced
+    assert gc.hull == [(126, 96), (514, 92), (630, 370), (5, 367)]
+    gc.clear()
+    assert not gc.is_ready() and gc.hull is None
+    assert GobanCorners([(0, 0), (5, 5), (10, 10), (3, 3)]).hull is None          # four points, no quadrilateral
 
 
 def test_nnmanager_codec_and_geometry():
@@ -91,46 +112,3 @@ def test_posgrid_and_getrect():
     for k, v in GOLD["sf_getrect"].items():
         r, c = map(int, k.split(","))
         assert list(sf.getrect(r, c)) == v
-
-
-def test_group_intersections_matches_the_plain_double_loop():
-    """the bisect membership test in BoardFinderAuto.group_intersections is a pure speed-up: same
-    groups, same order as the reference's any(...) formulation (bf_auto.py:143-172)"""
-    import math
-    import random
-    from camkifu_amd.board.bf_auto import BoardFinderAuto
-    from camkifu_amd.core import imgutil
-
-    class _VM:
-        imqueue = None
-
-    def plain(lines, shape):
-        length_ref = min(shape[0], shape[1])
-        margin, thresh = -length_ref / 15, (length_ref / 80) ** 2
-        groups = []
-        ordered = sorted(lines, key=lambda s: s.theta)
-        for s1 in ordered:
-            for s2 in reversed(ordered):
-                if not (math.pi / 3 < s1.line_angle(s2)):
-                    break
-                p0 = s1.intersection(s2)
-                if not imgutil.within_margin(p0, (0, 0, shape[1], shape[0]), margin):
-                    continue
-                for g in groups:
-                    if any((p0[0] - p1[0]) ** 2 + (p0[0] - p1[0]) ** 2 < thresh for p1 in g):
-                        g.append(p0)
-                        break
-                else:
-                    groups.append([p0])
-        return groups
-    rng = random.Random(5)
-    for trial in range(200):
-        shape = (480, 640, 3)
-        lines = []
-        for _ in range(rng.randint(2, 24)):
-            theta = rng.choice([0.03, 0.05, 1.55, 1.6, 1.58, 3.1, 0.8]) + rng.uniform(-0.02, 0.02)
-            lines.append(imgutil.segment_from_hough((rng.uniform(-300, 600), theta), shape[:2]))
-        bf = BoardFinderAuto(_VM(), ctx=False)
-        bf.lines_accu = list(lines)
-        bf.group_intersections(shape)
-        assert bf.groups_accu == plain(lines, shape), trial

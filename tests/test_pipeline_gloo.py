@@ -1,10 +1,13 @@
-"""N > 1 path on CPU: two processes, `gloo` backend.  Frames are dealt f -> rank f mod 2, each
-rank computes its shard's per-frame records, ONE all_gather moves them, and the ordered fold on
-every rank must give exactly what a single process gives on the whole batch."""
+"""N > 1 path on CPU: processes on the `gloo` backend.  Frames are dealt f -> rank f mod world, each rank computes
+its shard's per-frame records, ONE all_gather moves them, the background model runs sharded by PIXEL (bands of
+goban rows exchanged in one all_to_all, each rank's band through the whole batch in frame order), rank 0 folds
+and broadcasts the transform.  What rank 0 ends up with must be exactly what a single process gives on the
+whole batch -- including batches smaller than the world and frames with more Hough lines than a record holds."""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -12,71 +15,136 @@ import torch.multiprocessing as mp
 from camkifu_amd import pipeline
 from camkifu_amd.controller import ControllerHeadless
 
-H, W, NF = 480, 640, 13          # odd on purpose: ranks hold 7 and 6 frames
+H, W = 480, 640
+BATCHES = (13, 13, 1, 9, 22)      # odd sizes on purpose; the third is smaller than the world
+BG = 4                            # background frames of the stones policy in this test
 
 
-def _fake_compute(frame_ids):
+def _goban(g):
+    """goban image of global stones-frame g: a flat board, sensor noise, and a dark block that comes and goes"""
+    rng = np.random.default_rng(7000 + g)
+    img = np.full((380, 380, 3), (70, 110, 140), np.uint8) + rng.integers(0, 3, (380, 380, 3), dtype=np.uint8)
+    k = g % 12
+    if 5 <= k < 9:
+        img[60:130, 200 + 4 * k:290 + 4 * k] = 20
+    if g >= 14:
+        img[330:, 330:] = 230                      # something appears on the last row / column for good
+    return img
+
+
+def _fake_compute(state, use_band_model):
     """deterministic stand-in for the GPU core: records depend only on the global frame index"""
-    def compute(frames, mtx):
-        board, labels, conf = [], [], []
-        for f in frame_ids:
+    from .stub_ctx import OracleCtx
+    ctx = OracleCtx()
+    full_model = ctx.mog2_create(380, 380)
+
+    def compute(frames, mtx, rates):
+        ids = state["ids"]
+        board, rl, rc, fg, gob = [], [], [], [], []
+        for k, f in enumerate(ids):
             rng = np.random.default_rng(1000 + int(f))
-            # the four sides of a slanted board (so that the fold does find corners) plus a
-            # frame-dependent number of near-duplicates, as Hough peaks come in practice
+            # the four sides of a slanted board (so that the fold does find corners) plus a frame-dependent number
+            # of near-duplicates, as Hough peaks come in practice; frame 3 carries more lines than a record holds
             sides = np.array([[100, 0.05], [540, 0.08], [60, 1.55], [420, 1.62]], np.float32)
-            k = int(rng.integers(0, 4))
-            dup = sides[rng.integers(0, 4, k)] + np.stack([rng.integers(-1, 2, k), np.zeros(k)], 1).astype(np.float32)
+            extra = 70 if f == 3 else int(rng.integers(0, 4))
+            dup = sides[rng.integers(0, 4, extra)] + np.stack([rng.integers(-1, 2, extra), np.zeros(extra)], 1).astype(np.float32)
             lines = np.concatenate([sides, dup])
             board.append(dict(status=0, n_contours=1 + int(f), n_lines=len(lines), biggest_area=2e5 + f, lines=lines))
-            labels.append(rng.integers(0, 3, (19, 19)).astype(np.uint8))
-            conf.append(rng.uniform(0.3, 1.0, (19, 19)))
-        return board, np.stack(labels), np.stack(conf)
-    return compute
+            if mtx is not None:
+                g = state["stones_seen"] + int(np.flatnonzero(state["batch_ids"] == f)[0])
+                img = _goban(g)
+                gob.append(img)
+                lab = np.zeros((10, 10), np.uint8)
+                if g >= 14:
+                    lab[9, 9] = 2 * 27                       # white on (18, 18) once it has appeared
+                rl.append(lab)
+                rc.append(rng.uniform(0.7, 1.0, (10, 10)))
+                if not use_band_model:
+                    fg.append(ctx.zone_counts(ctx.mog2_apply(full_model, img, float(rates[k]))))
+        n = len(ids)
+        if mtx is None:
+            return board, np.zeros((n, 10, 10), np.uint8), np.zeros((n, 10, 10)), None, None
+        gobs = np.stack(gob) if gob else np.zeros((0, 380, 380, 3), np.uint8)
+        return (board, np.stack(rl) if rl else np.zeros((0, 10, 10), np.uint8), np.stack(rc) if rc else np.zeros((0, 10, 10)),
+                (np.stack(fg) if fg else None) if not use_band_model else None, gobs if use_band_model else None)
+    return compute, ctx
+
+
+def _drive(rank, world):
+    ctrl = ControllerHeadless()
+    state = dict(ids=None, batch_ids=None, stones_seen=0)
+    compute, octx = _fake_compute(state, use_band_model=world > 1)
+    pipe = pipeline.FastFilePipeline(H, W, ctrl, rank=rank, world=world, compute=compute, bg_init_frames=BG)
+    if world > 1:
+        a, b = pipe.band
+        handle = octx.mog2_create(min(20 * b, 380) - 20 * a, 380)
+        pipe.band_model = lambda band, rates: octx.mog2_band_run(handle, band.numpy(), rates, last_band=(b == 19))
+    pipe.board.refresh_frames = 3
+    out, first = [], 0
+    for n in BATCHES:
+        state["batch_ids"] = first + np.arange(n)
+        state["ids"] = state["batch_ids"][pipeline.shard_indices(n, rank, world)]
+        had_mtx = pipe.mtx is not None
+        emitted = pipe.process_batch(None, n)
+        if had_mtx:
+            state["stones_seen"] += n
+        out.append(emitted)
+        first += n
+    mtx = None if pipe.mtx is None else pipe.mtx.tolist()
+    return out, ctrl.kifu.to_sgf(), mtx, pipe.stones.policy.state()["targets"].tolist()
 
 
 def _run(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ctrl = ControllerHeadless()
-    idx = pipeline.shard_indices(NF, rank, world)
-    pipe = pipeline.FastFilePipeline(H, W, ctrl, rank=rank, world=world, compute=_fake_compute(idx))
-    pipe.board.refresh_frames = 3
-    out = []
-    for batch in range(2):
-        emitted = pipe.process_batch(None, NF)
-        out.append([[(m.color, m.x, m.y) for m in mv] for mv in emitted])
-    q.put((rank, out, ctrl.kifu.to_sgf(), None if pipe.board.mtx is None else pipe.board.mtx.tolist()))
-    dist.destroy_process_group()
+    try:
+        q.put((rank,) + _drive(rank, world))
+    finally:
+        dist.destroy_process_group()
 
 
-def _single():
-    ctrl = ControllerHeadless()
-    pipe = pipeline.FastFilePipeline(H, W, ctrl, compute=_fake_compute(np.arange(NF)))
-    pipe.board.refresh_frames = 3
-    out = []
-    for batch in range(2):
-        emitted = pipe.process_batch(None, NF)
-        out.append([[(m.color, m.x, m.y) for m in mv] for mv in emitted])
-    return out, ctrl.kifu.to_sgf(), None if pipe.board.mtx is None else pipe.board.mtx.tolist()
-
-
-def test_record_roundtrip():
-    board, labels, conf = _fake_compute(np.arange(5))(None, None)
-    rec = pipeline.pack_records(board, labels, conf)
-    assert rec.shape == (5, pipeline.REC_BYTES)
-    for f in range(5):
-        r = pipeline.unpack_record(rec[f])
-        assert r["n_contours"] == board[f]["n_contours"] and r["biggest_area"] == board[f]["biggest_area"]
-        assert np.array_equal(r["lines"], board[f]["lines"]) and np.array_equal(r["labels"], labels[f])
-        assert np.array_equal(r["conf"], conf[f])
+def test_record_roundtrip_and_line_cap():
+    rng = np.random.default_rng(1)
+    board = [dict(status=0, n_contours=4, n_lines=3, biggest_area=1e5, lines=rng.random((3, 2)).astype(np.float32)),
+             dict(status=2, n_contours=1, n_lines=0, biggest_area=7.5, lines=np.zeros((0, 2), np.float32)),
+             dict(status=0, n_contours=9, n_lines=90, biggest_area=3e5, lines=rng.random((90, 2)).astype(np.float32))]
+    rl = rng.integers(0, 81, (3, 10, 10)).astype(np.uint8)
+    rc = rng.random((3, 10, 10))
+    rec = pipeline.pack_records(board, rl, rc)
+    assert rec.dtype.itemsize == pipeline.REC_BYTES and rec.shape == (3,)
+    assert rec["n_lines"].tolist() == [3, 0, 90] and rec["flags"].tolist() == [0, 0, pipeline.FLAG_LINES_CUT]
+    assert np.array_equal(rec["lines"][0, :3], board[0]["lines"]) and not rec["lines"][0, 3:].any()
+    assert np.array_equal(rec["lines"][2], board[2]["lines"][:pipeline.LMAX])           # the strongest LMAX lines survive
+    assert np.array_equal(rec["region_label"], rl) and np.array_equal(rec["region_conf"], rc)
+    assert rec["biggest_area"].tolist() == [1e5, 7.5, 3e5]
+    # the raw form Context.board_detect(raw=True) hands over packs to the same bytes, stale scratch does not leak
+    from camkifu_amd import capi
+    res = np.zeros(3, capi.BOARD_DTYPE)
+    lines = np.full((3, 128, 2), 7.0, np.float32)
+    for f, b in enumerate(board):
+        res[f] = (b["status"], b["n_contours"], b["n_lines"], 0, b["biggest_area"])
+        lines[f, :b["n_lines"]] = b["lines"]
+    assert pipeline.pack_records((res, lines), rl, rc).tobytes() == rec.tobytes()
     assert list(pipeline.shard_indices(7, 1, 3)) == [1, 4]
+    assert pipeline.band_rows(8) == [(0, 2), (2, 5), (5, 7), (7, 10), (10, 12), (12, 14), (14, 17), (17, 19)]
+    assert pipeline.band_rows(1) == [(0, 19)]
 
 
-def test_two_rank_fold_equals_single_process():
-    # K7 (ck_get_perspective_transform) is host-only code of the C-ABI: it runs without a GPU
-    ref = _single()
-    assert ref[2] is not None                      # the fold did find the board
-    assert sum(len(m) for m in ref[0][1]) > 0      # second batch emits moves (transform known)
+def test_grid_of_regions_matches_the_oracle(ora):
+    rng = np.random.default_rng(3)
+    y = rng.random((100, 81)).astype(np.float32)
+    lab, conf = ora.decode_regions(y)
+    grid, cgrid = pipeline.grid_of(lab.reshape(1, 10, 10), conf.reshape(1, 10, 10))
+    want_l, want_c = ora.decode_all(y)
+    assert np.array_equal(grid[0], want_l) and np.array_equal(cgrid[0], want_c)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_fold_equals_single_process(world):
+    ref = _drive(0, 1)
+    assert ref[2] is not None                                  # the fold did find the board
+    assert any(req for batch in ref[0] for req in batch)       # and the policy emitted something afterwards
+    assert "W[ss]" in ref[1] or "W[" in ref[1]
 
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -84,25 +152,17 @@ def test_two_rank_fold_equals_single_process():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_run, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted(q.get(timeout=240) for _ in range(world))
     for p in procs:
-        p.join(30)
+        p.join(60)
         assert p.exitcode == 0
-    for rank, out, sgf, mtx in res:
-        assert out == ref[0] and sgf == ref[1]
-        assert np.allclose(np.array(mtx), np.array(ref[2]))
-
-
-def test_raw_pack_equals_dict_pack():
-    from camkifu_amd import capi
-    board, labels, conf = _fake_compute(np.arange(9))(None, None)
-    res = np.zeros(9, capi.BOARD_DTYPE)
-    lines = np.zeros((9, pipeline.LMAX, 2), np.float32)
-    for f, b in enumerate(board):
-        res[f] = (b["status"], b["n_contours"], b["n_lines"], 0, b["biggest_area"])
-        lines[f, :b["n_lines"]] = b["lines"]
-        lines[f, b["n_lines"]:] = 7.0                      # stale scratch beyond n_lines must not leak
-    assert np.array_equal(pipeline.pack_records_raw(res, lines, labels, conf), pipeline.pack_records(board, labels, conf))
+    rank0 = res[0]
+    assert rank0[1] == ref[0] and rank0[2] == ref[1]           # same requests, same game record
+    assert rank0[4] == ref[3]                                  # same policy state (targets) at the end
+    for r in res:
+        assert np.allclose(np.array(r[3]), np.array(ref[2]))   # every rank holds the broadcast transform
+    for r in res[1:]:
+        assert all(e is None for e in r[1])                    # only rank 0 folds

@@ -55,27 +55,56 @@ def test_controller_with_rules_keeps_record_and_goban_apart():
     assert plain.get_stones()[0, 0] == W            # default: a plain mirror of the finders' reports
 
 
-@pytest.mark.parametrize("linger", [0, 3])
-def test_fold_replays_a_game_with_captures(linger, tmp_path):
-    """positions of a random legal game (several captures) shown frame by frame; with linger > 0 the
-    prisoners stay on the board for a few frames after the capture, as in real footage"""
+def _regions_of(grid):
+    """(19, 19) uint8 grid -> the (10, 10) labels a perfect classifier would answer"""
+    from camkifu_amd.stone import nn_manager as nm
+    lab = np.zeros((10, 10), np.uint8)
+    for i, rs in enumerate(nm.REGION_START):
+        for j, cs in enumerate(nm.REGION_START):
+            lab[i, j] = sum(int(v) * 3 ** k for k, v in enumerate(grid[rs:rs + 2, cs:cs + 2].reshape(4)))
+    return lab
+
+
+def _film(moves, positions, hand=6, calm=3, bg=3):
+    """what the camera and the background model would report for a game: `bg` frames of the empty board, then per
+    move `hand` frames during which a hand covers the point played and its neighbours (the board still shows the
+    previous position, prisoners being taken off by the same hand) and `calm` frames showing the new position"""
+    rl, fg = [], []
+    shown = np.zeros((19, 19), np.uint8)
+    for _ in range(bg + 1):
+        rl.append(_regions_of(shown))
+        fg.append(np.zeros((19, 19), np.int32))
+    for (color, r, c), pos in zip(moves, positions):
+        busy = np.zeros((19, 19), np.int32)
+        busy[max(0, r - 1):r + 2, max(0, c - 1):c + 2] = 400
+        for _ in range(hand):
+            rl.append(_regions_of(shown))
+            fg.append(busy)
+        shown = pos
+        for _ in range(calm):
+            rl.append(_regions_of(shown))
+            fg.append(np.zeros((19, 19), np.int32))
+    return np.stack(rl), np.stack(fg)
+
+
+@pytest.mark.parametrize("chunk", [None, 37])
+def test_fold_replays_a_game_with_captures(chunk, tmp_path):
+    """a random legal game (several captures) filmed move by move and folded by the stones policy: every stone is
+    found once its zone has been agitated and has calmed down, prisoners leave the goban through the rule engine,
+    and the record equals the game -- whether the film is folded in one run or in batches"""
     rng = np.random.default_rng(20161001)
-    moves, positions, captured = synth.random_game(120, rng, cool=linger)
+    moves, positions, captured = synth.random_game(120, rng)
     assert sum(len(c) for c in captured) >= 5, "the fixture game must contain captures"
+    rl, fg = _film(moves, positions)
+    rc = np.full(rl.shape, 0.95)
     ctrl = ControllerHeadless(rules=True)
-    fold = StonesFold(ctrl)
-    conf = np.ones((19, 19))
-    for k, pos in enumerate(positions):
-        shown = pos.copy()
-        for j in range(max(0, k - linger + 1), k + 1):                 # prisoners of the last `linger` moves
-            for col, r, c in (captured[j] if linger else ()):
-                if shown[r, c] == 0:
-                    shown[r, c] = 1 if col == B else 2
-        for _ in range(2):                                             # every position is seen twice
-            fold.step(shown, conf)
-    for _ in range(2):
-        fold.step(positions[-1], conf)
+    fold = StonesFold(ctrl, bg_init_frames=3)
+    step = chunk or len(rl)
+    requests = []
+    for k in range(0, len(rl), step):
+        requests.extend(fold.run(rl[k:k + step], rc[k:k + step], fg[k:k + step]))
     assert [(m.color, m.y, m.x) for m in ctrl.kifu.moves] == moves
+    assert all(kind == 1 for per_frame in requests for kind, _ in per_frame)          # one stone at a time: suggest()
     got = ctrl.get_stones()
     want = np.array([[E, B, W][v] for v in positions[-1].reshape(-1)], dtype=object).reshape(19, 19)
     assert (got == want).all()
@@ -88,7 +117,5 @@ def test_fold_replays_a_game_with_captures(linger, tmp_path):
     assert KifuChecker(path).check(ctrl.kifu).ratio() == 1.0
     # without the rule engine the goban keeps the prisoners: it no longer matches the camera
     plain = ControllerHeadless()
-    fold2 = StonesFold(plain)
-    for pos in positions:
-        fold2.step(pos, conf)
+    StonesFold(plain, bg_init_frames=3).run(rl, rc, fg)
     assert (plain.get_stones() != want).any()

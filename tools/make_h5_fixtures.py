@@ -6,7 +6,7 @@ The files pin camkifu_amd/stone/h5lite.py (a from-scratch reader) against what l
   tests/golden/h5_structures.h5 (+ .json manifest of expected values)
       groups (a 40-entry one: several symbol-table nodes), contiguous / compact / chunked / deflate+shuffle
       datasets of several types, fixed and variable-length string attributes, numeric attributes.
-  tests/golden/keras.h5
+  camkifu_amd/data/keras.h5
       the trained stone classifier (tools/train_cnn.py -> tools/out/cnn_weights.npz) written the way Keras 1.2 `model.save`
       lays a model out (the file the reference loads: stone/nn_manager.py:22, 65-73): root attributes
       keras_version / model_config, group model_weights with attribute layer_names, one group per layer

@@ -32,7 +32,7 @@ def ref64(W, goban):
 def main():
     ctx = capi.Context(0)
     dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
-    for name, W in (("trained (tests/golden/keras.h5)", NNManager.init_net()), ("seeded random", synth.cnn_weights())):
+    for name, W in (("trained (camkifu_amd/data/keras.h5)", NNManager.init_net()), ("seeded random", synth.cnn_weights())):
         ctx.cnn_set_weights(W)
         errs = {m: 0.0 for m in ("fp32", "f16x2", "bf16", "oracle")}
         flips = {m: 0 for m in errs}

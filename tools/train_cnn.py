@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Train the stone classifier (NNManager.create_net architecture, nn_manager.py:277-298) on the
 synthetic renderer and write tools/out/cnn_weights.npz in Keras-1 'tf' layout
-(tools/make_h5_fixtures.py turns it into tests/golden/keras.h5 with the real h5py).
+(tools/make_h5_fixtures.py turns it into camkifu_amd/data/keras.h5 with the real h5py).
 
 The reference's trained keras.h5 cannot be fetched here (cvconf.py:58, no network), so labels
 produced with seeded random weights are meaningless.  This script makes them meaningful:
