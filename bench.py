@@ -1,21 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the per-frame vision hot path on synthetic 1080p video.
 
-One "step" = one pass of the hot path over one batch of frames that is already resident in
-HBM: board detect (K1..K6: median -> Canny -> contours -> Hough lines, lines back on the
-host) and stones detect (K8, K10..K12: warp -> 100 patches -> CNN -> 19x19 labels) for every
-frame of the batch, then (N > 1) ONE RCCL all-gather of the fixed-size per-frame records and the
-ordered host fold (line accumulation -> corners; label acceptance -> moves) on every rank.
-Workload (BASELINE.json configs[2]): 1080p, 256-frame batches on one MI355X; with N GPUs
-every rank processes its own 256-frame shard of the video (weak scaling, no data-path
-collective except the label gather).
+One "step" = one pass of the hot path over one batch of frames ALREADY RESIDENT IN HBM (rendered there once,
+before the timed region; the PCIe-inclusive rate is measured separately and reported as `pcie_inclusive`, it is
+never `value`): per frame board detect (K1..K6: median -> Canny -> contours -> Hough lines, lines back on the host)
+and the stones path (K8 warp -> K9 background model in frame order -> K10..K12 classifier answers for the 100
+regions), then the fixed-size per-frame records are packed, gathered (N > 1: ONE RCCL all-gather, plus the
+all-to-all of goban bands for the pixel-sharded background model) and folded IN FRAME ORDER on rank 0 by the
+library's ordered policy (corners -> transform, stones -> moves); the transform is broadcast back.
+Workload (BASELINE.json configs[2]): 1080p, 256-frame batches on one MI355X; with N GPUs ONE video is dealt to
+the ranks frame by frame (rank r holds frames r, r+N, ...), 256 frames per rank and step (weak scaling).
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
-torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run, one rank
+per GPU.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -23,32 +25,117 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
-MFMA_F32_PEAK_TF = 157.3         # v_mfma_f32_32x32x2_f32 dense peak
-MFMA_BF16_PEAK_TF = 2500.0
-
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3         # dense f32 MFMA
+MFMA_F16_PEAK_TF = 2500.0        # dense fp16 / bf16 MFMA
 # MACs per frame (100 patches), SURVEY.md 8(a)
 MACS = dict(cnn_conv1=311.04e6, cnn_conv2=2621.44e6, cnn_conv3=508.03e6, cnn_conv4=1049.76e6)
+FUSED_FILTER_BYTES = lambda h, w: 4 * h * w          # noqa: E731  read the frame once, write the edge map
+DST = [(0, 0), (380, 0), (380, 380), (0, 380)]
 
 
-def cpu_baseline(h, w, frames, corners, weights, nframes):
-    """Time the CPU oracle (our C restatement, OpenMP) on a bounded sample of the same workload."""
-    import numpy as np
+def thresholds_per_tile(med):
+    """what the median kernel's radix descent evaluates for a median image (n, h, w, 3) torch uint8: per 48x48 tile and
+    channel, one box filter per distinct prefix at each of the 8 bit levels -> mean count per tile"""
+    import torch
+    n, h, w, _ = med.shape
+    hh, ww = (h // 48) * 48, (w // 48) * 48
+    t = med[:, :hh, :ww].reshape(n, hh // 48, 48, ww // 48, 48, 3).permute(0, 1, 3, 5, 2, 4).reshape(-1, 48 * 48).to(torch.int64)
+    total = torch.zeros(t.shape[0], dtype=torch.int64, device=med.device)
+    for b in range(8):
+        pre = t >> (b + 1)
+        onehot = torch.zeros((t.shape[0], 256 >> (b + 1)), dtype=torch.bool, device=med.device)
+        onehot.scatter_(1, pre, True)
+        total += onehot.sum(1)
+    return float(total.float().mean())
+
+
+def cpu_baseline(frames, M, weights, n_warm, n_frames, reps):
+    """the CPU oracle (our C restatement, OpenMP) on a bounded sample of the same batch: `n_warm` untimed frames, then
+    the median of `reps` timings of `n_frames` frames (board path + stones path per frame)"""
     from oracle import oracle as ora
-    dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
-    M = ora.get_perspective_transform(corners, dst)
-    sample = [frames[i].cpu().numpy() for i in range(nframes)]
-    t0 = time.perf_counter()
-    for fr in sample:
+    sample = [frames[i].cpu().numpy() for i in range(max(n_warm, n_frames))]
+
+    def one(fr):
         ora.board_lines(ora.canny(ora.median(fr, 15), 25, 75))
         ora.decode_all(ora.cnn_predict_regions(weights, ora.warp_perspective(fr, M)))
-    dt = time.perf_counter() - t0
-    return dict(value=round(nframes / dt, 4), unit="frames/s", cores=ora.num_threads(), kind="port",
-                sample="%d frames of the same %dx%d batch, board path + stones path, oracle/*.c with OpenMP"
-                       % (nframes, w, h))
+    for fr in sample[:n_warm]:
+        one(fr)
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for fr in sample[:n_frames]:
+            one(fr)
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    return dict(value=round(n_frames / dt, 4), unit="frames/s", cores=ora.num_threads(), kind="port",
+                sample="median of %d timings of %d frames of the same batch after %d warm-up frames; board path + stones "
+                       "path per frame; oracle/*.c with OpenMP (%d threads of %d host cores)"
+                       % (reps, n_frames, n_warm, ora.num_threads(), os.cpu_count() or 0))
 
 
-LANES_DEFAULT = 2
+def torch_cpu_cnn_fps(weights, n_frames=4, reps=3):
+    """BASELINE.md 3's CNN leg: torch CPU fp32, batch = the 100 patches of a frame (true convolution = flipped kernels)"""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    w = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()}
+    conv = lambda x, k, b: F.relu(F.conv2d(x, k.flip(0, 1).permute(3, 2, 0, 1).contiguous(), b))    # noqa: E731
+    x = torch.rand(100, 3, 40, 40) * 255
+
+    def net(x):
+        x = conv(conv(x, w["c1w"], w["c1b"]), w["c2w"], w["c2b"])
+        x = F.max_pool2d(x, 2)
+        x = conv(conv(x, w["c3w"], w["c3b"]), w["c4w"], w["c4b"])
+        x = F.max_pool2d(x, 2).permute(0, 2, 3, 1).reshape(100, -1)
+        return torch.softmax(F.relu(x @ w["d1w"] + w["d1b"]) @ w["d2w"] + w["d2b"], 1)
+    with torch.no_grad():
+        net(x)
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            for _ in range(n_frames):
+                net(x)
+            times.append(time.perf_counter() - t0)
+    return dict(value=round(n_frames / statistics.median(times), 2), unit="frames/s", threads=torch.get_num_threads())
+
+
+def cv2_crosscheck(ctx, frames, M):
+    """If the box happens to have OpenCV: the reference's exact call sequence (board/bf_auto.py:72-75, 125-133;
+    stone/stonesfinder.py:140) on two frames of the batch, diffed stage by stage against the HIP path."""
+    try:
+        import cv2
+    except Exception:
+        return {"cv2": "absent"}
+    import math
+    import numpy as np
+    out = {"cv2": cv2.__version__, "frames": 2, "mismatch": {}}
+    try:
+        mm = out["mismatch"]
+        for k in range(2):
+            fr = frames[k].cpu().numpy()
+            med = cv2.medianBlur(fr, 15)
+            mm["median_px"] = mm.get("median_px", 0) + int((med != np.asarray(ctx.median15(fr))).sum())
+            can = cv2.Canny(med, 25, 75)
+            mm["canny_px"] = mm.get("canny_px", 0) + int((can != np.asarray(ctx.canny(med))).sum())
+            found = cv2.findContours(can.copy(), cv2.RETR_EXTERNAL, cv2.CHAIN_APPROX_SIMPLE)
+            contours = found[-2]
+            res, ghost_hip = ctx.board_lines(can, want_ghost=True)
+            mm["n_contours"] = mm.get("n_contours", 0) + abs(len(contours) - res[0]["n_contours"])
+            boxes = sorted(range(len(contours)), key=lambda i: (lambda b: b[1][0] * b[1][1])(cv2.minAreaRect(contours[i])))
+            ghost = np.zeros(can.shape, np.uint8)
+            for pos in boxes[-3:]:
+                cv2.drawContours(ghost, contours, pos, 255, thickness=1)
+            mm["ghost_px"] = mm.get("ghost_px", 0) + int((ghost != np.asarray(ghost_hip).reshape(can.shape)).sum())
+            lines = cv2.HoughLines(ghost, 1, math.pi / 180, threshold=int(min(can.shape) / 5))
+            lines = np.zeros((0, 2), np.float32) if lines is None else lines.reshape(-1, 2)
+            same = len(lines) == res[0]["n_lines"] and np.array_equal(lines, res[0]["lines"][:len(lines)])
+            mm["hough_lists_differ"] = mm.get("hough_lists_differ", 0) + (0 if same else 1)
+            warp = cv2.warpPerspective(fr, M, (380, 380))
+            mm["warp_px"] = mm.get("warp_px", 0) + int((warp != np.asarray(ctx.warp_perspective(fr, M))).sum())
+    except Exception as why:
+        out["error"] = "%s: %s" % (type(why).__name__, why)
+    return out
 
 
 def main():
@@ -63,13 +150,11 @@ def main():
                     help="f16x2 (default): f32-accurate split-fp16 operands on the fp16 matrix pipe; fp32: k-ordered f32 "
                          "MFMA chain; bf16: bf16 operands (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip fp32_chain / pcie_inclusive / k1_content / cv2 legs")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--cpu-frames", type=int, default=8)
-    ap.add_argument("--streams", action="store_true",
-                    help="BASELINE config 5: every GPU processes its OWN video stream (seed + rank), no record gather; "
-                         "the default is ONE video whose frames are dealt to the ranks and gathered (configs 3 / 4)")
-    ap.add_argument("--lanes", type=int, default=LANES_DEFAULT,
+    ap.add_argument("--lanes", type=int, default=2,
                     help="pairs of (board, stones) contexts per GPU; the batch is split between them so more "
                          "kernels are in flight and drain / host gaps of one lane are filled by the others")
     args = ap.parse_args()
@@ -94,275 +179,246 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
-    from camkifu_amd import capi, synth
-    from concurrent.futures import ThreadPoolExecutor
-    # like the reference, the board finder and the stones finder are two threads; each owns a
-    # context (= HIP stream + scratch), so the host-side gaps of one path are filled by the other
-    ctx_b = capi.Context(local_rank)
-    ctx = capi.Context(local_rank)
-    lanes = [(ctx_b, ctx)] + [(capi.Context(local_rank), capi.Context(local_rank)) for _ in range(args.lanes - 1)]
+    from camkifu_amd import capi, pipeline, synth
+    from camkifu_amd.controller import ControllerHeadless
+    from camkifu_amd.stone.nn_manager import NNManager, KERAS_MODEL_FILE
     H, W, F = args.height, args.width, args.frames
+    lanes = [(capi.Context(local_rank), capi.Context(local_rank)) for _ in range(args.lanes)]
+    ctx_bg = capi.Context(local_rank)
+    ctx_b, ctx = lanes[0]
 
-    # ---- synthetic video shard of this rank, rendered straight into HBM --------------------
-    # ONE game filmed by a fixed camera, world*F frames long: a random mid-game position, then one
-    # new stone every 5 frames.  Global frame g lives on rank g mod world (the
-    # pipeline's sharding), so every rank builds the same move list and renders only its frames;
-    # frames that show an unchanged position are the last render under fresh sensor noise.
-    dworld, drank = (1, 0) if args.streams else (world, rank)   # how the VIDEO is laid out over the ranks
-    rng = np.random.default_rng(synth.SEED + (rank if args.streams else 0))     # one game: identical on every rank
-    corners = synth.random_corners(H, W, rng)
-    frames = torch.empty((F, H, W, 3), dtype=torch.uint8, device=dev)
-    stones0 = synth.random_stones(rng, density=0.3)
-    true_moves = [("EBW"[stones0[r, c]], r, c) for r in range(19) for c in range(19) if stones0[r, c]]
-    n_init = len(true_moves)
-    positions, st, color = [stones0.copy()], stones0.copy(), 1
-    for k in range((dworld * F - 1) // 5):
-        while True:
-            r, c = rng.integers(1, 18, 2)
-            if st[r, c] == 0:
-                break
-        st[r, c] = color
-        true_moves.append(("EBW"[color], int(r), int(c)))
-        color = 3 - color
-        positions.append(st.copy())
-    truth = np.zeros((F, 19, 19), np.uint8)
-    last_pos, last = -1, None
-    for i in range(F):
-        g_idx = i * dworld + drank
-        pos = g_idx // 5
-        if pos != last_pos:
-            frames[i] = synth.render(H, W, positions[pos], corners, seed=synth.SEED + g_idx, device=dev)
-            last_pos, last = pos, i
-        else:
-            g = torch.Generator(device=dev)
-            g.manual_seed(synth.SEED + 7 * g_idx)
-            noise = torch.randint(-2, 3, frames[last].shape, generator=g, device=dev, dtype=torch.int16)
-            frames[i] = (frames[last].to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
-        truth[i] = positions[pos]
-    from camkifu_amd.stone.nn_manager import NNManager, GOLDEN_WEIGHTS
-    weights = NNManager.init_net()               # trained fixture when present, else seeded He-normal
+    # ---- ONE synthetic game filmed by a fixed camera, world * F frames; this rank renders its frames into HBM -------
+    # 52 quiet frames (the stones finder's background frames), then a move every 32 frames: a hand covers the point
+    # for 12 frames, then the stone is there (synth.film).  Global frame g lives on rank g mod world.
+    n_total = world * F
+    mine = pipeline.shard_indices(n_total, rank, world)
+    frames, corners, truth, true_moves, hands = synth.film(n_total, H, W, seed=synth.SEED, device=dev, quiet=52,
+                                                           move_every=32, hand_frames=12, select=mine)
+    weights = NNManager.init_net()
     torch.cuda.synchronize()
+    mode = {"fp32": capi.CK_CNN_FP32, "bf16": capi.CK_CNN_BF16, "f16x2": capi.CK_CNN_F16X2}[args.cnn]
     for _, c in lanes:
         c.cnn_set_weights({k: torch.from_numpy(v).to(dev) for k, v in weights.items()})
-        c.cnn_set_mode({"fp32": capi.CK_CNN_FP32, "bf16": capi.CK_CNN_BF16, "f16x2": capi.CK_CNN_F16X2}[args.cnn])
-    dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
-    M = capi.get_perspective_transform(corners, dst)
-    from camkifu_amd import pipeline
-    from camkifu_amd.controller import ControllerHeadless
-    pipe = pipeline.FastFilePipeline(H, W, ControllerHeadless(), ctx=ctx, ctx_board=ctx_b, rank=drank, world=dworld,
-                                     device=cdev)
-    # one host thread per context (a context is single-threaded by contract), each with its own stream
-    pools = [(ThreadPoolExecutor(1), ThreadPoolExecutor(1)) for _ in lanes]
-    cuts = [round(i * F / len(lanes)) for i in range(len(lanes) + 1)]
-    slices = [frames[cuts[i]:cuts[i + 1]] for i in range(len(lanes))]
+        c.cnn_set_mode(mode)
+    M_true = capi.get_perspective_transform(corners, np.array(DST, np.float32))
 
-    class _Both:
-        """the per-lane futures of one step, joined: board = (records, lines), stones = (labels, conf)"""
-        def __init__(self, futs):
-            self.futs = futs
-
-        def board(self):
-            parts = [fb.result() for fb, _ in self.futs]
-            return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]))
-
-        def stones(self):
-            parts = [fs.result() for _, fs in self.futs]
-            return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
-
-    def launch():
-        """GPU part of one step: per lane, the board path and the stones path on two host threads / HIP streams"""
-        return _Both([(pb.submit(cb.board_detect, fr, -1, pipeline.LMAX, True),        # K1..K6, lines on the host
-                       ps.submit(cs.stones_detect, fr, M))                             # K8, K10..K12, labels in HBM
-                      for (pb, ps), (cb, cs), fr in zip(pools, lanes, slices)])
-
-    host_s = [0.0, 0.0, 0.0]        # pack, gather, fold: host seconds spent per phase (diagnostic)
-
-    def finish_host(board, labels, conf):
-        """pack the fixed-size per-frame records, one all-gather (RCCL over xGMI), ordered fold"""
-        t_a = time.perf_counter()
-        rec = pipeline.pack_records_raw(board[0], board[1], labels.cpu().numpy(), conf.cpu().numpy())
-        t_b = time.perf_counter()
-        full = pipeline.gather_records(rec, world * F, rank, world, cdev) if dworld > 1 else rec
-        t_c = time.perf_counter()
-        pipe.stones = pipeline.StonesFold(ControllerHeadless())     # every step replays the same game from scratch
-        pipe.fold(full)
-        t_d = time.perf_counter()
-        host_s[0] += t_b - t_a; host_s[1] += t_c - t_b; host_s[2] += t_d - t_c
-
-    def run_steps(k):
-        """k steps, two batches in flight: the host part of batch i (contour pruning inside board_detect,
-        records, gather, fold) overlaps the GPU work of batches i+1 and i+2"""
-        DEPTH = 2
-        inflight = [launch() for _ in range(min(DEPTH, k))]
-        for i in range(k):
-            futs = inflight.pop(0)
-            board = futs.board()
-            labels, conf = futs.stones()
-            if i + DEPTH < k:
-                inflight.append(launch())
-            finish_host(board, labels, conf)
-        return board, labels
-
-    def step_serial():
-        board = ctx_b.board_detect(frames, cap=pipeline.LMAX)
-        labels, conf = ctx.stones_detect(frames, M)
-        return board, labels
+    def new_pipe():
+        return pipeline.FastFilePipeline(H, W, ControllerHeadless(), rank=rank, world=world, device=cdev,
+                                         lanes=lanes, ctx_bg=ctx_bg)
+    pipe = new_pipe()
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup:
-        run_steps(args.warmup)
-    sync()
-    host_s[:] = [0.0, 0.0, 0.0]
-    t0 = time.perf_counter()
-    board, labels = run_steps(args.steps)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # per-kernel durations: HIP events on each context's own stream, taken over a short SERIAL
-    # pass right after the timed region (with the two paths overlapped, an event pair on one
-    # stream would also count the time the other stream's kernels hold the CUs)
-    prof_steps = 2
+    # ---- untimed: find the board (the stones path needs its transform), then one validated pass ---------------------
+    pipe.process_batch(frames, n_total)
+    board_found = pipe.mtx is not None
+    if not board_found:                       # never seen; the timed work must not silently lose the stones path
+        pipe.mtx = M_true
+    M = pipe.mtx.copy()
+    requests = pipe.process_batch(frames, n_total)            # fresh policy, fresh background model: frames 0 .. n_total-1
+    quality = {}
     if rank == 0:
+        sym = "EBW"
+        first = [(sym[truth[50][r, c]], r, c) for r in range(19) for c in range(19) if truth[50][r, c]]
+        played = [(sym[col], r, c) for col, r, c, f in true_moves if f + 14 < n_total]
+        seen = [m for per_frame in requests for kind, ms in per_frame for m in ms]
+        import difflib
+        quality["move_sequence_ratio"] = round(difflib.SequenceMatcher(a=["%s%d,%d" % m for m in first + played],
+                                                                       b=["%s%d,%d" % m for m in seen]).ratio(), 4)
+        quality["moves_true"], quality["moves_recorded"] = len(first) + len(played), len(seen)
+    # 19x19 grids of this rank's frames against the truth (frames with a hand over the board excluded)
+    calm = ~hands[mine]
+    out = ctx.stones_run(frames[:64], M)
+    grid = pipeline.grid_of(out["region_label"].cpu().numpy())
+    quality["stone_grid_match_pct"] = round(100.0 * float((grid[calm[:64]] == truth[mine[:64]][calm[:64]]).mean()), 3)
+
+    # ---- timed region: two batches in flight ------------------------------------------------------------------------
+    def run_steps(p, k, batch):
+        DEPTH = 2
+        tickets = [p.submit(batch, n_total) for _ in range(min(DEPTH, k))]
+        for i in range(k):
+            t = tickets.pop(0)
+            if i + DEPTH < k:
+                tickets.append(p.submit(batch, n_total))
+            p.stones = pipeline.StonesFold(ControllerHeadless())        # every step folds the same film from its start
+            p.finish(t)
+
+    def timed(p, steps, warmup, batch):
+        if warmup:
+            run_steps(p, warmup, batch)
+        sync()
+        for k in p.host_seconds:
+            p.host_seconds[k] = 0.0
+        t0 = time.perf_counter()
+        run_steps(p, steps, batch)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    dt = timed(pipe, args.steps, args.warmup, frames)
+    host_ms = {k: round(1e3 * v / args.steps, 3) for k, v in pipe.host_seconds.items()}
+
+    extras = {}
+    if not args.no_extras:
+        # (1) the equal-precision chain: same region, classifier in plain f32 MFMA
+        if args.cnn != "fp32":
+            for _, c in lanes:
+                c.cnn_set_mode(capi.CK_CNN_FP32)
+            k = max(3, args.steps // 5)
+            d32 = timed(pipe, k, 2, frames)
+            extras["fp32_chain"] = dict(value=round(n_total * k / d32, 2), unit="frames/s", steps=k,
+                                        note="same timed region with CK_CNN_FP32 (k-ordered f32 MFMA chain)")
+            for _, c in lanes:
+                c.cnn_set_mode(mode)
+        # (2) PCIe-inclusive: the batch starts as I420 in PINNED host memory (what a video-file reader holds), is
+        # uploaded and converted lane by lane (ck_i420_to_bgr), answers come back to the host; two batches in flight
+        if world == 1:
+            host_i420 = torch.empty((F, H * W * 3 // 2), dtype=torch.uint8).pin_memory()
+            some = np.stack([synth.bgr_to_i420(frames[i].cpu().numpy()) for i in range(0, F, max(1, F // 8))])
+            host_i420.numpy()[:] = some[np.arange(F) % len(some)]
+            core = pipe.compute
+
+            def from_host(raw, mtx, rates):
+                cuts = core._cuts(len(raw))
+                parts = [ps.submit(cs.i420_to_bgr, raw[cuts[i]:cuts[i + 1]], H, W, dev)
+                         for i, ((_, ps), (_, cs)) in enumerate(zip(core.pools, core.lanes))]
+                return core(torch.cat([p.result() for p in parts]), mtx, rates)
+            pipe.compute = from_host
+            k = max(3, args.steps // 5)
+            dpc = timed(pipe, k, 1, host_i420)
+            pipe.compute = core
+            extras["pcie_inclusive"] = dict(value=round(F * k / dpc, 2), unit="frames/s", steps=k,
+                                            note="I420 frames in pinned host memory -> H2D -> ck_i420_to_bgr -> same path -> "
+                                                 "answers on the host; never the headline value")
+            del host_i420
+
+    sync()
+    # ---- per-kernel durations: HIP events on each context's own stream over a short SERIAL pass right after the timed
+    # region (with the paths overlapped, an event pair on one stream also counts the time other streams hold the CUs)
+    prof_steps = 2
+    out_line = None
+    if rank == 0:
+        handle = ctx.mog2_create(380, 380)
+        rates = np.full(F, 0.005)
         for c in (ctx, ctx_b):
             c.timing_enable(True)
             c.timing_reset()
         for _ in range(prof_steps):
-            step_serial()
+            ctx_b.board_detect(frames, cap=pipeline.LMAX, raw=True)
+            ctx.stones_run(frames, M, mog2=handle, learning_rates=rates)
         torch.cuda.synchronize()
-    if rank == 0:
-        stage_names = ["median", "canny_nms", "canny_hyst", "ccl", "contour_gather", "ghost", "hough_vote",
-                       "hough_peaks", "warp", "cnn_conv1", "cnn_conv2", "cnn_conv3", "cnn_conv4", "cnn_tail"]
+        names = ["median", "canny_nms", "canny_hyst", "ccl", "contour_gather", "ghost", "hough_vote", "hough_peaks",
+                 "warp", "mog2", "cnn_conv1", "cnn_conv2", "cnn_conv3", "cnn_conv4", "cnn_tail"]
         stages = {}
-        for nme in stage_names:
-            ms, cnt = ctx.timing_get(nme)
-            ms2, cnt2 = ctx_b.timing_get(nme)
-            ms, cnt = ms + ms2, cnt + cnt2
+        for nme in names:
+            ms, cnt = [a + b for a, b in zip(ctx.timing_get(nme), ctx_b.timing_get(nme))]
             if cnt:
                 stages[nme] = dict(ms_total=round(ms, 3), launches=cnt, us_per_frame=round(1e3 * ms / (prof_steps * F), 3))
-        ctx.timing_enable(False)
-        ctx_b.timing_enable(False)
-        pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.isfile(pmc_path) and (H, W) == (1080, 1920):
-            pmc = json.load(open(pmc_path))
-
-        def traffic_of(stage, frames_per_launch):
-            t = pmc.get(stage)
-            return None if not t else int(t["hbm_bytes_per_frame"] * frames_per_launch)
-        def valu_frac(stage):
-            """VALU issue-slot utilisation: wave-level VALU instructions (PMC SQ_INSTS_VALU, profiles/) x 4 cycles per
-            wave64 instruction on a SIMD16 / (1024 SIMDs x 2.4 GHz x kernel time)"""
-            t = pmc.get(stage)
-            if not t or "valu_wave_insts_per_frame" not in t:
-                return None
-            return round(t["valu_wave_insts_per_frame"] * 4.0 / (1024 * 2.4e9 * stages[stage]["us_per_frame"] * 1e-6), 4)
-        def mfma_busy_frac(stage, cycles_per_inst):
-            """share of the kernel time the matrix pipe is busy: MFMA instructions (PMC SQ_INSTS_MFMA) x their pipe cycles"""
-            t = pmc.get(stage)
-            if not t or not t.get("mfma_wave_insts_per_frame"):
-                return None
-            return round(t["mfma_wave_insts_per_frame"] * cycles_per_inst / (1024 * 2.4e9 * stages[stage]["us_per_frame"] * 1e-6), 4)
-
-        # split-precision mode: conv1 is fused into conv2 (its stage slot only times an empty scope)
-        fused_conv1 = args.cnn == "f16x2" and "cnn_conv1" in stages and stages["cnn_conv1"]["us_per_frame"] < 0.5
+        for c in (ctx, ctx_b):
+            c.timing_enable(False)
+        fused_conv1 = args.cnn == "f16x2" and stages.get("cnn_conv1", {}).get("us_per_frame", 1.0) < 0.5
         if fused_conv1:
-            del stages["cnn_conv1"]
+            del stages["cnn_conv1"]                       # conv1 runs inside conv2's staging in the default mode
         fused_conv34 = args.cnn == "f16x2" and "cnn_conv4" in stages and "cnn_conv3" not in stages
 
         def roof_of(stage):
-            per_launch_frames = prof_steps * F / stages[stage]["launches"]
+            per_launch = prof_steps * F / stages[stage]["launches"]           # frames per launch
             avg_s = stages[stage]["ms_total"] / stages[stage]["launches"] * 1e-3
             if stage in MACS:
-                # f16x2 executes three fp16 MFMAs per f32-equivalent MAC block: priced against the fp16 peak
-                f32_kernel = args.cnn == "fp32" or (args.cnn == "bf16" and stage == "cnn_conv1")     # bf16 mode keeps conv1 in f32
-                peak = MFMA_F32_PEAK_TF if f32_kernel else MFMA_BF16_PEAK_TF
-                mults = 1.0
-                if args.cnn == "f16x2":
-                    mults = 2.0 if stage == "cnn_conv1" else 3.0       # fp16 MFMAs executed per f32-equivalent product
-                macs = mults * MACS[stage]
-                r_note = None
+                f32_kernel = args.cnn == "fp32" or (args.cnn == "bf16" and stage == "cnn_conv1")
+                peak = MFMA_F32_PEAK_TF if f32_kernel else MFMA_F16_PEAK_TF
+                macs = MACS[stage]
                 if fused_conv1 and stage == "cnn_conv2":
-                    macs += 2.0 * MACS["cnn_conv1"]          # conv1 runs inside this kernel (two fp16 MFMAs per product)
-                    r_note = "conv1 is computed inside this kernel's staging; its algorithmic flops are included, the halo rows recomputed per block are not"
+                    macs += MACS["cnn_conv1"]
                 if fused_conv34 and stage == "cnn_conv4":
-                    macs += mults * MACS["cnn_conv3"]        # conv3 + conv4 of a patch run in one workgroup
-                    r_note = "conv3 and conv4 in one kernel (conv3's output stays in LDS); flops of both"
-                ach = 2.0 * macs * per_launch_frames / avg_s / 1e12
+                    macs += MACS["cnn_conv3"]
+                ach = 2.0 * macs * per_launch / avg_s / 1e12              # ALGORITHMIC flops, not executed MFMAs
                 r = dict(kernel=stage, bound="mfma", achieved=round(ach, 3), peak=peak, unit="TFLOP/s",
-                         frac=round(ach / peak, 5), traffic=traffic_of(stage, per_launch_frames))
-                if r_note:
-                    r["note"] = r_note
+                         frac=round(ach / peak, 5), traffic=None)
+                if args.cnn == "f16x2":
+                    mult = (3.0 * macs - (MACS["cnn_conv1"] if fused_conv1 and stage == "cnn_conv2" else 0.0)) / macs
+                    r["executed_mfma_frac"] = round(mult * ach / peak, 5)
+                    r["note"] = ("split precision: every f32-equivalent product is three fp16 MFMAs (two in conv1); `frac` prices "
+                                 "the ALGORITHMIC flops against the fp16 peak, executed_mfma_frac the instructions executed")
                 return r
-            bytes_per_frame = {"median": 2 * 3 * W * H, "canny_nms": 4 * W * H, "warp": 433200 + 3 * W * H,
-                               "ccl": 6 * W * H, "canny_hyst": 2 * W * H}.get(stage, 4 * W * H)
-            ach = bytes_per_frame * per_launch_frames / avg_s / 1e9
+            per_frame = {"median": 2 * 3 * W * H, "canny_nms": 4 * W * H, "warp": 433200 + 3 * W * H, "ccl": 6 * W * H,
+                         "canny_hyst": 2 * W * H, "mog2": 433200 + 1444}.get(stage, 4 * W * H)
+            ach = per_frame * per_launch / avg_s / 1e9
             r = dict(kernel=stage, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                     frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic_of(stage, per_launch_frames))
-            vf = valu_frac(stage)
-            if vf is not None:
-                r["valu_issue_frac"] = vf
-                mf = mfma_busy_frac(stage, 16.0)        # v_mfma_i32_16x16x64_i8: 4 passes of 4 cycles
-                if mf is not None:
-                    r["mfma_busy_frac"] = mf
-                    r["note"] = ("nominally HBM-bound (SURVEY 8d), in fact bound by instruction issue: the box sums run on the i8 "
-                                 "matrix cores (busy mfma_busy_frac of the kernel time), the rest on the vector ALUs (valu_issue_frac of "
-                                 "their issue slots, at the nominal 2.4 GHz); the two add up, a SIMD overlaps them only marginally")
-                else:
-                    r["note"] = ("nominally HBM-bound (SURVEY 8d), in fact bound by VALU instruction issue: "
-                                 "valu_issue_frac of the SIMDs' issue slots are busy")
+                     frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+                     algorithmic_bytes_per_launch=int(per_frame * per_launch), avg_launch_ms=round(avg_s * 1e3, 4))
+            if stage == "median":
+                r["note"] = ("nominally HBM-bound (SURVEY 8d: 2 x 3WH bytes per frame), in fact bound by instruction issue: per "
+                             "48x48 tile one 15x15 box count (30 i8 MFMAs + 84 VALU ops) per distinct median prefix; PMC traffic "
+                             "and issue-slot shares are in profiles/ (separate rocprofv3 --pmc runs), not measured by this run")
             return r
-        # roofline of the dominant kernel
-        dom = max(stages, key=lambda k: stages[k]["ms_total"]) if stages else None
-        roof = roof_of(dom) if dom is not None else None
-        # the dominant matrix-core kernel and the filter pass (K1; north_star quotes the HBM roofline on it) are
-        # always reported as well
-        conv_stages = [k for k in stages if k in MACS]
-        mfma_roof = roof_of(max(conv_stages, key=lambda k: stages[k]["ms_total"])) if conv_stages else None
-        filt = roof_of("median") if "median" in stages else None
-        out = {
+        dom = max(stages, key=lambda s: stages[s]["ms_total"])
+        conv = [s for s in stages if s in MACS]
+        filt_us = sum(stages[s]["us_per_frame"] for s in ("median", "canny_nms", "canny_hyst") if s in stages)
+        fused = FUSED_FILTER_BYTES(H, W) / (filt_us * 1e-6) / 1e9
+        out_line = {
             "metric": "frames/sec on 1920x1080 video + 19x19 stone-grid match % vs reference SGF",
-            "value": round(world * F * args.steps / dt, 2),
+            "value": round(n_total * args.steps / dt, 2),
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "u8+f32", "bf16": "u8+bf16", "f16x2": "u8+f16x2(f32 accumulate)"}[args.cnn], "data": "synthetic",
-            "config": {"workload": "%dx%d synthetic video, %d-frame batch per GPU, board detect (K1-K6) + "
-                                   "stones detect (K8,K10-K12), cnn %s" % (W, H, F, args.cnn),
-                       "frames_per_gpu": F, "height": H, "width": W, "parallelism": ("%d independent streams" % world) if args.streams else ("frames sharded x%d" % world),
-                       "lanes_per_gpu": len(lanes)},
-            "roofline": roof,
-            "mfma_kernel": mfma_roof,
-            "filter_pass": filt,
+            "config": {"workload": "%dx%d synthetic video (a filmed game with hands), %d-frame batch per GPU, FRAMES RESIDENT IN HBM "
+                                   "(rendered there before the timed region); per frame board detect K1-K6 + stones path K8, K9, "
+                                   "K10-K12 (cnn %s); records gathered and folded in order by the library's policy" % (W, H, F, args.cnn),
+                       "frames_per_gpu": F, "height": H, "width": W, "parallelism": "frames of one video dealt x%d" % world,
+                       "lanes_per_gpu": len(lanes), "batches_in_flight": 2},
+            "roofline": roof_of(dom),
+            "mfma_kernel": roof_of(max(conv, key=lambda s: stages[s]["ms_total"])) if conv else None,
+            "filter_pass": roof_of("median") if "median" in stages else None,
+            "filter_pass_fused": dict(bytes_per_frame=FUSED_FILTER_BYTES(H, W), us_per_frame=round(filt_us, 3),
+                                      achieved=round(fused, 2), unit="GB/s", frac=round(fused / HBM_PEAK_GBS, 5),
+                                      note="SURVEY 8d's fused floor (read the frame once, write the edge map) over median + NMS + hysteresis"),
             "stages": stages,
-            "stage_timing": "HIP events per context stream over %d serial steps after the timed region; the timed "
-                            "region overlaps the board and stones paths on two streams" % prof_steps,
-            "host_ms_per_step": {"pack_records": round(1e3 * host_s[0] / args.steps, 3),
-                                 "gather": round(1e3 * host_s[1] / args.steps, 3),
-                                 "ordered_fold": round(1e3 * host_s[2] / args.steps, 3),
-                                 "note": "rank 0; overlapped with the GPU work of the next batches"},
-            "lines_found_frame0": int(board[0]["n_lines"][0]),
-            "board_found_by_fold": pipe.board.mtx is not None,
-            "moves_recorded_by_fold": len(pipe.stones.controller.kifu.moves),
-            "move_sequence_ratio": round(__import__("difflib").SequenceMatcher(
-                a=["%s%d,%d" % m for m in true_moves],
-                b=["%s%d,%d" % (m.color, m.y, m.x) for m in pipe.stones.controller.kifu.moves[:len(true_moves)]]).ratio(), 4),
-            "stone_grid_match_pct": round(100.0 * float((labels.cpu().numpy() == truth).mean()), 3),
-            "cnn_weights": "trained on synthetic boards (camkifu_amd/data/keras.h5, Keras-1 HDF5 layout)" if os.path.isfile(GOLDEN_WEIGHTS)
-                           else "seeded random (labels meaningless)",
+            "stage_timing": "HIP events per context stream over %d serial steps after the timed region (256-frame launches); "
+                            "the timed region overlaps board and stones paths of two lanes on five streams" % prof_steps,
+            "host_ms_per_step": dict(host_ms, note="rank 0, overlapped with the GPU work of the next batch; fold = "
+                                                   "ck_boardfold_step + ck_policy_run over all %d records" % n_total),
+            "board_found_by_fold": board_found,
+            "cnn_weights": "trained on synthetic boards (%s, Keras-1 HDF5 layout)" % os.path.relpath(KERAS_MODEL_FILE, ROOT),
         }
+        out_line.update(quality)
+        out_line.update(extras)
+        if not args.no_extras:
+            # K1's cost follows the content: the bench scene, a textured frame, uniform noise (worst case)
+            import torch.nn.functional as TF
+            g = torch.Generator(device=dev)
+            g.manual_seed(7)
+            noise = torch.randint(0, 256, (8, H, W, 3), generator=g, device=dev, dtype=torch.uint8)
+            coarse = torch.rand((8, 3, H // 12 + 2, W // 12 + 2), generator=g, device=dev)
+            tex = (TF.interpolate(coarse, size=(H, W), mode="bilinear") * 255).permute(0, 2, 3, 1).contiguous().to(torch.uint8)
+            k1 = {}
+            for name, batch in (("bench_scene", frames[:8]), ("smooth_texture", tex), ("uniform_noise", noise)):
+                ctx.timing_enable(True)
+                ctx.timing_reset()
+                med = ctx.median15(batch)
+                ms, _ = ctx.timing_get("median")
+                ctx.timing_enable(False)
+                k1[name] = dict(us_per_frame=round(1e3 * ms / 8, 2), thresholds_per_tile=round(thresholds_per_tile(med), 2))
+            out_line["k1_content"] = k1
+            cv = cv2_crosscheck(ctx, frames, M)
+            out_line["cv2_version"] = cv.pop("cv2")
+            if cv:
+                out_line["cv2_crosscheck"] = cv
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(H, W, frames, corners, weights, args.cpu_frames)
-        print(json.dumps(out))
+            out_line["cpu_baseline"] = cpu_baseline(frames, M, weights, n_warm=2, n_frames=args.cpu_frames, reps=3)
+            out_line["cpu_baseline"]["cnn_torch_cpu"] = torch_cpu_cnn_fps(weights)
+        print(json.dumps(out_line))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

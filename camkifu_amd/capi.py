@@ -274,12 +274,18 @@ class Context:
         return out
 
     # ---- K8 ---------------------------------------------------------------------------------
-    def warp_perspective(self, bgr, M, dsize=380):
+    def warp_perspective(self, bgr, M, dsize=380, out=None):
+        """`out`: an (n, dsize, dsize, 3) uint8 array / tensor in the same memory space as `bgr` to write into"""
         n, h, w = self._shape(bgr, 3)
         p, sp, keep = _in(bgr)
         M = np.ascontiguousarray(M, np.float64).reshape(-1, 9)
         oshape = (dsize, dsize, 3) if len(bgr.shape) == 3 else (n, dsize, dsize, 3)
-        out, op, osp = self._out(bgr, oshape, np.uint8)
+        if out is None:
+            out, op, osp = self._out(bgr, oshape, np.uint8)
+        else:
+            assert tuple(out.shape) == oshape and (out.is_contiguous() if _is_torch(out) else out.flags.c_contiguous)
+            op, osp, _ = _in(out)
+            assert osp == sp, "out must live where the frames live"
         self._chk(lib().ck_warp_perspective(self._h, p, n, h, w, sp, M.ctypes.data_as(C.c_void_p), len(M),
                                             int(dsize), op, osp))
         return out

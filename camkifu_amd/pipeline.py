@@ -216,60 +216,108 @@ def learning_rates(first, n, bg_init_frames):
     return np.where(first + np.arange(n) < bg_init_frames, 0.01, 0.005)
 
 
+class GpuCore:
+    """The per-shard GPU work of one batch, spread over `lanes` = pairs of (board context, stones context).
+
+    Every context is a HIP stream with its own host thread (a context is single-threaded by contract), so the board
+    path (K1..K6) and the stones path (K8, K10..K12) of every lane are in flight together, like the reference's two
+    finder threads.  The background model (K9) is ONE stream of frames in order: the lanes warp their frames into
+    slices of one goban tensor, and a dedicated context runs the model over it batch after batch (world == 1); with
+    world > 1 the goban tensor is handed back for the pixel-sharded exchange instead."""
+
+    def __init__(self, lanes, bg_ctx=None, local_model=True):
+        from concurrent.futures import ThreadPoolExecutor
+        self.lanes = [(b if b is not None else s, s) for b, s in lanes]
+        self.pools = [(ThreadPoolExecutor(1), ThreadPoolExecutor(1)) for _ in self.lanes]
+        self.bg_ctx = bg_ctx if bg_ctx is not None else self.lanes[0][1]
+        self.bg_pool = ThreadPoolExecutor(1)                 # FIFO: batches go through the model in submission order
+        self.local_model, self._handle = local_model, None
+
+    @staticmethod
+    def _host(t):
+        return t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t)
+
+    def _cuts(self, n):
+        k = len(self.lanes)
+        return [round(i * n / k) for i in range(k + 1)]
+
+    def __call__(self, frames, mtx, rates):
+        n = len(frames)
+        if n == 0:
+            return ((np.zeros(0, capi.BOARD_DTYPE), np.zeros((0, LMAX, 2), np.float32)), np.zeros((0, 10, 10), np.uint8),
+                    np.zeros((0, 10, 10)), None, None)
+        cuts = self._cuts(n)
+        parts = [frames[cuts[i]:cuts[i + 1]] for i in range(len(self.lanes))]
+        board_f = [pb.submit(cb.board_detect, fr, -1, LMAX, True) if len(fr) else None
+                   for (pb, _), (cb, _), fr in zip(self.pools, self.lanes, parts)]
+        rl, rc, fg, gobans = np.zeros((n, 10, 10), np.uint8), np.zeros((n, 10, 10)), None, None
+        if mtx is not None:
+            on_gpu = hasattr(frames, "is_cuda") and frames.is_cuda
+            if on_gpu:
+                import torch
+                gobans = torch.empty((n, 380, 380, 3), dtype=torch.uint8, device=frames.device)
+            else:
+                gobans = np.empty((n, 380, 380, 3), np.uint8)
+
+            def stones(cs, fr, lo, hi):
+                view = gobans[lo:hi]
+                cs.warp_perspective(fr, mtx, out=view)
+                return view
+
+            def classify(cs, view):
+                lab, conf = cs.cnn_regions(view)
+                return self._host(lab), self._host(conf)
+            warp_f = [ps.submit(stones, cs, fr, cuts[i], cuts[i + 1]) if len(fr) else None
+                      for i, ((_, ps), (_, cs), fr) in enumerate(zip(self.pools, self.lanes, parts))]
+            views = [f.result() if f is not None else None for f in warp_f]
+            cnn_f = [ps.submit(classify, cs, v) if v is not None else None
+                     for (_, ps), (_, cs), v in zip(self.pools, self.lanes, views)]
+            if self.local_model:
+                fg_f = self.bg_pool.submit(self._model_run, gobans, rates)
+            for i, f in enumerate(cnn_f):
+                if f is not None:
+                    rl[cuts[i]:cuts[i + 1]], rc[cuts[i]:cuts[i + 1]] = f.result()
+            if self.local_model:
+                fg, gobans = self._host(fg_f.result()), None
+        res = [f.result() for f in board_f if f is not None]
+        board = (np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res]))
+        return board, rl, rc, fg, gobans
+
+    def _model_run(self, gobans, rates):
+        if self._handle is None:
+            self._handle = self.bg_ctx.mog2_create(380, 380)
+        return self.bg_ctx.mog2_band_run(self._handle, gobans, rates, last_band=True)
+
+
 class FastFilePipeline:
     """process_batch(my_frames, n_total): this rank's shard of a batch -> (on rank 0) the requests the fold emitted.
+    submit() / finish() split it so that the host part of batch k (records, collectives, fold) overlaps the GPU part
+    of batch k + 1; the transform a batch is warped with is the one known when it is submitted.
 
-    `compute(frames, mtx, learning_rates)` is the per-shard GPU core; by default ck_board_detect + ck_stones_run on
-    two contexts (= two HIP streams, two host threads, as the reference's two finder threads).  It returns
-    (board, region_label, region_conf, fgcount or None, gobans or None); `gobans` (device tensor n x 380 x 380 x 3) is
-    only needed when world > 1, for the pixel-sharded background model."""
+    `compute(frames, mtx, learning_rates)` is the per-shard GPU core (default: GpuCore over the given contexts).  It
+    returns (board, region_label, region_conf, fgcount or None, gobans or None); `gobans` (n x 380 x 380 x 3) is only
+    handed back when world > 1, for the pixel-sharded background model."""
 
     def __init__(self, h, w, controller, ctx=None, rank=0, world=1, device=None, compute=None, ctx_board=None,
-                 bg_init_frames=50, band_model=None):
+                 bg_init_frames=50, band_model=None, lanes=None, ctx_bg=None):
+        from concurrent.futures import ThreadPoolExecutor
         self.h, self.w = h, w
         self.rank, self.world = rank, world
         self.group = _Group(rank, world, device)
-        self.ctx, self.ctx_board = ctx, ctx_board
-        self._pool = None
-        self.compute = compute or self._gpu_compute
+        self.ctx = ctx if ctx is not None else (lanes[0][1] if lanes else None)
+        if compute is None:
+            compute = GpuCore(lanes or [(ctx_board, ctx)], bg_ctx=ctx_bg, local_model=(world == 1))
+        self.compute = compute
+        self._runner = ThreadPoolExecutor(1)
         self.board = BoardFold(h, w)
         self.stones = StonesFold(controller, bg_init_frames)
-        self.bg_init_frames, self.stone_frames = bg_init_frames, 0      # frames the stones path has seen (every rank counts)
+        self.bg_init_frames, self.stone_frames = bg_init_frames, 0      # frames the stones path has been given (every rank counts)
         self.mtx = None                                       # what every rank warps with (rank 0's fold, broadcast)
         self.frames_done = 0
-        self._mog2 = None
         self.band = band_rows(world)[rank]
         self.band_model = band_model                          # callable(gobans_band (n, rows, 380, 3), rates) -> counts (n, band, 19)
         self.errors = []
-
-    # ---- per-shard GPU core -----------------------------------------------------------------------------
-    def _gpu_compute(self, frames, mtx, rates):
-        bctx = self.ctx_board or self.ctx
-        if len(frames) == 0:
-            return (np.zeros(0, capi.BOARD_DTYPE), np.zeros((0, LMAX, 2), np.float32)), np.zeros((0, 10, 10), np.uint8), \
-                np.zeros((0, 10, 10)), None, None
-        if mtx is None:
-            board = bctx.board_detect(frames, cap=LMAX, raw=True)
-            return board, np.zeros((len(frames), 10, 10), np.uint8), np.zeros((len(frames), 10, 10)), None, None
-        fut = None
-        if self.ctx_board is not None:
-            if self._pool is None:
-                from concurrent.futures import ThreadPoolExecutor
-                self._pool = ThreadPoolExecutor(1)
-            fut = self._pool.submit(bctx.board_detect, frames, -1, LMAX, True)
-        gobans = None
-        if self.world == 1:
-            if self._mog2 is None:
-                self._mog2 = self.ctx.mog2_create(380, 380)
-            out = self.ctx.stones_run(frames, mtx, mog2=self._mog2, learning_rates=rates)
-            fg = out["fgcount"]
-        else:
-            gobans = self.ctx.warp_perspective(frames, mtx)
-            rl, rc = self.ctx.cnn_regions(gobans)
-            out, fg = dict(region_label=rl, region_conf=rc), None
-        board = fut.result() if fut is not None else bctx.board_detect(frames, cap=LMAX, raw=True)
-        as_np = lambda t: t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t)     # noqa: E731
-        return board, as_np(out["region_label"]), as_np(out["region_conf"]), (None if fg is None else as_np(fg)), gobans
+        self.host_seconds = dict(pack=0.0, collectives=0.0, fold=0.0)
 
     # ---- pixel-sharded background model (world > 1) -------------------------------------------------------
     def _band_counts(self, gobans, n_total, rates):
@@ -282,8 +330,8 @@ class FastFilePipeline:
             gobans = torch.zeros((0, 380, 380, 3), dtype=torch.uint8, device=self.group.device or "cpu")
         if not hasattr(gobans, "numel"):
             gobans = torch.from_numpy(np.ascontiguousarray(gobans))
-            if self.group.device is not None:
-                gobans = gobans.to(self.group.device)
+        if self.group.device is not None and gobans.device != torch.device(self.group.device):
+            gobans = gobans.to(self.group.device)                 # gloo rehearsal: collectives on host buffers
         lo, hi = px[self.rank]
         expect = [len(shard_indices(n_total, src, self.world)) * (hi - lo) * 380 * 3 for src in range(self.world)]
         parts = self.group.all_to_all_bands([gobans[:, a:b].contiguous() for a, b in px], expect)
@@ -307,21 +355,35 @@ class FastFilePipeline:
         return self.band_model
 
     # ---- one batch --------------------------------------------------------------------------------------
-    def process_batch(self, my_frames, n_total):
-        """my_frames: frames rank, rank + world, ... of the batch.  The transform used for the stones path is the one
-        known when the batch starts.  Returns the fold's per-frame request lists on rank 0, None elsewhere."""
+    def _guarded(self, frames, mtx, rates, n_mine):
+        try:
+            return self.compute(frames, mtx, rates), None
+        except Exception as why:                              # never leave the other ranks alone in a collective
+            blank = ((np.zeros(n_mine, capi.BOARD_DTYPE), np.zeros((n_mine, LMAX, 2), np.float32)),
+                     np.zeros((n_mine, 10, 10), np.uint8), np.zeros((n_mine, 10, 10)), None, None)
+            return blank, why
+
+    def submit(self, my_frames, n_total):
+        """start the GPU part of a batch (my_frames: frames rank, rank + world, ... of it) -> ticket for finish()"""
         mtx = self.mtx
         rates = learning_rates(self.stone_frames, n_total, self.bg_init_frames) if mtx is not None else np.zeros(n_total)
+        if mtx is not None:
+            self.stone_frames += n_total
         mine = shard_indices(n_total, self.rank, self.world)
-        failed = False
-        try:
-            board, rl, rc, fg, gobans = self.compute(my_frames, mtx, rates[mine])
-        except Exception as why:                              # never leave the other ranks alone in a collective
-            self.errors.append(why)
-            failed, fg, gobans = True, None, None
-            board = (np.zeros(len(mine), capi.BOARD_DTYPE), np.zeros((len(mine), LMAX, 2), np.float32))
-            rl, rc = np.zeros((len(mine), 10, 10), np.uint8), np.zeros((len(mine), 10, 10))
-        rec = pack_records(board, rl, rc, failed=failed)
+        rates_for_core = rates if self.world == 1 else rates[mine]
+        return self._runner.submit(self._guarded, my_frames, mtx, rates_for_core, len(mine)), mtx, rates, n_total
+
+    def finish(self, ticket):
+        """records, collectives, fold (rank 0), transform broadcast -> the fold's per-frame request lists on rank 0,
+        None elsewhere"""
+        import time
+        fut, mtx, rates, n_total = ticket
+        (board, rl, rc, fg, gobans), failure = fut.result()
+        if failure is not None:
+            self.errors.append(failure)
+        t0 = time.perf_counter()
+        rec = pack_records(board, rl, rc, failed=failure is not None)
+        t1 = time.perf_counter()
         if self.world == 1:
             full, counts = rec, fg
         else:
@@ -339,12 +401,14 @@ class FastFilePipeline:
                 slab[0, :, :mine_counts.shape[1]] = mine_counts
                 allc = self.group.all_gather_rows(slab, 1)[:, 0]                         # (world, n_total, widest, 19)
                 counts = np.concatenate([allc[r, :, :b - a] for r, (a, b) in enumerate(band_rows(self.world))], 1)
+        t2 = time.perf_counter()
         if (full["flags"] & FLAG_FAILED).any():
             raise RuntimeError("a rank failed in the GPU core of this batch: %s" % (self.errors[-1:] or "see its log"))
-        emitted = None
+        emitted, new = None, None
         if self.rank == 0:
             emitted = self.fold(full, counts, mtx is not None)
             new = self.board.mtx
+        t3 = time.perf_counter()
         if self.world > 1:
             wire = np.zeros(10)
             if self.rank == 0 and new is not None:
@@ -353,10 +417,16 @@ class FastFilePipeline:
             self.mtx = wire[1:].reshape(3, 3).copy() if wire[0] else None
         else:
             self.mtx = new
+        t4 = time.perf_counter()
+        hs = self.host_seconds
+        hs["pack"] += t1 - t0
+        hs["collectives"] += (t2 - t1) + (t4 - t3)
+        hs["fold"] += t3 - t2
         self.frames_done += n_total
-        if mtx is not None:
-            self.stone_frames += n_total
         return emitted
+
+    def process_batch(self, my_frames, n_total):
+        return self.finish(self.submit(my_frames, n_total))
 
     def fold(self, full, counts, have_mtx=True):
         """ordered replay of both finders on the gathered records of one batch (rank 0)"""

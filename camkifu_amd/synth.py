@@ -160,18 +160,22 @@ def video(nframes, h, w, seed=SEED, device="cpu", new_stone_every=5, noise=3.0):
     return torch.stack(frames), corners, grids, moves
 
 
-def film(nframes, h, w, seed=SEED, device="cpu", density=0.25, quiet=52, move_every=40, hand_frames=12, noise=3.0):
+def film(nframes, h, w, seed=SEED, device="cpu", density=0.25, quiet=52, move_every=40, hand_frames=12, noise=3.0,
+         select=None):
     """A fixed camera over a game in progress, with the players' hands: the position at the start holds random
     stones; after `quiet` frames a move is played every `move_every` frames -- a hand covers the point for
     `hand_frames` frames, and when it leaves the new stone is there.  That is what SfNeural's steady state needs to
     see a move (foreground agitation, then calm: sf_neural.py:72-154).
-    -> frames uint8 (n,h,w,3) tensor on `device`, corners, truth (n,19,19) uint8 = stones actually on the board in each
-    frame, moves [(color, r, c, frame at which the stone is first visible)]"""
+    `select`: frame numbers to render (a rank's shard of the film); the game is scripted for all `nframes` regardless.
+    -> frames uint8 (len(select) or n, h, w, 3) tensor on `device`, corners, truth (n,19,19) uint8 = stones actually on
+    the board in each frame, moves [(color, r, c, frame at which the stone is first visible)], hands (n,) bool"""
     rng = np.random.default_rng(seed)
     corners = random_corners(h, w, rng)
     stones = random_stones(rng, density)
-    frames = torch.empty((nframes, h, w, 3), dtype=torch.uint8, device=device)
+    wanted = {int(g): k for k, g in enumerate(range(nframes) if select is None else select)}
+    frames = torch.empty((len(wanted), h, w, 3), dtype=torch.uint8, device=device)
     truth = np.zeros((nframes, GSIZE, GSIZE), np.uint8)
+    hands = np.zeros(nframes, bool)
     moves, color, pending = [], B, None
     for f in range(nframes):
         k = f - quiet
@@ -191,9 +195,11 @@ def film(nframes, h, w, seed=SEED, device="cpu", density=0.25, quiet=52, move_ev
                 stones[pending[1], pending[2]] = pending[0]
                 moves.append(pending + (f,))
                 pending = None
-        frames[f] = render(h, w, stones, corners, seed=seed * 31 + f, noise=noise, device=device, hand=hand)
+        if f in wanted:
+            frames[wanted[f]] = render(h, w, stones, corners, seed=seed * 31 + f, noise=noise, device=device, hand=hand)
         truth[f] = stones
-    return frames, corners, truth, moves
+        hands[f] = hand is not None
+    return frames, corners, truth, moves, hands
 
 
 def cnn_weights(seed=SEED, as_torch=False, device="cpu"):

@@ -24,13 +24,27 @@ class OracleCtx:
             st = {-1: 1, -2: 2}.get(o["status"], 0)
             out.append(dict(status=st, n_contours=o["n_contours"], n_lines=max(o["status"], 0),
                             biggest_area=o["biggest_area"], lines=o["lines"]))
+        if raw:
+            from camkifu_amd import capi
+            res = np.zeros(len(out), capi.BOARD_DTYPE)
+            lines = np.zeros((len(out), cap, 2), np.float32)
+            for f, b in enumerate(out):
+                res[f] = (b["status"], b["n_contours"], b["n_lines"], 0, b["biggest_area"])
+                k = min(b["n_lines"], cap)
+                lines[f, :k] = b["lines"][:k]
+            return res, lines
         return out
 
-    def warp_perspective(self, frame, M, dsize=380):
+    def warp_perspective(self, frame, M, dsize=380, out=None):
         frame = np.asarray(frame)
         if frame.ndim == 4:
-            return np.stack([ora.warp_perspective(f, M, (dsize, dsize)) for f in frame])
-        return ora.warp_perspective(frame, M, (dsize, dsize))
+            res = np.stack([ora.warp_perspective(f, M, (dsize, dsize)) for f in frame])
+        else:
+            res = ora.warp_perspective(frame, M, (dsize, dsize))
+        if out is not None:
+            out[...] = res
+            return out
+        return res
 
     def mog2_create(self, h=380, w=380):
         k = len(self._mog)

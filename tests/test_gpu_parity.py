@@ -368,7 +368,7 @@ def test_fast_file_pipeline_on_gpu(ck, synth):
     from camkifu_amd.controller import ControllerHeadless
     from camkifu_amd.stone.nn_manager import NNManager
     from .stub_ctx import OracleCtx
-    frames, corners, truth, moves = synth.film(100, 480, 640, seed=8, quiet=8, move_every=30, hand_frames=12)
+    frames, corners, truth, moves, _hands = synth.film(100, 480, 640, seed=8, quiet=8, move_every=30, hand_frames=12)
     frames = frames.numpy()
     W = NNManager.init_net()
     ck.cnn_set_weights(W)
