@@ -9,8 +9,16 @@
  * varThreshold (Tb) 16, varThresholdGen (Tg) 9, backgroundRatio (TB) 0.9, varInit 15,
  * varMin 4, varMax 75, complexity reduction CT 0.05, no shadow detection.
  * float32 arithmetic, one model per pixel, modes kept sorted by weight.
- * "parity unpinned": restated from the published algorithm; the exact treatment of a
- * pruned mode (see PRUNE NOTE) follows the library's loop structure as recalled.
+ * "parity unpinned": the reference holds no MOG2 vector and OpenCV cannot be run here, so this is a
+ * restatement of the published algorithm -- Z. Zivkovic, "Improved adaptive Gaussian mixture model for
+ * background subtraction" (ICPR 2004) and Zivkovic & van der Heijden, "Efficient adaptive density estimation
+ * per image pixel ..." (PRL 2006), whose reference implementation OpenCV adopted as bgfg_gaussmix2.
+ * What is ASSUMED beyond the papers' equations (they define the update, not the bookkeeping) is marked
+ * ASSUMPTION below: (1) the order of the per-mode loop body (decay, match test on the first fitting mode only,
+ * sort by bubbling the matched mode up, prune); (2) the prune test `w < -prune` with prune = -alpha * CT sits at
+ * the END of the loop body and shortens the loop bound itself (see PRUNE NOTE); (3) a new mode replaces the
+ * weakest one when all five are in use.  tests/test_gpu_parity.py::test_cv2_live_crosscheck compares masks with
+ * the real library whenever a machine has it.
  */
 #include "ck_oracle.h"
 #include <stdlib.h>
@@ -111,9 +119,12 @@ void ora_mog2_apply(ora_mog2* m, const uint8_t* img, double learning_rate, uint8
                     }
                 }
             }
-            /* PRUNE NOTE: a mode whose decayed weight falls below -prune is dropped by
-             * shortening the loop bound; modes are sorted by weight so only trailing
-             * modes can be affected. */
+            /* PRUNE NOTE (ASSUMPTION 2).  Zivkovic's complexity-reduction prior subtracts alpha * CT from every
+             * weight (eq. 14 of the 2006 paper: w <- w + alpha (o - w) - alpha c_T) and discards a component whose
+             * weight becomes negative.  Here, as in his implementation, `prune` = -alpha * CT is already added to
+             * `weight` above, the test is weight < -prune (i.e. below +alpha * CT: the component could not survive
+             * the next subtraction), and discarding = zero weight + one fewer live mode; because `nmodes` is the
+             * bound of this very loop and the modes are sorted by weight, only trailing modes are ever cut. */
             if (weight < -prune) { weight = 0.f; nmodes--; }
             gw[mode - swap_count] = weight;
             totalWeight += weight;

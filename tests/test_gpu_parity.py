@@ -718,3 +718,103 @@ def test_split_precision_falls_back_when_fp16_overflows(ck, synth):
         ck.cnn_set_mode(capi.CK_CNN_DEFAULT)
         ck.cnn_set_weights(synth.cnn_weights())
     assert np.array_equal(y, y32) and np.array_equal(lab, l32) and np.array_equal(conf, c32)
+
+
+# ---------------------------------------------------------------- independent pins
+def _torch_fp64_classifier(W, gobans):
+    """the network of nn_manager.py:277-298 evaluated in float64 by torch on the box: 'valid' true convolutions
+    (Keras-1 on Theano flips the kernels), channels-last flatten, softmax -- no code shared with oracle/ora_cnn.c"""
+    import torch
+    import torch.nn.functional as F
+    w = {k: torch.from_numpy(np.ascontiguousarray(v)).double() for k, v in W.items()}
+    patches = []
+    for g in gobans:
+        for a in (0, 40, 80, 120, 160, 200, 240, 280, 320, 340):
+            for b in (0, 40, 80, 120, 160, 200, 240, 280, 320, 340):
+                patches.append(g[a:a + 40, b:b + 40])
+    x = torch.from_numpy(np.stack(patches)).double().permute(0, 3, 1, 2)
+
+    def conv(x, k, b):
+        return F.relu(F.conv2d(x, k.flip(0, 1).permute(3, 2, 0, 1), b))
+    x = conv(conv(x, w["c1w"], w["c1b"]), w["c2w"], w["c2b"])
+    x = F.max_pool2d(x, 2)
+    x = conv(conv(x, w["c3w"], w["c3b"]), w["c4w"], w["c4b"])
+    x = F.max_pool2d(x, 2).permute(0, 2, 3, 1).reshape(len(patches), -1)
+    y = torch.softmax(F.relu(x @ w["d1w"] + w["d1b"]) @ w["d2w"] + w["d2b"], 1)
+    return y.numpy().reshape(len(gobans), 100, 81)
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "fp32", "bf16"])
+def test_cnn_against_torch_fp64(ck, ora, synth, mode):
+    """K11 pinned without the oracle: the HIP classifier against a float64 torch evaluation of the same network
+    on the same gobans.  f32-accurate modes: softmax within 1e-4 and identical labels wherever float64's own
+    margin between the best two classes exceeds 1e-3; bf16: labels only, on the trained weights."""
+    from camkifu_amd import capi
+    from camkifu_amd.stone.nn_manager import NNManager
+    gobans = []
+    for seed in range(4):
+        sc = synth.scene(480, 640, seed=70 + seed, density=0.15 * seed)
+        gobans.append(ora.warp_perspective(sc["frame"].numpy(), ora.get_perspective_transform(sc["corners"],
+                      np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32))))
+    gobans = np.stack(gobans)
+    for W in ((NNManager.init_net(),) if mode == "bf16" else (NNManager.init_net(), synth.cnn_weights())):
+        ck.cnn_set_weights(W)
+        ck.cnn_set_mode({"f16x2": capi.CK_CNN_F16X2, "fp32": capi.CK_CNN_FP32, "bf16": capi.CK_CNN_BF16}[mode])
+        try:
+            y, labels, conf = ck.cnn_predict(gobans)
+            rl, rc = ck.cnn_regions(gobans)
+        finally:
+            ck.cnn_set_mode(capi.CK_CNN_DEFAULT)
+        y64 = _torch_fp64_classifier(W, gobans)
+        top2 = np.sort(y64, axis=2)[..., -2:]
+        clear = (top2[..., 1] - top2[..., 0]) > 1e-3
+        want = y64.argmax(2)
+        assert np.array_equal(rl.reshape(len(gobans), 100)[clear], want[clear])
+        if mode != "bf16":
+            assert np.abs(y - y64).max() <= 1e-4
+            assert np.abs(rc.reshape(len(gobans), 100) - y64.max(2) / y64.sum(2)).max() <= 1e-4
+
+
+def test_cv2_live_crosscheck(ck, ora, synth):
+    """Whenever a machine has OpenCV: the reference's exact call sequence (board/bf_auto.py:72-75, 125-133;
+    stone/stonesfinder.py:113-115, 140, 171-176) on synthetic scenes, and BOTH the HIP path and the oracle diffed
+    against it stage by stage.  This is the only route by which K1-K9 can be pinned against the library the
+    reference pins (src/ckmain.py:53); the build image and the GPU pool do not ship cv2, so the test usually skips."""
+    cv2 = pytest.importorskip("cv2")
+    import math
+    dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
+    report = {}
+    bg_cv = cv2.createBackgroundSubtractorMOG2(detectShadows=False)
+    bg_hip, bg_ora = ck.mog2_create(380, 380), ora.MOG2(380, 380, 3)
+    for k, (h, w) in enumerate([(480, 640), (480, 640), (1080, 1920)]):
+        sc = synth.scene(h, w, seed=400 + k, density=0.3)
+        fr = sc["frame"].numpy()
+        med = cv2.medianBlur(fr, 15)
+        report["median"] = int((med != ck.median15(fr)).sum()) + int((med != ora.median(fr, 15)).sum())
+        can = cv2.Canny(med, 25, 75)
+        report["canny"] = int((can != ck.canny(med)).sum()) + int((can != ora.canny(med, 25, 75)).sum())
+        contours = cv2.findContours(can.copy(), cv2.RETR_EXTERNAL, cv2.CHAIN_APPROX_SIMPLE)[-2]
+        areas = sorted((lambda b: b[1][0] * b[1][1])(cv2.minAreaRect(c)) for c in contours)
+        res, ghost_hip = ck.board_lines(can, want_ghost=True)
+        ref = ora.board_lines(can)
+        report["n_contours"] = abs(len(contours) - res[0]["n_contours"]) + abs(len(contours) - ref["n_contours"])
+        report["biggest_area"] = float(abs(areas[-1] - res[0]["biggest_area"]) + abs(areas[-1] - ref["biggest_area"]))
+        order = sorted(range(len(contours)), key=lambda i: (lambda b: b[1][0] * b[1][1])(cv2.minAreaRect(contours[i])))
+        ghost = np.zeros(can.shape, np.uint8)
+        for pos in order[-3:]:
+            cv2.drawContours(ghost, contours, pos, 255, thickness=1)
+        report["ghost"] = int((ghost != np.asarray(ghost_hip).reshape(can.shape)).sum())
+        lines = cv2.HoughLines(ghost, 1, math.pi / 180, threshold=int(min(h, w) / 5))
+        lines = np.zeros((0, 2), np.float32) if lines is None else lines.reshape(-1, 2)
+        report["hough"] = int(len(lines) != res[0]["n_lines"] or not np.array_equal(lines, res[0]["lines"][:len(lines)]))
+        M = cv2.getPerspectiveTransform(sc["corners"], dst)
+        report["transform"] = float(np.abs(M - ora.get_perspective_transform(sc["corners"], dst)).max())
+        warp = cv2.warpPerspective(fr, M, (380, 380))
+        report["warp"] = int((warp != ck.warp_perspective(fr, M)).sum()) + int((warp != ora.warp_perspective(fr, M)).sum())
+        for rate in (0.01, 0.005):
+            mask = bg_cv.apply(warp, learningRate=rate)
+            report["mog2"] = int((mask != ck.mog2_apply(bg_hip, warp, rate)).sum()) + int((mask != bg_ora.apply(warp, rate)).sum())
+        print("cv2 %s cross-check, scene %d:" % (cv2.__version__, k), report)
+        assert report["median"] == 0 and report["canny"] == 0 and report["n_contours"] == 0 and report["ghost"] == 0
+        assert report["hough"] == 0 and report["warp"] == 0 and report["mog2"] == 0
+        assert report["biggest_area"] <= 1e-3 and report["transform"] <= 1e-9
