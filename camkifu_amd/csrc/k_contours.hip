@@ -373,37 +373,48 @@ __global__ __launch_bounds__(256) void border_list_kernel(const uint8_t* __restr
         int p = 0, cslot = -1;
         if (i < ne) {
             p = E[i];
-            b = (!e[p - 1] && in_s0(L, p - 1, root0)) || (!e[p + 1] && in_s0(L, p + 1, root0)) ||
-                (!e[p - w] && in_s0(L, p - w, root0)) || (!e[p + w] && in_s0(L, p + w, root0));
+            // the four neighbours at once (three rounds of independent loads instead of up to twelve dependent ones behind
+            // short-circuit tests): edge byte, run head, head's root.  An edge neighbour looks up L[0], which is root0's own
+            // node and never counts because of the edge test.
+            const int q[4] = { p - 1, p + 1, p - w, p + w };
+            int ev[4], head[4], top[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) ev[k] = e[q[k]];
+#pragma unroll
+            for (int k = 0; k < 4; k++) head[k] = L[ev[k] ? 0 : q[k]];
+#pragma unroll
+            for (int k = 0; k < 4; k++) top[k] = L[head[k]];
+#pragma unroll
+            for (int k = 0; k < 4; k++) b |= !ev[k] && top[k] == root0;
             if (b) {
                 cslot = compid[off + L[p]];
                 if ((unsigned)cslot >= (unsigned)maxc) b = false;
             }
         }
-        // bounding boxes: neighbouring list entries usually belong to one component, so reduce
-        // inside the wave first and let one lane issue the four atomics
+        // bounding boxes: a wave's border pixels belong to one component or to a few; reduce per component inside the wave
+        // and let one lane update the box -- and only where the box actually grows (a relaxed read first: a stale value
+        // merely costs a redundant atomic, min / max are monotone), so the big contours stop hammering four addresses
         {
-            const unsigned long long bm = __builtin_amdgcn_ballot_w64(b);
-            if (bm) {
-                const int lead = __builtin_ctzll(bm);
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(b);
+            const int y = p / w, x = p - y * w;
+            const int lane = threadIdx.x & 63;
+            while (todo) {
+                const int lead = __builtin_ctzll(todo);
                 const int s_lead = __builtin_amdgcn_readlane(cslot, lead);
-                const int y = p / w, x = p - y * w;
-                if (__builtin_amdgcn_ballot_w64(b && cslot != s_lead) == 0) {
-                    int mnx = b ? x : 0x7fffffff, mxx = b ? x : -1, mny = b ? y : 0x7fffffff, mxy = b ? y : -1;
+                const bool mine = b && cslot == s_lead;
+                todo &= ~__builtin_amdgcn_ballot_w64(mine);
+                int mnx = mine ? x : 0x7fffffff, mxx = mine ? x : -1, mny = mine ? y : 0x7fffffff, mxy = mine ? y : -1;
 #pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) {
-                        mnx = min(mnx, __shfl_xor(mnx, d)); mxx = max(mxx, __shfl_xor(mxx, d));
-                        mny = min(mny, __shfl_xor(mny, d)); mxy = max(mxy, __shfl_xor(mxy, d));
-                    }
-                    if ((threadIdx.x & 63) == lead) {
-                        int32_t* bb = aabb + ((size_t)f * maxc + s_lead) * 4;
-                        atomicMin(bb + 0, mnx); atomicMax(bb + 1, mxx);
-                        atomicMin(bb + 2, mny); atomicMax(bb + 3, mxy);
-                    }
-                } else if (b) {
-                    int32_t* bb = aabb + ((size_t)f * maxc + cslot) * 4;
-                    atomicMin(bb + 0, x); atomicMax(bb + 1, x);
-                    atomicMin(bb + 2, y); atomicMax(bb + 3, y);
+                for (int d = 32; d >= 1; d >>= 1) {
+                    mnx = min(mnx, __shfl_xor(mnx, d)); mxx = max(mxx, __shfl_xor(mxx, d));
+                    mny = min(mny, __shfl_xor(mny, d)); mxy = max(mxy, __shfl_xor(mxy, d));
+                }
+                if (lane == lead) {
+                    int32_t* bb = aabb + ((size_t)f * maxc + s_lead) * 4;
+                    if (mnx < uf_load(bb, 0)) atomicMin(bb + 0, mnx);
+                    if (mxx > uf_load(bb, 1)) atomicMax(bb + 1, mxx);
+                    if (mny < uf_load(bb, 2)) atomicMin(bb + 2, mny);
+                    if (mxy > uf_load(bb, 3)) atomicMax(bb + 3, mxy);
                 }
             }
         }
