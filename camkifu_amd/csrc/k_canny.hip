@@ -191,7 +191,23 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
                                                                int* __restrict__ cand_count, uint8_t* __restrict__ edges_zero,
     const int* __restrict__ thr /* nullable: per-frame (low, high) pairs */)
 {
-    if (thr) { low = thr[2 * blockIdx.z]; high = thr[2 * blockIdx.z + 1]; }
+    // XCD-aware tile order.  Workgroups go round-robin over the 8 XCDs by their linear id, so with the plain (x, y, frame)
+    // mapping the eight horizontal neighbours of a tile row sit on eight different L2s and every halo line (a tile row
+    // touches three 64-B lines per plane for 64 useful bytes) is fetched from HBM by each of them.  Here XCD k owns the
+    // k-th contiguous eighth of the tile sequence instead: neighbours share an L2.  (Identity when the grid is no
+    // multiple of 8.)
+    int bxi = blockIdx.x, byi = blockIdx.y, f = blockIdx.z;
+    {
+        const unsigned G = gridDim.x * gridDim.y * gridDim.z;
+        if ((G & 7u) == 0) {
+            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            const unsigned t = (lin & 7u) * (G >> 3) + (lin >> 3);
+            bxi = (int)(t % gridDim.x);
+            byi = (int)((t / gridDim.x) % gridDim.y);
+            f = (int)(t / (gridDim.x * gridDim.y));
+        }
+    }
+    if (thr) { low = thr[2 * f]; high = thr[2 * f + 1]; }
     // pixel tile: columns ox-4 .. ox+67 (18 aligned dwords per row), rows oy-2 .. oy+PTH+1, border replicated.
     // The candidate buffer of the last phase reuses its space.
     constexpr int PXW = 3 * PLH * LWD, CBUF = PTH * TW;
@@ -202,8 +218,7 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
     __shared__ __attribute__((aligned(16))) int16_t gxy[2][PGR][PGW];       // dx, dy of the chosen channel; later the tile-local parents
     int16_t (*gdx)[PGW] = gxy[0], (*gdy)[PGW] = gxy[1];
     __shared__ int ccount, cbase;
-    const int f = blockIdx.z;
-    const int ox = blockIdx.x * TW, oy = blockIdx.y * PTH;
+    const int ox = bxi * TW, oy = byi * PTH;
     const int tid = threadIdx.x;
     const uint8_t* base = planes + (size_t)f * 3 * h * pitch;
     if (tid == 0) ccount = 0;

@@ -189,24 +189,31 @@ __global__ __launch_bounds__(ZTHREADS) void mog2_run_kernel(const uint8_t* __res
     __syncthreads();
     const int npx = h * w, px = y * w + x;
     Mix m;
-    float nxt[3] = { 0.f, 0.f, 0.f };
-    if (live) {
-        mix_load(m, gw_, gv_, mean_, nmodes_, npx, px);
-#pragma unroll
-        for (int c = 0; c < 3; c++) nxt[c] = (float)gobans[(size_t)px * 3 + c];
-    }
+    if (live) mix_load(m, gw_, gv_, mean_, nmodes_, npx, px);
     bool background = true;
-    for (int f = 0; f < nframes; f++) {
-        float data[3] = { nxt[0], nxt[1], nxt[2] };
-        if (live && f + 1 < nframes) {
-            const uint8_t* q = gobans + ((size_t)(f + 1) * npx + px) * 3;
+    // frames in groups of four: the twelve byte loads of a group are issued together (one round of memory latency per
+    // four updates instead of one per update), the updates then run back to back
+    constexpr int GRP = 4;
+    for (int f0 = 0; f0 < nframes; f0 += GRP) {
+        uint8_t raw[GRP][3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) nxt[c] = (float)q[c];
+        for (int j = 0; j < GRP; j++) {
+            const int f = f0 + j < nframes ? f0 + j : nframes - 1;
+            const uint8_t* q = gobans + ((size_t)f * npx + (live ? px : 0)) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) raw[j][c] = q[c];
         }
-        const float2 r = rates[f];
-        if (live) background = mix_update(m, data, r.x, r.y);
-        const unsigned long long fgmask = __ballot(counted && !background);
-        if ((t & 63) == 0 && fgmask) atomicAdd(&zcount[f], __popcll(fgmask));
+#pragma unroll
+        for (int j = 0; j < GRP; j++) {
+            const int f = f0 + j;
+            if (f < nframes) {                              // uniform across the workgroup
+                const float data[3] = { (float)raw[j][0], (float)raw[j][1], (float)raw[j][2] };
+                const float2 r = rates[f];
+                if (live) background = mix_update(m, data, r.x, r.y);
+                const unsigned long long fgmask = __ballot(counted && !background);
+                if ((t & 63) == 0 && fgmask) atomicAdd(&zcount[f], __popcll(fgmask));
+            }
+        }
     }
     if (live) {
         mix_store(m, gw_, gv_, mean_, nmodes_, npx, px);

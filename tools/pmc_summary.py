@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, optionally SQ_INSTS_VALU + SQ_INSTS_MFMA; separate runs, --kernel-trace only)
-into per-stage HBM traffic per frame, corrected as MI355X_MICROARCH.md prescribes for gfx950:
-FETCH_SIZE counts 128-B read requests at 64 B, so wide coalesced reads are doubled; WRITE_SIZE
-is exact; both are in KiB.  SQ_INSTS_VALU = wave-level VALU instructions (each costs one 4-cycle issue slot per SIMD).
+"""Turn the rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, optionally SQ_INSTS_VALU + SQ_INSTS_MFMA; separate runs,
+--kernel-trace only) into per-stage HBM traffic per frame.
+
+Units and the gfx950 correction, as MI355X_MICROARCH.md (HBM / rocprofv3 section) prescribes: both counters are KiB;
+WRITE_SIZE is exact; FETCH_SIZE reports exactly HALF of the bytes of a wide coalesced streaming read -- 16 B per lane --
+and only of those.  So the x2 is applied per kernel, only where the loads ARE 16 B per lane (column `wide_loads`):
+the classifier's weight-fragment / activation loads and the I420 converter; the median's byte loads, the NMS's and the
+row kernel's dword loads are left as counted.  Both the raw and the corrected figure are written, with the run they
+come from (frames per batch, lanes), so that nobody has to take the correction on trust.
 usage: pmc_summary.py <fetch_dir> <write_dir> <frames_per_batch> <out.json> [<valu_dir>]"""
 import collections
 import csv
@@ -10,11 +15,13 @@ import glob
 import json
 import sys
 
-STAGE = [("median15", "median", None), ("canny_nms", "canny_nms", None),
-         ("prep_rows", "ccl_prep_rows", None), ("hough_vote", "hough_vote", None),
-         ("warp_kernel", "warp", None),
-         ("conv1_", "cnn_conv1", 128), ("_kernel<36, 36, 32", "cnn_conv2", 128), ("conv34_h2_kernel", "cnn_conv4", 128),
-         ("_kernel<16, 16, 32", "cnn_conv3", 128), ("_kernel<14, 14, 9", "cnn_conv4", 128)]
+# (kernel-name substring, stage, frames per dispatch cap, loads are 16 B per lane)
+STAGE = [("median_mfma_kernel<15>", "median", None, False), ("canny_nms", "canny_nms", None, False),
+         ("prep_rows", "ccl_prep_rows", None, False), ("border_list", "ccl_border_list", None, False),
+         ("hough_vote", "hough_vote", None, False), ("warp_kernel", "warp", None, False),
+         ("mog2_run_kernel", "mog2", None, False),
+         ("conv_mfma16_h2_kernel", "cnn_conv2", 128, True), ("conv34_h2_kernel", "cnn_conv4", 128, True),
+         ("fc1_h2_kernel", "cnn_fc1", None, True)]
 
 
 def load(d, counter):
@@ -22,10 +29,11 @@ def load(d, counter):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
-            for key, stage, _ in STAGE:
+            for key, stage, _, _ in STAGE:
                 if key in r["Kernel_Name"]:
                     agg[stage][0] += 1
                     agg[stage][1] += float(r["Counter_Value"])
+                    break
     return agg
 
 
@@ -34,20 +42,22 @@ def main():
     valu = load(sys.argv[5], "SQ_INSTS_VALU") if len(sys.argv) > 5 else {}
     mfma = load(sys.argv[5], "SQ_INSTS_MFMA") if len(sys.argv) > 5 else {}
     frames = int(sys.argv[3])
-    out = {"_note": "KiB counters from rocprofv3 --pmc (separate passes); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
-                    "(gfx950 FETCH_SIZE halves wide coalesced reads); per frame of a %d-frame batch" % frames}
-    for key, stage, chunk in STAGE:
-        if stage not in fetch:
+    out = {"_source": "rocprofv3 --pmc, one pass per counter group, `bench.py --steps 1 --warmup 0 --frames %d --lanes 1 "
+                      "--no-cpu-baseline --no-extras` (tools/collect_profiles.sh); KiB counters; per frame" % frames,
+           "_correction": "hbm_bytes_raw = (FETCH_SIZE + WRITE_SIZE) * 1024; hbm_bytes_corrected doubles FETCH_SIZE only for "
+                          "kernels with wide_loads = true (16 B per lane), MI355X_MICROARCH.md"}
+    for key, stage, chunk, wide in STAGE:
+        if stage not in fetch or stage not in write:
             continue
-        per_dispatch_frames = min(chunk or frames, frames)
-        fk = fetch[stage][1] / fetch[stage][0] / per_dispatch_frames
-        wk = write[stage][1] / write[stage][0] / per_dispatch_frames
-        out[stage] = dict(fetch_kib_per_frame=round(fk, 1), write_kib_per_frame=round(wk, 1),
-                          hbm_bytes_per_frame=int((2 * fk + wk) * 1024), dispatches=fetch[stage][0])
+        per = min(chunk or frames, frames)
+        fk = fetch[stage][1] / fetch[stage][0] / per
+        wk = write[stage][1] / write[stage][0] / per
+        out[stage] = dict(fetch_kib_per_frame=round(fk, 1), write_kib_per_frame=round(wk, 1), wide_loads=wide,
+                          hbm_bytes_raw=int((fk + wk) * 1024), hbm_bytes_corrected=int(((2 if wide else 1) * fk + wk) * 1024),
+                          dispatches=fetch[stage][0])
         if stage in valu:
-            # SQ_INSTS_VALU includes the MFMA instructions: report the two separately
-            m = int(mfma[stage][1] / mfma[stage][0] / per_dispatch_frames) if stage in mfma else 0
-            out[stage]["valu_wave_insts_per_frame"] = int(valu[stage][1] / valu[stage][0] / per_dispatch_frames) - m
+            m = int(mfma[stage][1] / mfma[stage][0] / per) if stage in mfma else 0      # SQ_INSTS_VALU includes the MFMAs
+            out[stage]["valu_wave_insts_per_frame"] = int(valu[stage][1] / valu[stage][0] / per) - m
             out[stage]["mfma_wave_insts_per_frame"] = m
     json.dump(out, open(sys.argv[4], "w"), indent=1)
     print(json.dumps(out, indent=1))
