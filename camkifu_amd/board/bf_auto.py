@@ -34,10 +34,9 @@ class BoardFinderAuto(board_finder_base()):
     def _doframe(self, frame):
         idle = time.monotonic() - self.last_positive
         if idle > self.auto_refresh:
-            super()._doframe(frame)
-        else:
-            self.metadata["Last detection {}s ago"] = int(idle)
-            self._show(frame)
+            return super()._doframe(frame)
+        self.metadata["Last detection {}s ago"] = int(idle)
+        self._show(frame)
 
     def detect_core(self, frame):
         """the stateless half on the GPU -> dict(status, n_contours, n_lines, biggest_area, lines)"""
@@ -57,11 +56,12 @@ class BoardFinderAuto(board_finder_base()):
             self.metadata["Clusters : {}"].append(stats[0])
             self.metadata["Line intersections: {}"] = stats[1]
         if update:
-            self.corners.clear()
+            corners = self.corners
+            corners.clear()
             for p in centers:
-                self.corners.submit(p)
+                corners.submit(p)
         if self.total_f_processed % 4 == 0:
-            self.metadata["Board  : {}"] = "found" if found else "searching"
+            self.metadata["Board  : {}"] = ("searching", "found")[bool(found)]
             self._show(frame)
         if found:
             self.last_positive = time.monotonic()

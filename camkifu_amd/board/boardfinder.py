@@ -31,8 +31,8 @@ class GobanCorners:
     def is_ready(self):
         return bool(self.hull)
 
-    def submit(self, point):
-        p = np.asarray(point, np.int64)[:2]
+    def submit(self, candidate):
+        p = np.asarray(candidate, np.int64)[:2]
         if len(self._xy):
             d = np.sqrt(((self._xy - p) ** 2).sum(1).astype(np.float64))
             nearest = int(d.argmin())
@@ -45,7 +45,7 @@ class GobanCorners:
     def clear(self):
         self._xy, self.hull = np.zeros((0, 2), np.int64), None
 
-    def paint(self, img):
+    def paint(self, canvas):
         """display only: nothing to draw on in the headless build"""
 
     def _refresh(self):
@@ -67,11 +67,12 @@ class BoardFinder(VidProcessor):
         raise NotImplementedError("a board finder implements _detect(frame) -> bool")
 
     def _doframe(self, frame):
-        self.corners.frame = frame
+        corners = self.corners
+        corners.frame = frame
         if not self._detect(frame):
             return
         try:
-            self.mtx = capi.get_perspective_transform(np.asarray(self.corners.hull, np.float32), self.transform_dst)
+            self.mtx = capi.get_perspective_transform(np.asarray(corners.hull, np.float32), self.transform_dst)
         except (capi.CkError, ValueError, TypeError) as why:      # no usable quadrilateral: the stones finder must wait
             print("board located but not usable: %s" % why)
             self.mtx = None

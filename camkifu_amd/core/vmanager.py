@@ -86,7 +86,7 @@ class VManagerBase(Thread):
     def error_raised(self, finder, error):
         print("%s stops: %s in %s" % (type(self).__name__, type(error).__name__, type(finder).__name__))
         self.error = error
-        self.interrupt()
+        type(self).interrupt(self)
 
     def confirm_stop(self, finder):
         """a finder's loop has ended"""
@@ -111,7 +111,7 @@ class VManager(VManagerBase):
         self._over = Event()
 
     def run(self):
-        self.init_capt()
+        VManagerBase.init_capt(self)
         while not self._over.is_set():
             self._poll()
             self._over.wait(self.POLL_SECONDS)
@@ -122,8 +122,8 @@ class VManager(VManagerBase):
             return
         wanted = self.controller.video
         if wanted is not self.current_video and wanted != self.current_video:
-            self.stop_processing()
-            self.init_capt()
+            VManager.stop_processing(self)
+            VManagerBase.init_capt(self)
             self.board_finder = self.stones_finder = None
             self.controller.pipe("video_changed")
         if self.capt is not None:

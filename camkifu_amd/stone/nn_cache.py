@@ -24,16 +24,16 @@ class NNCache:
             self._regions = np.asarray(lab)[0], np.asarray(conf)[0]
         return self._regions
 
-    def predict_4_stones(self, i, j):
+    def predict_4_stones(self, ri, cj):
         lab, conf = self.regions()
-        return nm.SYMBOLS[nm.DIGITS[lab[i, j]]].reshape(nm.STEP, nm.STEP), float(conf[i, j])
+        return nm.SYMBOLS[nm.DIGITS[lab[ri, cj]]].reshape(nm.STEP, nm.STEP), float(conf[ri, cj])
 
-    def predict_stone(self, r, c):
-        # NB: the region is (r // 2, c // 2) and the entry 2 * (r % 2) + c % 2 of its four stones, which on row / column
+    def predict_stone(self, row, col):
+        # NB: the region is (row // 2, col // 2) and the entry 2 * (row % 2) + col % 2 of its four stones, which on row / column
         # 18 is the region's FIRST row / column -- the reference's arithmetic (nn_cache.py:16-23), kept as it is
         lab, conf = self.regions()
-        i, j = r // nm.STEP, c // nm.STEP
-        return nm.SYMBOLS[nm.DIGITS[lab[i, j], nm.STEP * (r % nm.STEP) + c % nm.STEP]], float(conf[i, j])
+        i, j = row // nm.STEP, col // nm.STEP
+        return nm.SYMBOLS[nm.DIGITS[lab[i, j], nm.STEP * (row % nm.STEP) + col % nm.STEP]], float(conf[i, j])
 
     def predict_all_stones(self):
         """(19, 19, 2) object array [colour, confidence]; regions are laid down in raster order, so on row / column

@@ -10,7 +10,7 @@ Tables (gsize 19, 10 x 10 regions of 2 x 2 intersections, the last region pulled
     PATCH_ORIGIN[i]  first pixel of region i's 40-pixel window     0, 40, ..., 320, 340
 """
 import os
-import threading
+from threading import RLock
 
 import numpy as np
 
@@ -40,15 +40,19 @@ class ModelMissing(FileNotFoundError):
     pass
 
 
+def _seeded_weights():
+    from .. import synth
+    return synth.cnn_weights()
+
+
 class NNManager:
-    _network = None                  # the weights, loaded once per process like the reference's lazily built model
-    _guard = threading.RLock()
+    _network, _guard = None, RLock()      # the weights, loaded once per process like the reference's lazily built model
 
     def __init__(self):
         self.canonical_shape = (cvconf.canonical_size,) * 2
         self.split, self.step, self.nb_classes = SPLIT, STEP, NB_CLASSES
         self.r_width = self.c_width = PATCH_SIDE
-        self.c_indices = None
+        self.c_indices = self._class_table = None
 
     # ---- model ---------------------------------------------------------------------------------
     @classmethod
@@ -58,7 +62,6 @@ class NNManager:
                 cls._network = cls.init_net()
             return cls._network
 
-    @staticmethod
     def init_net(download=False, allow_random=False):
         """the twelve weight arrays (Keras-1 'tf' layout) from KERAS_MODEL_FILE.  A missing file is an error -- a
         classifier with random weights reads garbage -- unless seeded random weights are asked for explicitly
@@ -66,59 +69,59 @@ class NNManager:
         if os.path.isfile(KERAS_MODEL_FILE):
             return NNManager.load_model(KERAS_MODEL_FILE)
         if allow_random:
-            return NNManager.create_net()
+            return _seeded_weights()
         raise ModelMissing("stone classifier model not found: %s (set CAMKIFU_KERAS_MODEL)" % KERAS_MODEL_FILE)
 
-    @staticmethod
     def load_model(path):
         from . import keras1
         return keras1.load_model(path)
 
-    @staticmethod
     def create_net():
         """the architecture of nn_manager.py:277-298 with seeded He-normal weights (untrained)"""
-        from .. import synth
-        return synth.cnn_weights()
+        return _seeded_weights()
+
+    init_net, load_model, create_net = staticmethod(init_net), staticmethod(load_model), staticmethod(create_net)
 
     # ---- geometry --------------------------------------------------------------------------------
-    def _subregion(self, i, j):
-        """(row start, row end, col start, col end) of region (i, j), ends exclusive"""
-        rs, cs = int(REGION_START[i]), int(REGION_START[j])
-        return rs, rs + STEP, cs, cs + STEP
+    def _subregion(self, ri, cj):
+        """(row start, row end, col start, col end) of region (ri, cj), ends exclusive"""
+        r0, c0 = int(REGION_START[ri]), int(REGION_START[cj])
+        return r0, r0 + STEP, c0, c0 + STEP
 
-    def get_region_indices(self, r, c):
-        return r // STEP, c // STEP
+    def get_region_indices(self, row, col):
+        return row // STEP, col // STEP
 
-    def getrect(self, r, c, re=0, ce=0):
-        """pixel box (x0, y0, x1, y1) of intersections r..re, c..ce (inclusive; 0 = just r / c) in the canonical image"""
-        last_r, last_c = (re if re > 0 else r), (ce if ce > 0 else c)
-        return r * CELL_PX, c * CELL_PX, (last_r + 1) * CELL_PX, (last_c + 1) * CELL_PX
+    def getrect(self, row, col, re=0, ce=0):
+        """pixel box (x0, y0, x1, y1) of intersections row..re, col..ce (inclusive; 0 = just row / col), canonical image"""
+        last_r, last_c = (re if re > 0 else row), (ce if ce > 0 else col)
+        return row * CELL_PX, col * CELL_PX, (last_r + 1) * CELL_PX, (last_c + 1) * CELL_PX
 
-    def _get_rect_nn(self, rs, re, cs, ce):
+    def _get_rect_nn(self, r0, r1, c0, c1):
         """(x0, x1, y0, y1) of the classifier's window for a block of intersections: always PATCH_SIDE wide,
         anchored at the block's far edge"""
-        x1, y1 = re * CELL_PX, ce * CELL_PX
+        x1, y1 = r1 * CELL_PX, c1 * CELL_PX
         return x1 - PATCH_SIDE, x1, y1 - PATCH_SIDE, y1
 
-    def _get_x(self, i, j, img):
-        a, b = int(PATCH_ORIGIN[i]), int(PATCH_ORIGIN[j])
-        return img[a:a + PATCH_SIDE, b:b + PATCH_SIDE]
+    def _get_x(self, ri, cj, image):
+        a, b = int(PATCH_ORIGIN[ri]), int(PATCH_ORIGIN[cj])
+        return image[a:a + PATCH_SIDE, b:b + PATCH_SIDE]
 
     # ---- codec -----------------------------------------------------------------------------------
-    @staticmethod
-    def compute_label(rs, re, cs, ce, stones):
-        block = np.asarray(stones)[rs:re, cs:ce].reshape(-1)
+    def compute_label(r0, r1, c0, c1, stones):
+        block = np.asarray(stones)[r0:r1, c0:c1].reshape(-1)
         return int(sum(CODE[s] * 3 ** k for k, s in enumerate(block)))
 
-    @staticmethod
     def compute_stones(label, dimension=STEP * STEP):
         if dimension == STEP * STEP:
             return SYMBOLS[DIGITS[int(label)]]
         return SYMBOLS[(int(label) // 3 ** np.arange(dimension)) % 3]
 
+    compute_label, compute_stones = staticmethod(compute_label), staticmethod(compute_stones)
+
     def class_indices(self):
         """[intersection k, colour, :] = the labels that put that colour on that intersection (27 each)"""
-        if self.c_indices is None:
+        table = self._class_table
+        if table is None:
             per_colour = [[np.flatnonzero(DIGITS[:, k] == col) for col in range(3)] for k in range(STEP * STEP)]
-            self.c_indices = np.array(per_colour, np.uint8)
-        return self.c_indices
+            table = self.c_indices = self._class_table = np.array(per_colour, np.uint8)
+        return table

@@ -50,9 +50,9 @@ class PosGrid:
             before[:, 0, 1] = -p[:, 0, 1]
             after[-1, :, 0] = 2 * self.size - p[-1, :, 0] - 2
             after[:, -1, 1] = 2 * self.size - p[:, -1, 1] - 2
-            w = cursor / 2
-            lo = np.maximum(0, (w * before + (1 - w) * p).astype(np.int64))  # astype truncates toward zero like int()
-            hi = np.minimum(self.size, ((1 - w) * p + w * after).astype(np.int64))
+            k = 0.5 * cursor
+            lo = np.maximum(0, (k * before + (1 - k) * p).astype(np.int64))  # astype truncates toward zero like int()
+            hi = np.minimum(self.size, ((1 - k) * p + k * after).astype(np.int64))
             hit = np.concatenate([lo, hi], -1)
             self._zones = {key: hit}
         return hit
@@ -95,7 +95,7 @@ class DeletionWatch:
         delta = self.saved_bg[x0:x1, y0:y1] - goban_img[x0:x1, y0:y1]
         if np.sum(np.absolute(delta)) / (delta.shape[0] * delta.shape[1]) < 40:
             raise DeletedError(((r, c),), "The zone has not changed enough since last deletion.")
-        print("previously user-deleted location: {} now unlocked".format((r, c)))
+        print("intersection %s looks different from when the user emptied it: unlocked" % ((r, c),))
         self.left[r, c] = -1
 
 
@@ -192,21 +192,20 @@ class StonesFinder(VidProcessor):
         return VidProcessor.ready_to_read(self) and getattr(bf, "mtx", None) is not None
 
     def _doframe(self, frame):
-        self.intersections = None
-        bf = self.vmanager.board_finder
+        bf, self.intersections = self.vmanager.board_finder, None
         mtx = None if bf is None else bf.mtx
         if mtx is None:
             return
-        self.goban_img = self.ctx.warp_perspective(frame, mtx, cvconf.canonical_size)           # K8
-        self._learn_bg()
-        self._learn()
-        self._find(self.goban_img)
+        goban = self.goban_img = self.ctx.warp_perspective(frame, mtx, cvconf.canonical_size)   # K8
+        for stage in (self._learn_bg, self._learn):
+            stage()
+        self._find(goban)
 
     def _find(self, goban_img):
         raise NotImplementedError("a stones finder implements _find(goban_img)")
 
     def _learn_bg(self):
-        if hasattr(self, "bg_model"):
+        if getattr(self, "bg_model", None) is not None:
             rate = 0.01 if self.total_f_processed < self.bg_init_frames else 0.005
             self._fg = self.ctx.mog2_apply(self.bg_model, self.goban_img, rate)                  # K9
 
@@ -215,8 +214,9 @@ class StonesFinder(VidProcessor):
 
     # ---- user corrections ------------------------------------------------------------------------
     def corrected(self, err_move, exp_move):
+        pending = self.corrections
         try:
-            self.corrections.put_nowait((err_move, exp_move))
+            pending.put_nowait((err_move, exp_move))
         except queue.Full:
             print("Corrections queue full (%s), ignoring %s -> %s" % (correc_size, err_move, exp_move))
 

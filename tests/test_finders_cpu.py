@@ -102,3 +102,63 @@ def test_kifu_checker_scoring(tmp_path):
         bad = Kifu()
         bad.append(Move(NP_TYPE, ('W', 3, 3)))
         KifuChecker(path, failfast=True).check(bad)
+
+
+def test_finders_take_the_host_applications_base_classes(tmp_path):
+    """camkifu_amd/host.py: when CamKifu is importable the drop-ins inherit ITS BoardFinder / StonesFinder (what
+    "drop into vmanager.py unchanged" means); here a stand-in package plays the host application"""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    pkg = tmp_path / "camkifu"
+    for sub in ("", "board", "stone"):
+        (pkg / sub).mkdir(exist_ok=True)
+        (pkg / sub / "__init__.py").write_text("")
+    (pkg / "board" / "boardfinder.py").write_text(textwrap.dedent("""
+        import collections
+        class Corners:
+            hull = None
+            frame = None
+            def __init__(self): self.pts = []
+            def clear(self): self.pts, self.hull = [], None
+            def submit(self, p):
+                self.pts.append(tuple(p))
+                if len(self.pts) == 4: self.hull = list(self.pts)
+        class BoardFinder:
+            HOST = True
+            def __init__(self, vmanager):
+                self.vmanager, self.total_f_processed, self.corners = vmanager, 0, Corners()
+                self.metadata, self.mtx, self.shown = collections.defaultdict(list), None, 0
+            def _show(self, *a, **k): self.shown += 1
+            def _doframe(self, frame): self.corners.frame = frame; self.hit = self._detect(frame)
+    """))
+    (pkg / "stone" / "stonesfinder.py").write_text(textwrap.dedent("""
+        class StonesFinder:
+            HOST = True
+            def __init__(self, vmanager, learn_bg=True):
+                self.vmanager, self.total_f_processed, self.bg_init_frames = vmanager, 0, 3
+    """))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import numpy as np
+        from camkifu_amd import host
+        from camkifu_amd.board.bf_auto import BoardFinderAuto
+        from camkifu_amd.stone.sf_neural import SfNeural
+        import camkifu.board.boardfinder as hb, camkifu.stone.stonesfinder as hs
+        assert host.in_host() and issubclass(BoardFinderAuto, hb.BoardFinder) and issubclass(SfNeural, hs.StonesFinder)
+        bf = BoardFinderAuto(object())
+        frame = np.zeros((480, 640, 3), np.uint8)
+        lines = np.array([[100, 0.05], [540, 0.08], [60, 1.55], [420, 1.62]], np.float32)
+        hit = bf._detect(frame, record=dict(status=0, n_lines=4, lines=lines))
+        assert hit and bf.corners.hull is not None and len(bf.corners.hull) == 4 and bf.shown == 1
+        class Ctx:
+            def cnn_set_weights(self, w): pass
+        sf = SfNeural(object(), ctx=Ctx())
+        assert sf.HOST and sf.policy is not None and sf.bg_init_frames == 3
+        print("host bases ok")
+    """)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), root]))
+    env.pop("CAMKIFU_AMD_STANDALONE", None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0 and "host bases ok" in out.stdout, out.stderr[-2000:]
