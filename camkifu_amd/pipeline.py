@@ -193,10 +193,12 @@ class StonesFold:
     def run(self, region_label, region_conf, fgcount):
         """-> per-frame lists of (kind, [(colour, r, c), ...]) requests, in frame order"""
         n = len(region_label)
-        out = [[] for _ in range(n)]
+        out = [()] * n                     # frames that emit nothing share one empty tuple (no per-frame allocation)
 
         def apply(kind, moves, k):
             named = [(_SYMBOL[col], r, c) for col, r, c in moves]
+            if not out[k]:
+                out[k] = []
             out[k].append((kind, named))
             from .core.exceptions import DeletedError
             try:
@@ -432,7 +434,7 @@ class FastFilePipeline:
         """ordered replay of both finders on the gathered records of one batch (rank 0)"""
         self.board.run(full)
         if not have_mtx:
-            return [[] for _ in range(len(full))]
+            return [()] * len(full)
         return self.stones.run(full["region_label"], full["region_conf"], counts)
 
     def process_y4m(self, capture, batch=256, file_fps=None, torch_device=None):

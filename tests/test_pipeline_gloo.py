@@ -139,7 +139,7 @@ def test_grid_of_regions_matches_the_oracle(ora):
     assert np.array_equal(grid[0], want_l) and np.array_equal(cgrid[0], want_c)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_multi_rank_fold_equals_single_process(world):
     ref = _drive(0, 1)
     assert ref[2] is not None                                  # the fold did find the board
@@ -166,3 +166,73 @@ def test_multi_rank_fold_equals_single_process(world):
         assert np.allclose(np.array(r[3]), np.array(ref[2]))   # every rank holds the broadcast transform
     for r in res[1:]:
         assert all(e is None for e in r[1])                    # only rank 0 folds
+
+
+# ---------------------------------------------------------------- host cost against the world size
+def _timed_rank(rank, world, port, q, per_rank, steps):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        n_total = per_rank * world
+        mine = pipeline.shard_indices(n_total, rank, world)
+        rng = np.random.default_rng(5)
+        sides = np.array([[100, 0.05], [540, 0.08], [60, 1.55], [420, 1.62]], np.float32)
+        lines = np.zeros((len(mine), pipeline.LMAX, 2), np.float32)
+        lines[:, :4] = sides
+        from camkifu_amd import capi
+        res = np.zeros(len(mine), capi.BOARD_DTYPE)
+        res["n_lines"] = 4
+        gob = np.zeros((len(mine), 380, 380, 3), np.uint8)
+        rl, rc = np.zeros((len(mine), 10, 10), np.uint8), np.full((len(mine), 10, 10), 0.9)
+        fg1 = np.zeros((n_total, 19, 19), np.int32)
+
+        def compute(frames, mtx, rates):                    # no GPU, no oracle: the host side is what is being timed
+            if mtx is None:
+                return (res, lines), rl, rc, None, None
+            return (res, lines), rl, rc, (fg1 if world == 1 else None), (gob if world > 1 else None)
+        pipe = pipeline.FastFilePipeline(H, W, ControllerHeadless(), rank=rank, world=world, compute=compute)
+        a, b = pipe.band
+        pipe.band_model = lambda band, rates: np.zeros((len(band), b - a, 19), np.int32)
+        for _ in range(2):
+            pipe.process_batch(None, n_total)                # board found, one stones batch
+        for k in pipe.host_seconds:
+            pipe.host_seconds[k] = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.process_batch(None, n_total)
+        wall = time.perf_counter() - t0
+        q.put((rank, {k: 1e3 * v / steps for k, v in pipe.host_seconds.items()}, 1e3 * wall / steps, n_total))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_rank0_host_cost_per_frame_does_not_grow_with_world(capsys):
+    """weak scaling rehearsal on CPU (gloo, fake GPU core, 32 frames per rank and step): rank 0 folds world x 32
+    records per step; what it spends per RECORD in pack + fold must not grow with the world (the fold is O(records) in
+    C++, Python is only entered for frames that emit), and the fold of a whole step stays in the low milliseconds"""
+    per_rank, steps, got = 32, 6, {}
+    for world in (1, 2, 8):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_timed_rank, args=(r, world, port, q, per_rank, steps)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=240) for _ in range(world))
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        got[world] = res[0]
+    with capsys.disabled():
+        for world, (_, phases, wall, n_total) in got.items():
+            print("\n  world %d: %4d records/step  pack %.3f ms  collectives %.3f ms  fold %.3f ms  (step %.2f ms, gloo on CPU)"
+                  % (world, n_total, phases["pack"], phases["collectives"], phases["fold"], wall), end="")
+    per_rec = {w: (got[w][1]["pack"] + got[w][1]["fold"]) / got[w][3] for w in got}
+    assert per_rec[8] <= 2.0 * per_rec[1] + 0.01, per_rec            # ms per record: flat (generous slack for a busy box)
+    assert got[8][1]["fold"] < 25.0                                    # 256 records folded in a few ms
