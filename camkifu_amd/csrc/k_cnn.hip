@@ -1570,6 +1570,11 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
     return CK_OK;
 }
 
+// Tuning knob (developer only): extra dynamic LDS requested by the two big classifier kernels.  Enough of it leaves ONE
+// workgroup per CU instead of two, i.e. room (registers, wave slots) for waves of the board path running on other streams.
+static int lds_pad_conv2() { static const int v = getenv("CK_CONV2_LDS_PAD") ? atoi(getenv("CK_CONV2_LDS_PAD")) : 0; return v; }
+static int lds_pad_conv34() { static const int v = getenv("CK_CONV34_LDS_PAD") ? atoi(getenv("CK_CONV34_LDS_PAD")) : 0; return v; }
+
 int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, uint8_t* d_labels, double* d_conf,
                   int* d_nonfinite, uint8_t* d_rlabel, double* d_rconf)
 {
@@ -1655,7 +1660,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             // 8x8 pooling tiles of 4x4 pixels: workgroups of whole tile rows, pooled output 16x16x32
             if (h2) {
 #if H2C2_SWZ
-                hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, 24, 3, 8, 2, true, H2C2S_PF, H2C2S_SB, true, H2_FUSE1 != 0>), dim3(np, 3), dim3(512), 0, ctx->stream,
+                hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, 24, 3, 8, 2, true, H2C2S_PF, H2C2S_SB, true, H2_FUSE1 != 0>), dim3(np, 3), dim3(512), (size_t)lds_pad_conv2(), ctx->stream,
                                    (const float*)a1, (const uint16_t*)W.c2w_h2.p, (const float*)W.c2b.p, p2, 1.f / H2_WSCALE, d_nonfinite,
                                    gob, (const uint16_t*)W.c1w_h2.p, (const float*)W.c1b.p);
 #else
@@ -1672,7 +1677,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         if (h2 && H2_FUSE34) {
             TimeScope ts(ctx, "cnn_conv4");
             // conv3 + conv4 of a patch in one workgroup; pooled 6x6x90 written directly
-            hipLaunchKernelGGL(conv34_h2_kernel, dim3(np), dim3(256), 0, ctx->stream, (const float*)p2, (const uint16_t*)W.c3w_h2.p,
+            hipLaunchKernelGGL(conv34_h2_kernel, dim3(np), dim3(256), (size_t)lds_pad_conv34(), ctx->stream, (const float*)p2, (const uint16_t*)W.c3w_h2.p,
                                (const float*)W.c3b.p, (const uint16_t*)W.c4w_h2.p, (const float*)W.c4b.p, p4, 1.f / H2_WSCALE, d_nonfinite);
         } else {
             {
