@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--streams", action="store_true",
+                    help="BASELINE config 5: every GPU processes its OWN video stream (its own game, camera and background "
+                         "model; seed + rank) -- no record gather, no band exchange; the default is ONE video dealt to the ranks")
     ap.add_argument("--lanes", type=int, default=2,
                     help="pairs of (board, stones) contexts per GPU; the batch is split between them so more "
                          "kernels are in flight and drain / host gaps of one lane are filled by the others")
@@ -190,10 +193,11 @@ def main():
     # ---- ONE synthetic game filmed by a fixed camera, world * F frames; this rank renders its frames into HBM -------
     # 52 quiet frames (the stones finder's background frames), then a move every 32 frames: a hand covers the point
     # for 12 frames, then the stone is there (synth.film).  Global frame g lives on rank g mod world.
-    n_total = world * F
-    mine = pipeline.shard_indices(n_total, rank, world)
-    frames, corners, truth, true_moves, hands = synth.film(n_total, H, W, seed=synth.SEED, device=dev, quiet=52,
-                                                           move_every=32, hand_frames=12, select=mine)
+    pw, pr = (1, 0) if args.streams else (world, rank)          # the pipeline's world: a stream is a world of its own
+    n_total = pw * F
+    mine = pipeline.shard_indices(n_total, pr, pw)
+    frames, corners, truth, true_moves, hands = synth.film(n_total, H, W, seed=synth.SEED + (rank if args.streams else 0),
+                                                           device=dev, quiet=52, move_every=32, hand_frames=12, select=mine)
     weights = NNManager.init_net()
     torch.cuda.synchronize()
     mode = {"fp32": capi.CK_CNN_FP32, "bf16": capi.CK_CNN_BF16, "f16x2": capi.CK_CNN_F16X2}[args.cnn]
@@ -203,7 +207,7 @@ def main():
     M_true = capi.get_perspective_transform(corners, np.array(DST, np.float32))
 
     def new_pipe():
-        return pipeline.FastFilePipeline(H, W, ControllerHeadless(), rank=rank, world=world, device=cdev,
+        return pipeline.FastFilePipeline(H, W, ControllerHeadless(), rank=pr, world=pw, device=cdev,
                                          lanes=lanes, ctx_bg=ctx_bg)
     pipe = new_pipe()
 
@@ -273,7 +277,7 @@ def main():
                 c.cnn_set_mode(capi.CK_CNN_FP32)
             k = max(3, args.steps // 5)
             d32 = timed(pipe, k, 2, frames)
-            extras["fp32_chain"] = dict(value=round(n_total * k / d32, 2), unit="frames/s", steps=k,
+            extras["fp32_chain"] = dict(value=round((world if args.streams else 1) * n_total * k / d32, 2), unit="frames/s", steps=k,
                                         note="same timed region with CK_CNN_FP32 (k-ordered f32 MFMA chain)")
             for _, c in lanes:
                 c.cnn_set_mode(mode)
@@ -284,12 +288,25 @@ def main():
             some = np.stack([synth.bgr_to_i420(frames[i].cpu().numpy()) for i in range(0, F, max(1, F // 8))])
             host_i420.numpy()[:] = some[np.arange(F) % len(some)]
             core = pipe.compute
+            landing = [torch.empty_like(frames), torch.empty_like(frames)]       # two batches in flight
+            turn = [0]
 
-            def from_host(raw, mtx, rates):
-                cuts = core._cuts(len(raw))
-                parts = [ps.submit(cs.i420_to_bgr, raw[cuts[i]:cuts[i + 1]], H, W, dev)
-                         for i, ((_, ps), (_, cs)) in enumerate(zip(core.pools, core.lanes))]
-                return core(torch.cat([p.result() for p in parts]), mtx, rates)
+            from concurrent.futures import ThreadPoolExecutor
+            uploaders = [(capi.Context(local_rank), ThreadPoolExecutor(1)) for _ in range(2)]   # their own streams + threads
+
+            class FromHost:
+                ticket = core.ticket
+
+                def __call__(self, raw, mtx, rates, seq=None):
+                    dst = landing[turn[0] % 2]
+                    turn[0] += 1
+                    half = len(raw) // 2
+                    parts = [pool.submit(c.i420_to_bgr, raw[a:b], H, W, None, dst[a:b])
+                             for (c, pool), (a, b) in zip(uploaders, ((0, half), (half, len(raw))))]
+                    for p in parts:
+                        p.result()
+                    return core(dst, mtx, rates, seq)
+            from_host = FromHost()
             pipe.compute = from_host
             k = max(3, args.steps // 5)
             dpc = timed(pipe, k, 1, host_i420)
@@ -297,7 +314,7 @@ def main():
             extras["pcie_inclusive"] = dict(value=round(F * k / dpc, 2), unit="frames/s", steps=k,
                                             note="I420 frames in pinned host memory -> H2D -> ck_i420_to_bgr -> same path -> "
                                                  "answers on the host; never the headline value")
-            del host_i420
+            del host_i420, landing
 
     sync()
     # ---- per-kernel durations: HIP events on each context's own stream over a short SERIAL pass right after the timed
@@ -365,7 +382,7 @@ def main():
         fused = FUSED_FILTER_BYTES(H, W) / (filt_us * 1e-6) / 1e9
         out_line = {
             "metric": "frames/sec on 1920x1080 video + 19x19 stone-grid match % vs reference SGF",
-            "value": round(n_total * args.steps / dt, 2),
+            "value": round((world if args.streams else 1) * n_total * args.steps / dt, 2),
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -374,7 +391,7 @@ def main():
             "config": {"workload": "%dx%d synthetic video (a filmed game with hands), %d-frame batch per GPU, FRAMES RESIDENT IN HBM "
                                    "(rendered there before the timed region); per frame board detect K1-K6 + stones path K8, K9, "
                                    "K10-K12 (cnn %s); records gathered and folded in order by the library's policy" % (W, H, F, args.cnn),
-                       "frames_per_gpu": F, "height": H, "width": W, "parallelism": "frames of one video dealt x%d" % world,
+                       "frames_per_gpu": F, "height": H, "width": W, "parallelism": ("%d independent streams, one per GPU" % world) if args.streams else ("frames of one video dealt x%d" % world),
                        "lanes_per_gpu": len(lanes), "batches_in_flight": 2},
             "roofline": roof_of(dom),
             "mfma_kernel": roof_of(max(conv, key=lambda s: stages[s]["ms_total"])) if conv else None,

@@ -254,17 +254,20 @@ class Context:
                 for f, r in enumerate(res)]
 
     # ---- frame source ------------------------------------------------------------------------
-    def i420_to_bgr(self, i420, h, w, to_device=None):
+    def i420_to_bgr(self, i420, h, w, to_device=None, out=None):
         """planar YUV 4:2:0 frames (n, h*w*3/2) or one flat frame -> BGR (n, h, w, 3) / (h, w, 3).
-        `to_device`: a torch device to leave the BGR frames in HBM even when the I420 bytes come from
-        host memory (the fast-file path uploads 1.5 B/px and converts on the GPU)."""
+        `to_device`: a torch device to leave the BGR frames in HBM even when the I420 bytes come from host memory (the
+        fast-file path uploads 1.5 B/px and converts on the GPU); `out`: a preallocated BGR tensor / array to fill."""
         fsz = h * w * 3 // 2
         single = len(i420.shape) == 1
         n = 1 if single else int(i420.shape[0])
         assert int(i420.shape[-1]) == fsz, (tuple(i420.shape), fsz)
         p, sp, keep = _in(i420)
         oshape = (h, w, 3) if single else (n, h, w, 3)
-        if to_device is not None and sp == CK_HOST:
+        if out is not None:
+            assert tuple(out.shape) == oshape
+            op, osp, _ = _in(out)
+        elif to_device is not None and sp == CK_HOST:
             import torch
             out = torch.empty(oshape, dtype=torch.uint8, device=to_device)
             op, osp = C.c_void_p(out.data_ptr()), CK_DEVICE

@@ -234,6 +234,15 @@ class GpuCore:
         self.bg_ctx = bg_ctx if bg_ctx is not None else self.lanes[0][1]
         self.bg_pool = ThreadPoolExecutor(1)                 # FIFO: batches go through the model in submission order
         self.local_model, self._handle = local_model, None
+        import threading
+        self._turn, self._issued, self._served = threading.Condition(), 0, 0
+
+    def ticket(self):
+        """call in batch order (FastFilePipeline.submit does): the background model sees the batches in that order even
+        when two of them are inside __call__ at once"""
+        with self._turn:
+            self._issued += 1
+            return self._issued - 1
 
     @staticmethod
     def _host(t):
@@ -243,7 +252,31 @@ class GpuCore:
         k = len(self.lanes)
         return [round(i * n / k) for i in range(k + 1)]
 
-    def __call__(self, frames, mtx, rates):
+    def _in_order(self, seq, fn):
+        if seq is None:
+            return fn()
+        with self._turn:
+            while self._served != seq:
+                self._turn.wait()
+            try:
+                return fn()
+            finally:
+                self._served += 1
+                self._turn.notify_all()
+
+    def __call__(self, frames, mtx, rates, seq=None):
+        turn = {"open": seq is not None}
+
+        def take_turn(fn):
+            turn["open"] = False
+            return self._in_order(seq, fn)
+        try:
+            return self._batch(frames, mtx, rates, take_turn)
+        finally:
+            if turn["open"]:                                 # failed (or had nothing for the model) before its turn:
+                self._in_order(seq, lambda: None)            # the batches behind must not wait for it forever
+
+    def _batch(self, frames, mtx, rates, take_turn):
         n = len(frames)
         if n == 0:
             return ((np.zeros(0, capi.BOARD_DTYPE), np.zeros((0, LMAX, 2), np.float32)), np.zeros((0, 10, 10), np.uint8),
@@ -275,7 +308,7 @@ class GpuCore:
             cnn_f = [ps.submit(classify, cs, v) if v is not None else None
                      for (_, ps), (_, cs), v in zip(self.pools, self.lanes, views)]
             if self.local_model:
-                fg_f = self.bg_pool.submit(self._model_run, gobans, rates)
+                fg_f = take_turn(lambda: self.bg_pool.submit(self._model_run, gobans, rates))
             for i, f in enumerate(cnn_f):
                 if f is not None:
                     rl[cuts[i]:cuts[i + 1]], rc[cuts[i]:cuts[i + 1]] = f.result()
@@ -310,7 +343,7 @@ class FastFilePipeline:
         if compute is None:
             compute = GpuCore(lanes or [(ctx_board, ctx)], bg_ctx=ctx_bg, local_model=(world == 1))
         self.compute = compute
-        self._runner = ThreadPoolExecutor(1)
+        self._runner = ThreadPoolExecutor(2)                  # two batches may be inside the GPU core at once
         self.board = BoardFold(h, w)
         self.stones = StonesFold(controller, bg_init_frames)
         self.bg_init_frames, self.stone_frames = bg_init_frames, 0      # frames the stones path has been given (every rank counts)
@@ -357,8 +390,10 @@ class FastFilePipeline:
         return self.band_model
 
     # ---- one batch --------------------------------------------------------------------------------------
-    def _guarded(self, frames, mtx, rates, n_mine):
+    def _guarded(self, frames, mtx, rates, n_mine, seq):
         try:
+            if seq is not None:
+                return self.compute(frames, mtx, rates, seq), None
             return self.compute(frames, mtx, rates), None
         except Exception as why:                              # never leave the other ranks alone in a collective
             blank = ((np.zeros(n_mine, capi.BOARD_DTYPE), np.zeros((n_mine, LMAX, 2), np.float32)),
@@ -373,7 +408,8 @@ class FastFilePipeline:
             self.stone_frames += n_total
         mine = shard_indices(n_total, self.rank, self.world)
         rates_for_core = rates if self.world == 1 else rates[mine]
-        return self._runner.submit(self._guarded, my_frames, mtx, rates_for_core, len(mine)), mtx, rates, n_total
+        seq = self.compute.ticket() if hasattr(self.compute, "ticket") else None
+        return self._runner.submit(self._guarded, my_frames, mtx, rates_for_core, len(mine), seq), mtx, rates, n_total
 
     def finish(self, ticket):
         """records, collectives, fold (rank 0), transform broadcast -> the fold's per-frame request lists on rank 0,
