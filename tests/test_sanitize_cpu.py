@@ -17,3 +17,4 @@ def test_host_geometry_and_oracle_are_clean_under_asan_ubsan():
         pytest.skip("sanitizer runtime not installed")
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "host geometry:" in res.stdout and "oracle: every routine clean" in res.stdout
+    assert "ordered halves:" in res.stdout and "clean" in res.stdout
