@@ -102,3 +102,36 @@ def test_stones_run_without_background_model(ck, ora):
     for f in range(3):
         assert again["labels"][f][16, 16] == again["region_label"][f][8, 8] % 3
         assert again["conf"][f][18, 18] == again["region_conf"][f][9, 9]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_band_models_equal_the_whole_image_model(ck, ora, world):
+    """the multi-GPU form of K9: the goban split into `world` bands of intersection rows, one model per band run over the
+    whole sequence (ck_mog2_band_run, host and device inputs) == the whole-image run of ck_stones_run, count for count"""
+    import torch
+    from camkifu_amd import pipeline
+    from camkifu_amd.stone.nn_manager import NNManager
+    ck.cnn_set_weights(NNManager.init_net())
+    n = 30
+    frames, corners = _clip(n, seed=21)
+    M = ora.get_perspective_transform(corners, DST)
+    lr = np.where(np.arange(n) < 10, 0.01, 0.005)
+    h = ck.mog2_create(380, 380)
+    whole = ck.stones_run(frames, M, mog2=h, learning_rates=lr)["fgcount"]
+    gobans = ck.warp_perspective(frames, M)
+    parts = []
+    for k, (a, b) in enumerate(pipeline.band_rows(world)):
+        lo, hi = 20 * a, min(20 * b, 380)
+        hb = ck.mog2_create(hi - lo, 380)
+        band = np.ascontiguousarray(gobans[:, lo:hi])
+        if k % 2:                                            # device-resident band, in two runs (state carries over)
+            t = torch.from_numpy(band).cuda()
+            got = torch.cat([ck.mog2_band_run(hb, t[:11], lr[:11], last_band=(b == 19)),
+                             ck.mog2_band_run(hb, t[11:], lr[11:], last_band=(b == 19))]).cpu().numpy()
+        else:
+            got = ck.mog2_band_run(hb, band, lr, last_band=(b == 19))
+        assert got.shape == (n, b - a, 19)
+        parts.append(got)
+        ck.mog2_destroy(hb)
+    assert np.array_equal(np.concatenate(parts, 1), whole) and whole.sum() > 0
+    ck.mog2_destroy(h)
