@@ -57,6 +57,10 @@ struct FrameTab {        // device-side per-frame counters
 #define CCL_LIST_BLOCKS 48
 #endif
 constexpr int LIST_BLOCKS = CCL_LIST_BLOCKS;          // grid-stride blocks per frame for the list kernels
+#ifndef CK_HOUGH_THREADS
+#define CK_HOUGH_THREADS 1024    // the theta slab fills a CU's LDS (one workgroup per CU): all the latency hiding comes from its own waves
+#endif
+constexpr int HOUGH_THREADS = CK_HOUGH_THREADS;
 
 // ---- A. frame clearing + parent initialisation + edge list -----------------------------
 // one wave per image row; walks the row in 64-pixel segments carrying the position of the
@@ -570,7 +574,7 @@ __global__ void hough_peaks_kernel(const int32_t* __restrict__ accum, int numrho
 // ---- H + I fused: the votes of rb theta rows (plus one halo row either side) as 16-bit counters packed two per
 // LDS dword, peaks found on the slab itself: the accumulator never exists in HBM.  A cell's count is at most the
 // number of ghost pixels on one discrete line (< w + h), so the halves cannot carry into each other.
-__global__ __launch_bounds__(256) void hough_vote_peaks_kernel(const uint32_t* __restrict__ hpts, FrameTab* __restrict__ tab,
+__global__ __launch_bounds__(HOUGH_THREADS) void hough_vote_peaks_kernel(const uint32_t* __restrict__ hpts, FrameTab* __restrict__ tab,
                                                                int pcap, const float* __restrict__ trig /* cos[180], sin[180] */,
                                                                int numrho, int rb, int threshold,
                                                                int32_t* __restrict__ peaks /* f*PEAK_CAP*2 */)
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(256) void hough_vote_peaks_kernel(const uint32_t* _
     const int stride = numrho + 2;                        // as the global accumulator had: a zero guard cell either side
     const int rowdw = (stride + 1) >> 1;                  // dwords per LDS row
     const int nrows = rb + 2;                             // LDS row j <-> theta row n0 - 1 + j
-    for (int i = threadIdx.x; i < nrows * rowdw; i += 256) slab16[i] = 0u;
+    for (int i = threadIdx.x; i < nrows * rowdw; i += HOUGH_THREADS) slab16[i] = 0u;
     __syncthreads();
     int npts = tab[f].n_hough_pts;
     if (npts > pcap) npts = pcap;
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(256) void hough_vote_peaks_kernel(const uint32_t* _
     const int j_lo = n0 == 0 ? 1 : 0;
     int j_hi = NUMANGLE - (n0 - 1);                       // exclusive: rows past theta 179 stay zero
     if (j_hi > nrows) j_hi = nrows;
-    for (int i = threadIdx.x; i < npts; i += 256) {
+    for (int i = threadIdx.x; i < npts; i += HOUGH_THREADS) {
         const uint32_t pk = P[i];
         const float xf = (float)(pk & 0xFFFF), yf = (float)(pk >> 16);
         for (int j = j_lo; j < j_hi; j++) {
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(256) void hough_vote_peaks_kernel(const uint32_t* _
         const int n = n0 + k;
         if (n >= NUMANGLE) break;
         const uint16_t* row = cnt + (k + 1) * rowhw;
-        for (int r = threadIdx.x; r < numrho; r += 256) {
+        for (int r = threadIdx.x; r < numrho; r += HOUGH_THREADS) {
             const int v = row[r + 1];
             if (v <= threshold) continue;
             if (v > row[r] && v >= row[r + 2] && v > row[r + 1 - rowhw] && v >= row[r + 1 + rowhw]) {
@@ -893,7 +897,7 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         if (rb < 1) return ck_fail(ctx, CK_ERR_ARG, "image too large for the Hough LDS slab");
         CK_HIP(ctx, hipFuncSetAttribute((const void*)hough_vote_peaks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)((rb + 2) * row_bytes)));
-        hipLaunchKernelGGL(hough_vote_peaks_kernel, dim3((NUMANGLE + rb - 1) / rb, n), dim3(256), (rb + 2) * row_bytes, ctx->stream,
+        hipLaunchKernelGGL(hough_vote_peaks_kernel, dim3((NUMANGLE + rb - 1) / rb, n), dim3(HOUGH_THREADS), (rb + 2) * row_bytes, ctx->stream,
                            (const uint32_t*)d_hpts, d_tab, pcap, (const float*)d_trig, numrho, rb, hough_thresh, d_peaks);
         CK_HIP(ctx, hipGetLastError());
     }
