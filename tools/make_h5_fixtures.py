@@ -76,7 +76,7 @@ def structures():
 
 def keras_model():
     W = np.load(os.path.join(ROOT, "tools", "out", "cnn_weights.npz"))
-    path = os.path.join(GOLD, "keras.h5")
+    path = os.path.join(ROOT, "camkifu_amd", "data", "keras.h5")          # the model ships inside the package
     layers = [("convolution2d_1", ["c1w", "c1b"]), ("convolution2d_2", ["c2w", "c2b"]), ("maxpooling2d_1", []),
               ("dropout_1", []), ("convolution2d_3", ["c3w", "c3b"]), ("convolution2d_4", ["c4w", "c4b"]),
               ("maxpooling2d_2", []), ("dropout_2", []), ("flatten_1", []), ("dense_1", ["d1w", "d1b"]),
