@@ -18,6 +18,7 @@ class ControllerHeadless:
         self.bounds = bounds
         self.kifu = Kifu()
         self.board = [[None] * gsize for _ in range(gsize)]      # board[x][y] -> Move
+        self._stones = np.full((gsize, gsize), E, dtype=object)  # the same goban in numpy coordinates, kept in step
         self.autosave_path = autosave_path
         self.ignored = set()
         self.api = {"append": self._append, "delete": self._delete, "bulk": self._bulk, "auto_save": self._auto_save}
@@ -37,13 +38,16 @@ class ControllerHeadless:
             self.last_captured = self.rules.put(move)          # raises StateError when illegal
             for _, cx, cy in self.last_captured:
                 self.board[cx][cy] = None                      # prisoners leave the goban, not the record
+                self._stones[cy, cx] = E
         self.board[move.x][move.y] = move
+        self._stones[move.y, move.x] = move.color
         self.kifu.append(move)
 
     def _delete(self, x, y):
         mv = self.board[x][y]
         if mv is not None:
             self.board[x][y] = None
+            self._stones[y, x] = E
             self.kifu.pop_at(x, y)
             if self.rules is not None:
                 self.rules.remove(x, y)
@@ -68,9 +72,4 @@ class ControllerHeadless:
 
     def get_stones(self):
         """copy of the goban in numpy coordinates: stones[r][c] in {'E','B','W'}"""
-        out = np.full((gsize, gsize), E, dtype=object)
-        for x in range(gsize):
-            for y in range(gsize):
-                if self.board[x][y] is not None:
-                    out[y, x] = self.board[x][y].color
-        return out
+        return self._stones.copy()
