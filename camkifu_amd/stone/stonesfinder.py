@@ -141,28 +141,35 @@ class StoneSink:
 
     def bulk_update(self, tuples):
         """several changes as ONE controller instruction: E empties, B / W places (recolouring = empty, then place;
-        an identical stone already there is skipped).  Vetoed places are left out and reported together afterwards."""
-        ctl, batch, refused = self.controller, [], []
+        an identical stone already there is skipped).  Vetoed places are left out and reported together afterwards.
+        The goban is looked at as it WILL be after the changes already scheduled in this call, so a point named twice
+        -- the regions of rows / columns 16-17 and 17-18 overlap and may both report it -- is sent once (or, if they
+        disagree, settled in favour of the later one) instead of reaching the controller as two stones on one point."""
+        ctl, batch, refused, scheduled = self.controller, [], [], {}
+
+        def colour_at(r, c):
+            if (r, c) in scheduled:
+                return scheduled[(r, c)]
+            return E if self.is_empty(r, c) else ctl.locate(c, r).color
         for color, r, c in tuples:
-            occupied = not self.is_empty(r, c)
+            now = colour_at(r, c)
             if color == E:
-                if occupied:
+                if now != E:
                     batch.append(Move(NP_TYPE, (E, r, c)))
+                    scheduled[(r, c)] = E
                 continue
-            if color not in (B, W):
+            if color not in (B, W) or now == color:
                 continue
-            if occupied and ctl.locate(c, r).color == color:
-                continue
+            if now != E:
+                batch.append(Move(NP_TYPE, (E, r, c)))               # the clearing half goes out even if the stone is vetoed
+                scheduled[(r, c)] = E
             try:
                 self._vet(r, c)
             except DeletedError as veto:
-                if occupied:
-                    batch.append(Move(NP_TYPE, (E, r, c)))           # the clearing half still goes out
                 refused.append(veto)
                 continue
-            if occupied:
-                batch.append(Move(NP_TYPE, (E, r, c)))
             batch.append(Move(NP_TYPE, (color, r, c)))
+            scheduled[(r, c)] = color
         if batch:
             ctl.pipe("bulk", batch)
             ctl.pipe("auto_save")

@@ -115,6 +115,10 @@ def test_sink_semantics():
     assert ctl.get_stones()[4, 4] == B and len(ctl.kifu.moves) == 2
     sink.bulk_update([(E, 3, 3)])
     assert ctl.get_stones()[3, 3] == E
+    # a point named twice in one call (overlapping regions): once if they agree, the later one if they do not
+    sink.bulk_update([(W, 17, 5), (W, 17, 5), (B, 17, 9), (W, 17, 9)])
+    assert ctl.get_stones()[17, 5] == W and ctl.get_stones()[17, 9] == W
+    assert [repr(m) for m in ctl.kifu.moves].count("W[F2]") == 1
     sink.suggest(W, 10, 10, doprint=False)
     assert ctl.get_stones()[10, 10] == W and np.array_equal(sink.board_codes()[10, 10], 2)
     with pytest.raises(AssertionError):

@@ -3,7 +3,7 @@
 a video (frames saved with np.save, or a synthetic clip) + a reference SGF -> move-sequence
 match ratio.  Runs the drop-in finders (BoardFinderAuto + SfNeural) on the HIP library.
 
-    python tools/detectiontest.py --synthetic 640x480 --frames 120
+    python tools/detectiontest.py --synthetic 640x480 --frames 200
     python tools/detectiontest.py -v clip.npy --sgf game.sgf [--bf BoardFinderAuto --sf SfNeural]
 """
 import argparse
@@ -26,22 +26,26 @@ def main():
     ap.add_argument("-v", "--video", help=".npy file holding (n,h,w,3) uint8 BGR frames")
     ap.add_argument("--sgf", help="reference SGF")
     ap.add_argument("--synthetic", default=None, help="WxH: render a clip and its reference game instead")
-    ap.add_argument("--frames", type=int, default=120)
+    ap.add_argument("--frames", type=int, default=200)
     ap.add_argument("--bf", default=None)
     ap.add_argument("--sf", default=None)
     ap.add_argument("--failfast", action="store_true")
     args = ap.parse_args()
     if args.synthetic:
+        # a filmed game: a position, then a move every 30 frames with the player's hand over the point first
+        # (synth.film); the reference game = that position in the order the first assessment reports it, then the moves
         w, h = map(int, args.synthetic.lower().split("x"))
-        rng = np.random.default_rng(synth.SEED)
-        corners = synth.random_corners(h, w, rng)
-        stones = synth.random_stones(rng, density=0.3)
-        frames = np.stack([synth.render(h, w, stones, corners, seed=synth.SEED + f).numpy() for f in range(args.frames)])
+        film, corners, truth, moves, hands = synth.film(args.frames, h, w, seed=synth.SEED, quiet=62, move_every=30,
+                                                         hand_frames=12)
+        frames = film.numpy()
         ref = Kifu()
-        for r in range(19):                       # reference = the position, in the order predict_all reports it
+        for r in range(19):
             for c in range(19):
-                if stones[r, c]:
-                    ref.append(Move(NP_TYPE, ("EBW"[stones[r, c]], r, c)))
+                if truth[0][r, c]:
+                    ref.append(Move(NP_TYPE, ("EBW"[truth[0][r, c]], r, c)))
+        for col, r, c, f in moves:
+            if f + 14 < args.frames:                    # the finder needs the stone to settle into the background
+                ref.append(Move(NP_TYPE, ("EBW"[col], r, c)))
         name = "synthetic-%dx%d" % (w, h)
     else:
         frames, ref, name = np.load(args.video, mmap_mode="r"), Kifu(sgffile=args.sgf), os.path.basename(args.video)
@@ -53,6 +57,9 @@ def main():
         raise vm.error
     matcher = KifuChecker(ref, failfast=args.failfast).check(ctrl.kifu)
     print(report(name, matcher, time.time() - t0))
+    got, want = set(matcher.b), set(matcher.a)
+    print("moves: %d recorded, %d of the %d reference moves among them, %d not in the reference"
+          % (len(matcher.b), len(got & want), len(want), len(got - want)))
     return matcher.ratio()
 
 
