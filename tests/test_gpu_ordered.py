@@ -135,3 +135,33 @@ def test_band_models_equal_the_whole_image_model(ck, ora, world):
         ck.mog2_destroy(hb)
     assert np.array_equal(np.concatenate(parts, 1), whole) and whole.sum() > 0
     ck.mog2_destroy(h)
+
+
+def test_ordered_entry_points_report_errors(ora):
+    """status codes, never exceptions across the boundary: missing weights, bad model handles, a learning rate that
+    would reset the model inside a run, single-frame and empty-ish calls"""
+    from camkifu_amd import capi
+    ctx = capi.Context(0)
+    try:
+        frames, corners = _clip(2, seed=1)
+        M = ora.get_perspective_transform(corners, DST)
+        with pytest.raises(capi.CkError, match="error 4"):                  # CK_ERR_STATE: no weights yet
+            ctx.stones_run(frames, M)
+        from camkifu_amd.stone.nn_manager import NNManager
+        ctx.cnn_set_weights(NNManager.init_net())
+        with pytest.raises(capi.CkError, match="error 1"):
+            ctx.stones_run(frames, M, mog2=7, learning_rates=[0.01, 0.01])  # no such model
+        h = ctx.mog2_create(380, 380)
+        with pytest.raises(capi.CkError, match="error 1"):
+            ctx.stones_run(frames, M, mog2=h, learning_rates=[0.01, 1.0])   # a reset inside a run is refused
+        one = ctx.stones_run(frames[:1], M, mog2=h, learning_rates=[0.01])
+        assert one["fgcount"].shape == (1, 19, 19) and one["region_label"].shape == (1, 10, 10)
+        small = ctx.mog2_create(40, 380)
+        with pytest.raises(capi.CkError, match="error 1"):
+            ctx.stones_run(frames, M, mog2=small, learning_rates=[0.01, 0.01])   # a band model is not a goban model
+        with pytest.raises(capi.CkError, match="error 1"):
+            ctx.mog2_band_run(99, np.zeros((1, 40, 380, 3), np.uint8), [0.01], last_band=False)
+        out = ctx.mog2_band_run(small, np.zeros((3, 40, 380, 3), np.uint8), [0.01] * 3, last_band=False)
+        assert out.shape == (3, 2, 19) and out[0].sum() == 40 * 379 and out[1:].sum() == 0     # first frame: all foreground
+    finally:
+        ctx.close()
