@@ -266,10 +266,27 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
     static_assert(K % 2 == 1 && K >= 3 && MT + K - 1 <= 64, "window size");
     constexpr int HK = K / 2, RANK = (K * K + 1) / 2;
     __shared__ uint32_t flags[3][64];
+    __shared__ uint32_t otile[MT * MT / 4];                    // the finished tile, for dword stores
     const int lane = threadIdx.x;
     const int n = lane & 15, g = lane >> 4;
-    const int ox = blockIdx.x * MT, oy = blockIdx.y * MT;
-    const int f = blockIdx.z / 3, c = blockIdx.z % 3;
+    // XCD-aware tile order (as in the NMS kernel): workgroups go round-robin over the 8 XCDs by linear id; XCD k takes the
+    // k-th contiguous eighth of the (x, y, plane) sequence, so horizontal neighbours share an L2 -- their halo columns are
+    // fetched once and the two halves of a 64-byte output line (tile rows are 48 bytes) meet in one L2 before write-back.
+    int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+    {
+        const unsigned G = gridDim.x * gridDim.y * gridDim.z;
+        if ((G & 7u) == 0) {
+            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            const unsigned t = (lin & 7u) * (G >> 3) + (lin >> 3);
+            // channel innermost: the three planes of a tile position read the same interleaved BGR lines
+            const unsigned pos = t / 3u;
+            bxi = (int)(pos % gridDim.x);
+            byi = (int)((pos / gridDim.x) % gridDim.y);
+            bzi = (int)(3u * (pos / (gridDim.x * gridDim.y)) + t % 3u);
+        }
+    }
+    const int ox = bxi * MT, oy = byi * MT;
+    const int f = bzi / 3, c = bzi % 3;
     const uint8_t* src = in + (size_t)f * h * w * 3 + c;
 
     // ---- load: column tile i, lane (n, g) <- column ox - K/2 + 16 i + n, rows oy - K/2 + 16 g + 0..15 (replicate border)
@@ -404,16 +421,27 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
     // ---- store: planar; lane (n, g) holds rows 16 t + 4 g + e of column 16 u + n
     uint8_t* plane = out + ((size_t)(f * 3 + c) * h) * pitch;
     if (ox + MT <= w && oy + MT <= h) {
-        uint8_t* base = plane + (size_t)oy * pitch + ox;
-        const uint32_t voff = (uint32_t)(4 * g * pitch + n);
+        // whole tile inside the image: through LDS, so that HBM sees dwords (12 per tile row) instead of byte stores --
+        // the byte form wrote 8.1 MB per 1080p frame for 6.2 MB of output (PMC WRITE_SIZE, partial-line writes)
+        uint8_t* tb = reinterpret_cast<uint8_t*>(otile);
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                uint8_t* row = base + (size_t)(16 * t + e) * pitch;
+            for (int e = 0; e < 4; e++)
 #pragma unroll
-                for (int u = 0; u < 3; u++) (row + 16 * u)[voff] = (uint8_t)med[t][u][e];
+                for (int u = 0; u < 3; u++) tb[(16 * t + 4 * g + e) * MT + 16 * u + n] = (uint8_t)med[t][u][e];
+        // one wave = the whole workgroup: its own LDS writes are visible to it after the counter wait
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 60) {                                        // 5 tile rows of 12 dwords per round, 10 rounds (48 rows)
+            const int r0 = lane / 12, c4 = lane % 12;
+            uint8_t* dst = plane + (size_t)(oy + r0) * pitch + ox + 4 * c4;
+#pragma unroll
+            for (int it = 0; it < 10; it++) {
+                if (5 * it + r0 < MT)
+                    *reinterpret_cast<uint32_t*>(dst + (size_t)(5 * it) * pitch) = otile[(5 * it + r0) * (MT / 4) + c4];
             }
+        }
     } else {
 #pragma unroll
         for (int u = 0; u < 3; u++) {
