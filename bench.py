@@ -24,6 +24,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# one hardware queue per HIP stream in flight (see camkifu_amd/__init__.py); must be in the environment before the HIP
+# runtime initialises, i.e. before the first torch.cuda call below
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3         # dense f32 MFMA
