@@ -322,6 +322,102 @@ def test_mog2_behaviour(ora):
     assert set(np.unique(fg)) <= {0, 255}
 
 
+def _mog2_reference(frames, rates):
+    """Zivkovic's adaptive mixture written out pixel by pixel in numpy float32 scalars (library defaults: 5 modes, Tb 16,
+    Tg 9, TB 0.9, initial variance 15 clipped to [4, 75], complexity reduction 0.05, no shadows) -- a second, structurally
+    different statement of K9 (lists of modes that are re-sorted, instead of in-place bubbling over fixed arrays)"""
+    f32 = np.float32
+    h, w = frames[0].shape[:2]
+    modes = [[[] for _ in range(w)] for _ in range(h)]           # each mode: [weight, variance, mean(3)]
+    masks = []
+    for t, (img, rate) in enumerate(zip(frames, rates)):
+        nframes = t + 1
+        lr = rate if (rate >= 0 and nframes > 1) else 1.0 / min(2 * nframes, 500)
+        alpha = f32(lr)
+        one_minus = f32(1.0) - alpha
+        prune = f32(-lr * f32(0.05))
+        mask = np.zeros((h, w), np.uint8)
+        for y in range(h):
+            for x in range(w):
+                px = img[y, x].astype(np.float32)
+                ms = modes[y][x]
+                background, fits, total = False, False, f32(0)
+                k = 0
+                while k < len(ms):
+                    wgt = one_minus * ms[k][0] + prune
+                    moved_to = k
+                    if not fits:
+                        var = ms[k][1]
+                        d = ms[k][2] - px
+                        dist2 = f32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]
+                        if total < f32(0.9) and dist2 < f32(16) * var:
+                            background = True
+                        if dist2 < f32(9) * var:
+                            fits = True
+                            wgt = wgt + alpha
+                            kk = alpha / wgt
+                            ms[k][2] = ms[k][2] - kk * d
+                            nv = var + kk * (dist2 - var)
+                            ms[k][1] = min(max(nv, f32(4)), f32(75))
+                            while moved_to > 0 and not (wgt < ms[moved_to - 1][0]):     # keep the modes sorted by weight
+                                ms[moved_to], ms[moved_to - 1] = ms[moved_to - 1], ms[moved_to]
+                                moved_to -= 1
+                    if wgt < -prune:
+                        wgt = f32(0)
+                        ms[moved_to][0] = wgt
+                        ms.pop()                                   # sorted: the mode that falls away is the last one
+                        if moved_to >= len(ms):
+                            continue
+                    else:
+                        ms[moved_to][0] = wgt
+                    total = total + wgt
+                    k += 1
+                inv = f32(1) / total if len(ms) else f32(0)
+                for m in ms:
+                    m[0] = m[0] * inv
+                if not fits and alpha > 0:
+                    if len(ms) == 5:
+                        ms.pop()
+                    if not ms:
+                        ms.append([f32(1), f32(15), px.copy()])
+                    else:
+                        for m in ms:
+                            m[0] = m[0] * one_minus
+                        ms.append([alpha, f32(15), px.copy()])
+                        j = len(ms) - 1
+                        while j > 0 and not (alpha < ms[j - 1][0]):
+                            ms[j], ms[j - 1] = ms[j - 1], ms[j]
+                            j -= 1
+                mask[y, x] = 0 if background else 255
+        masks.append(mask)
+    return masks
+
+
+def test_mog2_vs_numpy_restatement(ora):
+    """the C oracle against the list-of-modes numpy statement above, mask for mask, over a sequence with sensor noise, an
+    object that appears and stays (absorbed into the background), one that passes, and both learning rates"""
+    rng = np.random.default_rng(31)
+    h, w, n = 12, 14, 90
+    base = rng.integers(40, 200, (h, w, 3)).astype(np.int16)
+    frames, rates = [], []
+    for t in range(n):
+        fr = np.clip(base + rng.integers(-3, 4, base.shape), 0, 255).astype(np.uint8)
+        if t >= 30:
+            fr[2:6, 3:8] = np.clip(220 + rng.integers(-2, 3, (4, 5, 3)), 0, 255)       # a stone is put down and stays
+        if 50 <= t < 58:
+            fr[7:11, (t - 50):(t - 46)] = 15                                           # something dark passes
+        frames.append(fr)
+        rates.append(0.01 if t < 20 else 0.005)
+    want = _mog2_reference(frames, rates)
+    m = ora.MOG2(h, w, 3)
+    seen_fg = 0
+    for t in range(n):
+        got = m.apply(frames[t], rates[t])
+        assert np.array_equal(got, want[t]), t
+        seen_fg += int((got[2:6, 3:8] == 255).sum())
+    assert seen_fg > 0 and (want[-1][2:6, 3:8] == 0).all()                              # seen, then absorbed
+
+
 # ---------------------------------------------------------------- K10-K12
 def _weights(seed=20161001, scale1=1.0 / 128):
     rng = np.random.default_rng(seed)
