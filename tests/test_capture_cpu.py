@@ -180,9 +180,11 @@ def test_threaded_vmanager_lock_step_over_y4m(tmp_path, ora, monkeypatch):
         time.sleep(0.02)
     vm.interrupt()
     vm.join(timeout=5)
-    a, b = sorted((seen["RecB"], seen["RecS"]), key=len, reverse=True)
-    # every frame once, in order; the finder spawned first may have read a few frames alone, and a
-    # processor leaves its loop as soon as the capture position reaches bounds[1]
-    assert len(a) >= 6 and a == sorted(set(a)) and b == sorted(set(b))
-    i = a.index(b[0])
-    assert a[i:i + len(b)] == b and len(a) - (i + len(b)) <= 1
+    a, b = seen["RecB"], seen["RecS"]
+    # every frame at most once and in order for each finder; on the stretch both were reading they saw the SAME frames.
+    # The finder spawned first may read a frame or two alone before the other one is registered, and a finder leaves its
+    # loop as soon as the capture position reaches bounds[1], so either of them may miss the very last frame.
+    assert len(a) >= 6 and len(b) >= 6 and a == sorted(set(a)) and b == sorted(set(b))
+    lo, hi = max(a[0], b[0]), min(a[-1], b[-1])
+    assert [v for v in a if lo <= v <= hi] == [v for v in b if lo <= v <= hi]
+    assert sum(v < lo for v in a + b) <= 3 and sum(v > hi for v in a + b) <= 1
