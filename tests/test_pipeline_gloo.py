@@ -197,13 +197,16 @@ def _timed_rank(rank, world, port, q, per_rank, steps):
         pipe.band_model = lambda band, rates: np.zeros((len(band), b - a, 19), np.int32)
         for _ in range(2):
             pipe.process_batch(None, n_total)                # board found, one stones batch
-        for k in pipe.host_seconds:
-            pipe.host_seconds[k] = 0.0
-        t0 = time.perf_counter()
+        per_step, walls = [], []
         for _ in range(steps):
+            for k in pipe.host_seconds:
+                pipe.host_seconds[k] = 0.0
+            t0 = time.perf_counter()
             pipe.process_batch(None, n_total)
-        wall = time.perf_counter() - t0
-        q.put((rank, {k: 1e3 * v / steps for k, v in pipe.host_seconds.items()}, 1e3 * wall / steps, n_total))
+            walls.append(1e3 * (time.perf_counter() - t0))
+            per_step.append({k: 1e3 * v for k, v in pipe.host_seconds.items()})
+        med = {k: float(np.median([p[k] for p in per_step])) for k in per_step[0]}      # medians: a GC pause is not the fold
+        q.put((rank, med, float(np.median(walls)), n_total))
     finally:
         if world > 1:
             dist.destroy_process_group()
