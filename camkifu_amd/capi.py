@@ -27,6 +27,7 @@ EXPORTS = [
     "ck_mog2_create", "ck_mog2_apply", "ck_mog2_destroy",
     "ck_cnn_set_weights", "ck_cnn_set_mode", "ck_cnn_predict", "ck_stones_detect",
     "ck_cnn_regions", "ck_stones_run", "ck_zone_counts", "ck_mog2_band_run",
+    "ck_contour_stones", "ck_contours_external",
     "ck_ordered_hull", "ck_boardfold_create", "ck_boardfold_destroy", "ck_boardfold_reset", "ck_boardfold_step",
     "ck_policy_create", "ck_policy_destroy", "ck_policy_run", "ck_policy_get_state", "ck_policy_set_state",
     "ck_policy_watch",
@@ -400,6 +401,62 @@ class Context:
         out, op, osp = self._out(mask, (19, 19) if single else (n, 19, 19), np.int32)
         self._chk(lib().ck_zone_counts(self._h, p, n, sp, op, osp))
         return out
+
+    # ---- SfContours.find_stones -------------------------------------------------------------
+    def contour_stones(self, goban, fg, rects, rs=0, re=19, cs=0, ce=19, want_all=False):
+        """SfContours.find_stones (stone/sf_contours.py:48-111) for one goban image (side, side, 3) + its foreground mask
+        (side, side), or a batch (n, ...) of them, host or device; rects = (19, 19, 4) StonesFinder.getrect table.
+        -> stones uint8 (19, 19) / (n, 19, 19) of 0 E, 1 B, 2 W (and with want_all: zones int16 (.., re-rs, ce-cs, 4),
+        the hull mask uint8 (.., hs, ws) of the analysed view)"""
+        single = len(goban.shape) == 3
+        n = 1 if single else int(goban.shape[0])
+        side = int(goban.shape[-2])
+        if tuple(goban.shape[-3:]) != (side, side, 3) or tuple(fg.shape[-2:]) != (side, side) or len(fg.shape) != len(goban.shape) - 1:
+            raise ValueError("goban %r / foreground %r: expected (.., s, s, 3) and (.., s, s)" % (tuple(goban.shape), tuple(fg.shape)))
+        rects = np.ascontiguousarray(rects, np.int32).reshape(19, 19, 4)
+        p, sp, keep = _in(goban)
+        q, sq, keep2 = _in(fg)
+        if sp != sq:
+            raise ValueError("goban image and foreground mask must live in the same space (both host or both device)")
+        stones = np.zeros((n, 19, 19), np.uint8)
+        zones = mask = None
+        zp = mp = None
+        if want_all:
+            hs = int(rects[re - 1, ce - 1, 2] - rects[rs, cs, 0])
+            ws = int(rects[re - 1, ce - 1, 3] - rects[rs, cs, 1])
+            zones = np.zeros((n, re - rs, ce - cs, 4), np.int16)
+            mask = np.zeros((n, max(hs, 0), max(ws, 0)), np.uint8)
+            zp, mp = zones.ctypes.data_as(C.c_void_p), mask.ctypes.data_as(C.c_void_p)
+        self._chk(lib().ck_contour_stones(self._h, p, q, n, side, sp, rects.ctypes.data_as(C.c_void_p), int(rs), int(re), int(cs),
+                                          int(ce), stones.ctypes.data_as(C.c_void_p), zp, mp))
+        if single:
+            return (stones[0], zones[0], mask[0]) if want_all else stones[0]
+        return (stones, zones, mask) if want_all else stones
+
+    def contours_external(self, edges, want_points=False):
+        """cv2.findContours(edges, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) as SfContours reads it: for one (h, w) edge map or a
+        batch (n, h, w) -> per map a list of dicts {start: (x, y), nvert, pix: (k, 2) int32 or None} in cv2's order"""
+        single = len(edges.shape) == 2
+        n = 1 if single else int(edges.shape[0])
+        h, w = int(edges.shape[-2]), int(edges.shape[-1])
+        p, sp, keep = _in(edges)
+        cap = n * (h * w // 4 + 1)
+        counts = np.zeros(n, np.int32)
+        table = np.zeros((cap, 4), np.int32)
+        pts = np.zeros((n * h * w, 2), np.int32) if want_points else None
+        self._chk(lib().ck_contours_external(self._h, p, n, h, w, sp, counts.ctypes.data_as(C.c_void_p),
+                                             table.ctypes.data_as(C.c_void_p), cap,
+                                             pts.ctypes.data_as(C.c_void_p) if want_points else None, n * h * w))
+        out, k, o = [], 0, 0
+        for f in range(n):
+            lst = []
+            for _ in range(int(counts[f])):
+                x, y, nv, npx = (int(v) for v in table[k])
+                lst.append(dict(start=(x, y), nvert=nv, pix=pts[o:o + npx].copy() if want_points else None))
+                k += 1
+                o += npx
+            out.append(lst)
+        return out[0] if single else out
 
 
 def get_perspective_transform(src4, dst4):

@@ -97,6 +97,64 @@ int ck_timing_collect(ck_ctx* ctx)
     return CK_OK;
 }
 
+// OpenCV's getThreshVal_Otsu_8u restated (double arithmetic, the FLT_EPSILON guards, first maximum wins)
+static double otsu_level(const int* hist, size_t npx)
+{
+    double mu = 0, scale = 1. / (double)npx;
+    for (int i = 0; i < 256; i++) mu += i * (double)hist[i];
+    mu *= scale;
+    double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+    for (int i = 0; i < 256; i++) {
+        const double p_i = hist[i] * scale;
+        mu1 *= q1;
+        q1 += p_i;
+        const double q2 = 1. - q1;
+        if (std::min(q1, q2) < FLT_EPSILON || std::max(q1, q2) > 1. - FLT_EPSILON) continue;
+        mu1 = (mu1 + i * p_i) / q1;
+        const double mu2 = (mu - q1 * mu1) / q2;
+        const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+        if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+    }
+    return max_val;
+}
+
+// the device half of ck_goban_canny: interleaved BGR on the device -> edge maps on the device (one host round trip
+// for the Otsu levels of the batch).  Scratch: planes, out_stage, misc, map, labels, mats.
+int ck_goban_canny_dev(ck_ctx* ctx, const uint8_t* d_in, int n, int h, int w, uint8_t* d_edges, double* otsu_out)
+{
+    const size_t npx1 = (size_t)h * w, npx = (size_t)n * npx1;
+    const int pitch = ck_pitch(w);
+    CK_TRY(ck_ensure(ctx, ctx->planes, (size_t)n * 3 * h * pitch));
+    CK_TRY(ck_ensure(ctx, ctx->out_stage, npx * 3));
+    // medianBlur 13, then 7 (the kernel reads interleaved BGR and writes planes)
+    CK_TRY(k_median_planar(ctx, d_in, n, h, w, 13, (uint8_t*)ctx->planes.p, pitch));
+    CK_TRY(k_planar_to_interleaved(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, (uint8_t*)ctx->out_stage.p));
+    CK_TRY(k_median_planar(ctx, (const uint8_t*)ctx->out_stage.p, n, h, w, 7, (uint8_t*)ctx->planes.p, pitch));
+    // grey histogram per frame -> Otsu level on the host (256 bins, double arithmetic as the library does it)
+    CK_TRY(ck_ensure(ctx, ctx->misc, (size_t)n * 256 * 4 + (size_t)n * 64 + 4096));
+    int* d_hist = (int*)ctx->misc.p;
+    CK_TRY(k_gray_hist(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, d_hist));
+    std::vector<int> hist((size_t)n * 256);
+    CK_HIP(ctx, hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CK_TRY(ck_ensure(ctx, ctx->map, npx));
+    CK_TRY(ck_ensure(ctx, ctx->labels, npx * 4));
+    // cv2.Canny(median, otsu / 2, otsu): thresholds are floored (L1 gradient); one pair per frame, one batched call
+    std::vector<int> thr((size_t)n * 2);
+    for (int f = 0; f < n; f++) {
+        const double otsu = otsu_level(&hist[(size_t)f * 256], npx1);
+        if (otsu_out) otsu_out[f] = otsu;
+        thr[2 * f] = (int)std::floor(otsu / 2);
+        thr[2 * f + 1] = (int)std::floor(otsu);
+    }
+    CK_TRY(ck_ensure(ctx, ctx->mats, (size_t)n * 8 + 1024));
+    int* d_thr = (int*)ctx->mats.p;
+    CK_HIP(ctx, hipMemcpyAsync(d_thr, thr.data(), thr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));           // thr is a local: the copy must be done before it goes
+    return k_canny_planar(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, 0, 0, (uint8_t*)ctx->map.p,
+                          (int32_t*)ctx->labels.p, d_edges, nullptr, nullptr, d_thr);
+}
+
 extern "C" {
 
 int ck_version(void) { return 100; }
@@ -237,67 +295,17 @@ int ck_canny(ck_ctx* ctx, const uint8_t* img3, int n, int h, int w, int in_space
     return finish(ctx);
 }
 
-// OpenCV's getThreshVal_Otsu_8u restated (double arithmetic, the FLT_EPSILON guards, first maximum wins)
-static double otsu_level(const int* hist, size_t npx)
-{
-    double mu = 0, scale = 1. / (double)npx;
-    for (int i = 0; i < 256; i++) mu += i * (double)hist[i];
-    mu *= scale;
-    double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
-    for (int i = 0; i < 256; i++) {
-        const double p_i = hist[i] * scale;
-        mu1 *= q1;
-        q1 += p_i;
-        const double q2 = 1. - q1;
-        if (std::min(q1, q2) < FLT_EPSILON || std::max(q1, q2) > 1. - FLT_EPSILON) continue;
-        mu1 = (mu1 + i * p_i) / q1;
-        const double mu2 = (mu - q1 * mu1) / q2;
-        const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
-        if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
-    }
-    return max_val;
-}
-
 int ck_goban_canny(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space, uint8_t* edges, int out_space,
                    double* otsu_out)
 {
     CK_TRY(check_img(ctx, bgr, n, h, w));
     if (!edges) return ck_fail(ctx, CK_ERR_ARG, "edges is NULL");
-    const size_t npx1 = (size_t)h * w, npx = (size_t)n * npx1;
-    const int pitch = ck_pitch(w);
+    const size_t npx = (size_t)n * h * w;
     const void* d_in;
     CK_TRY(ck_to_device(ctx, bgr, npx * 3, in_space, ctx->in_stage, &d_in));
-    CK_TRY(ck_ensure(ctx, ctx->planes, (size_t)n * 3 * h * pitch));
-    CK_TRY(ck_ensure(ctx, ctx->out_stage, npx * 3));
-    // medianBlur 13, then 7 (the kernel reads interleaved BGR and writes planes)
-    CK_TRY(k_median_planar(ctx, (const uint8_t*)d_in, n, h, w, 13, (uint8_t*)ctx->planes.p, pitch));
-    CK_TRY(k_planar_to_interleaved(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, (uint8_t*)ctx->out_stage.p));
-    CK_TRY(k_median_planar(ctx, (const uint8_t*)ctx->out_stage.p, n, h, w, 7, (uint8_t*)ctx->planes.p, pitch));
-    // grey histogram per frame -> Otsu level on the host (256 bins, double arithmetic as the library does it)
-    CK_TRY(ck_ensure(ctx, ctx->misc, (size_t)n * 256 * 4 + (size_t)n * 64 + 4096));
-    int* d_hist = (int*)ctx->misc.p;
-    CK_TRY(k_gray_hist(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, d_hist));
-    std::vector<int> hist((size_t)n * 256);
-    CK_HIP(ctx, hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    CK_TRY(ck_ensure(ctx, ctx->map, npx));
-    CK_TRY(ck_ensure(ctx, ctx->labels, npx * 4));
     uint8_t* d_edges = edges;
     if (out_space == CK_HOST) { CK_TRY(ck_ensure(ctx, ctx->edges, npx)); d_edges = (uint8_t*)ctx->edges.p; }
-    // cv2.Canny(median, otsu / 2, otsu): thresholds are floored (L1 gradient); one pair per frame, one batched call
-    std::vector<int> thr((size_t)n * 2);
-    for (int f = 0; f < n; f++) {
-        const double otsu = otsu_level(&hist[(size_t)f * 256], npx1);
-        if (otsu_out) otsu_out[f] = otsu;
-        thr[2 * f] = (int)std::floor(otsu / 2);
-        thr[2 * f + 1] = (int)std::floor(otsu);
-    }
-    CK_TRY(ck_ensure(ctx, ctx->mats, (size_t)n * 8 + 1024));
-    int* d_thr = (int*)ctx->mats.p;
-    CK_HIP(ctx, hipMemcpyAsync(d_thr, thr.data(), thr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));           // thr is a local: the copy must be done before it goes
-    CK_TRY(k_canny_planar(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, 0, 0, (uint8_t*)ctx->map.p,
-                          (int32_t*)ctx->labels.p, d_edges, nullptr, nullptr, d_thr));
+    CK_TRY(ck_goban_canny_dev(ctx, (const uint8_t*)d_in, n, h, w, d_edges, otsu_out));
     if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, edges, d_edges, npx, CK_HOST));
     return finish(ctx);
 }
@@ -584,6 +592,50 @@ int ck_zone_counts(ck_ctx* ctx, const uint8_t* mask, int n, int in_space, int32_
     if (out_space == CK_HOST) { CK_TRY(ck_ensure(ctx, ctx->fgcbuf, (size_t)n * 361 * sizeof(int32_t))); d_cnt = (int32_t*)ctx->fgcbuf.p; }
     CK_TRY(k_zone_counts(ctx, (const uint8_t*)d_in, n, 380, d_cnt));
     if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, counts, d_cnt, (size_t)n * 361 * sizeof(int32_t), CK_HOST));
+    return finish(ctx);
+}
+
+int ck_contour_stones(ck_ctx* ctx, const uint8_t* goban, const uint8_t* fg, int n, int side, int in_space, const int32_t* rects,
+                      int rs, int re, int cs, int ce, uint8_t* stones, int16_t* zones, uint8_t* mask)
+{
+    if (!ctx) return CK_ERR_ARG;
+    if (!goban || !fg || !rects || !stones || n <= 0) return ck_fail(ctx, CK_ERR_ARG, "NULL argument or n <= 0");
+    if (side < 19 * 4 || side > 4096) return ck_fail(ctx, CK_ERR_ARG, "goban image side %d", side);
+    if (rs < 0 || cs < 0 || re > 19 || ce > 19 || re <= rs || ce <= cs)
+        return ck_fail(ctx, CK_ERR_ARG, "intersection range rows [%d, %d) columns [%d, %d)", rs, re, cs, ce);
+    CK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)n * side * side;
+    const void *d_img, *d_fg;
+    CK_TRY(ck_to_device(ctx, goban, px * 3, in_space, ctx->in_stage, &d_img));
+    CK_TRY(ck_to_device(ctx, fg, px, in_space, ctx->in_stage2, &d_fg));
+    CK_TRY(k_contour_stones(ctx, (const uint8_t*)d_img, (const uint8_t*)d_fg, n, side, rects, rs, re, cs, ce, stones, zones, mask));
+    return finish(ctx);
+}
+
+int ck_contours_external(ck_ctx* ctx, const uint8_t* edges, int n, int h, int w, int in_space,
+                         int32_t* counts, int32_t* table, int table_cap, int32_t* points, int points_cap)
+{
+    CK_TRY(check_img(ctx, edges, n, h, w));
+    if (!counts || !table || table_cap <= 0) return ck_fail(ctx, CK_ERR_ARG, "NULL table");
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, edges, (size_t)n * h * w, in_space, ctx->in_stage, &d_in));
+    std::vector<std::vector<CkContour>> found;
+    CK_TRY(k_contour_survey(ctx, (const uint8_t*)d_in, n, h, w, found));
+    size_t nt = 0, np = 0;
+    for (int f = 0; f < n; f++) {
+        counts[f] = (int32_t)found[f].size();
+        for (const CkContour& c : found[f]) {
+            if ((int)nt >= table_cap) return ck_fail(ctx, CK_ERR_CAPACITY, "more than %d contours in the batch", table_cap);
+            int32_t* t = table + nt * 4;
+            t[0] = c.root % w; t[1] = c.root / w; t[2] = c.nvert; t[3] = (int32_t)(c.pts.size() / 2);
+            nt++;
+            if (points) {
+                if (np + c.pts.size() / 2 > (size_t)points_cap) return ck_fail(ctx, CK_ERR_CAPACITY, "more than %d border pixels in the batch", points_cap);
+                memcpy(points + np * 2, c.pts.data(), c.pts.size() * 4);
+                np += c.pts.size() / 2;
+            }
+        }
+    }
     return finish(ctx);
 }
 

@@ -136,6 +136,17 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
                   float* lines, int cap, ck_board_result* res, uint8_t* d_ghost_out,
                   const int* d_canny_border_flag = nullptr);
 // d_nonfinite (nullable): set to 1 when a softmax came out inf / NaN
+// one external contour of an edge map (k_contour_survey): first pixel (raster index = discovery key), length of the
+// CHAIN_APPROX_SIMPLE vertex list, outer-border pixels as x0, y0, x1, y1, ...
+struct CkContour {
+    int root = 0;
+    int nvert = 0;
+    std::vector<int32_t> pts;
+};
+int k_contour_survey(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, std::vector<std::vector<CkContour>>& out);
+int ck_goban_canny_dev(ck_ctx* ctx, const uint8_t* d_in, int n, int h, int w, uint8_t* d_edges, double* otsu_out);   // ck_api.hip
+int k_contour_stones(ck_ctx* ctx, const uint8_t* d_goban, const uint8_t* d_fg, int n, int side, const int32_t* rects,
+                     int rs, int re, int cs, int ce, uint8_t* stones, int16_t* zones_out, uint8_t* mask_out);
 int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int n, float* d_y, uint8_t* d_labels, double* d_conf,
                   int* d_nonfinite = nullptr, uint8_t* d_rlabel = nullptr, double* d_rconf = nullptr);
 int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space);
@@ -147,3 +158,5 @@ int k_zone_counts(ck_ctx* ctx, const uint8_t* d_mask, int n, int side, int32_t* 
 // host geometry (ck_host_geom.cpp)
 void ck_invert3x3(const double* s, double* d);
 void ck_min_area_rect(const int32_t* pts, int n, float* out_wh);
+void ck_min_area_rect_box(const int32_t* pts, int n, float* out_wha);     // + angle in degrees (cv2.minAreaRect's box[2])
+std::vector<int32_t> ck_hull_points(const int32_t* pts, int n);           // strictly convex hull, x0, y0, x1, y1, ...

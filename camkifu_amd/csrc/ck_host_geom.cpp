@@ -14,6 +14,8 @@
 
 #include "../../include/camkifu_amd.h"
 
+void ck_min_area_rect_box(const int32_t* pts, int n, float* out_wha);
+
 void ck_invert3x3(const double* s, double* d)
 {
     double det = s[0] * (s[4] * s[8] - s[5] * s[7]) - s[1] * (s[3] * s[8] - s[5] * s[6]) +
@@ -71,16 +73,35 @@ std::vector<P2> hull_ordered(const int32_t* pts, int n)
 
 }  // namespace
 
+std::vector<int32_t> ck_hull_points(const int32_t* pts, int n)
+{
+    std::vector<int32_t> out;
+    if (n <= 0) return out;
+    for (const P2& p : hull_ordered(pts, n)) { out.push_back(p.x); out.push_back(p.y); }
+    return out;
+}
+
 void ck_min_area_rect(const int32_t* pts, int n, float* out_wh)
 {
-    out_wh[0] = out_wh[1] = 0.f;
+    float wha[3];
+    ck_min_area_rect_box(pts, n, wha);
+    out_wh[0] = wha[0]; out_wh[1] = wha[1];
+}
+
+// (w, h, angle in degrees) as the cv2 binding returns box[1], box[2]: the angle is the direction of the rectangle's first
+// side vector (atan2 in double -> float, then float * 180 / pi in double -> float)
+void ck_min_area_rect_box(const int32_t* pts, int n, float* out_wh)
+{
+    out_wh[0] = out_wh[1] = out_wh[2] = 0.f;
     if (n <= 0) return;
     const std::vector<P2> hull = hull_ordered(pts, n);
     const int hn = (int)hull.size();
+    auto degrees = [](float a) { return (float)((double)(a * 180.f) / 3.1415926535897932384626433832795); };
     if (hn == 2) {
         const double dx = (double)((float)hull[1].x - (float)hull[0].x);
         const double dy = (double)((float)hull[1].y - (float)hull[0].y);
         out_wh[0] = (float)std::sqrt(dx * dx + dy * dy);
+        out_wh[2] = degrees((float)std::atan2(dy, dx));
         return;
     }
     if (hn < 3) return;
@@ -152,6 +173,7 @@ void ck_min_area_rect(const int32_t* pts, int n, float* out_wh)
     const float v2x = -best_b * best_h, v2y = best_a * best_h;
     out_wh[0] = (float)std::sqrt((double)v1x * v1x + (double)v1y * v1y);
     out_wh[1] = (float)std::sqrt((double)v2x * v2x + (double)v2y * v2y);
+    out_wh[2] = degrees((float)std::atan2((double)v1y, (double)v1x));
 }
 
 extern "C" int ck_get_perspective_transform(const float* src, const float* dst, double* M)

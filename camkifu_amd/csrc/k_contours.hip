@@ -462,7 +462,8 @@ __global__ __launch_bounds__(256) void gather_points_kernel(const uint8_t* __res
                                                             const int32_t* __restrict__ labels, const int32_t* __restrict__ compid,
                                                             int maxc, const uint8_t* __restrict__ want, int wpitch, const FrameTab* __restrict__ tab,
                                                             const int32_t* __restrict__ blist, int32_t* __restrict__ counter, int cap,
-                                                            int32_t* __restrict__ pts /* x|y<<16, slot ; then frame */)
+                                                            int32_t* __restrict__ pts /* x|y<<16, slot ; then frame */,
+                                                            int keep_mid /* 1: every border pixel, not only hull candidates */)
 {
     int f, bx;
     list_frame_block(LIST_BLOCKS, f, bx);
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(256) void gather_points_kernel(const uint8_t* __res
         if (i < nb) {
             p = B[i];
             slot = compid[off + labels[off + p]];
-            take = want[(size_t)f * wpitch + slot] && !mid_of_run(ez + off, p, w);
+            take = want[(size_t)f * wpitch + slot] && (keep_mid || !mid_of_run(ez + off, p, w));
         }
         const int k = wave_append(counter, take);           // one atomic per wave
         if (take && k < cap) {
@@ -487,6 +488,51 @@ __global__ __launch_bounds__(256) void gather_points_kernel(const uint8_t* __res
             pts[2 * (size_t)cap + k] = f;
         }
     }
+}
+
+// ---- F2. vertex count of every external contour as CHAIN_APPROX_SIMPLE would store it -------
+// (SfContours filters on `cont.shape[0]`, stone/sf_contours.py:197, 266.)  One lane per contour runs the library's
+// border follower from the pixel the raster scan would start it at -- the first pixel of the component, which is the
+// union-find root -- reading the edge bytes only: the marks the serial algorithm writes into its image steer where
+// LATER borders start, never the path of the one being followed.  A vertex is stored where the step direction changes.
+__constant__ int8_t TRACE_DX[8] = { 1, 1, 0, -1, -1, -1, 0, 1 };      // 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE (y grows downwards)
+__constant__ int8_t TRACE_DY[8] = { 0, -1, -1, -1, 0, 1, 1, 1 };
+
+__global__ __launch_bounds__(64) void trace_count_kernel(const uint8_t* __restrict__ ez, int h, int w, FrameTab* __restrict__ tab,
+                                                         const int32_t* __restrict__ roots, int maxc, int32_t* __restrict__ nvert)
+{
+    const int f = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nr = min(tab[f].n_roots, maxc);
+    if (s >= nr) return;
+    const uint8_t* e = ez + (size_t)f * h * w;
+    const int p0 = roots[(size_t)f * maxc + s];
+    int dir = 4, first = -1;
+    do {                                             // clockwise from west: the first neighbour on the border
+        dir = (dir - 1) & 7;
+        const int q = p0 + TRACE_DY[dir] * w + TRACE_DX[dir];
+        if (e[q]) { first = q; break; }
+    } while (dir != 4);
+    int count = 1;                                   // an isolated pixel is a contour of one point
+    if (first >= 0) {
+        count = 0;
+        int cur = p0, prev_dir = dir ^ 4;
+        const long long cap = 8ll * h * w;           // every (pixel, direction) pair at most once: far above any real border
+        long long step = 0;
+        for (; step < cap; step++) {
+            int nxt;
+            for (;;) {                               // counter-clockwise from the pixel we came from
+                dir = (dir + 1) & 7;
+                nxt = cur + TRACE_DY[dir] * w + TRACE_DX[dir];
+                if (e[nxt]) break;
+            }
+            if (dir != prev_dir) { count++; prev_dir = dir; }
+            if (nxt == p0 && cur == first) break;
+            cur = nxt;
+            dir = (dir + 4) & 7;
+        }
+        if (step >= cap) tab[f].overflow = 1;
+    }
+    nvert[(size_t)f * maxc + s] = count;
 }
 
 // ---- G. ghost image + Hough point list ------------------------------------------------------
@@ -801,7 +847,7 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
             CK_HIP(ctx, hipMemsetAsync(d_counter, 0, 4, ctx->stream));
             hipLaunchKernelGGL(gather_points_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w,
                                (const int32_t*)L, (const int32_t*)compid, maxc, (const uint8_t*)d_want, nc_max,
-                               (const FrameTab*)d_tab, (const int32_t*)blist, d_counter, gcap, d_pts);
+                               (const FrameTab*)d_tab, (const int32_t*)blist, d_counter, gcap, d_pts, 0);
             CK_HIP(ctx, hipGetLastError());
         }
         int npts = 0;
@@ -963,5 +1009,130 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         }
     }
     lap("peaks d2h+sort");
+    return CK_OK;
+}
+
+
+// ---- external contours of a batch of (small) edge maps, handed to the host -------------------------------------
+// The survey SfContours.find_stones needs of each edge map (stone/sf_contours.py:78-83, 264-270): every RETR_EXTERNAL
+// contour with the length of its CHAIN_APPROX_SIMPLE vertex list and its outer-border pixels (the set drawContours
+// paints with thickness 1, and a superset of the hull vertices), in the order cv2 hands contours back: last found
+// first.  Same labelling kernels as the board path above; the follower (F2) only counts.
+int k_contour_survey(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, std::vector<std::vector<CkContour>>& out)
+{
+    const size_t fpx = (size_t)h * w, npx = fpx * n;
+    int maxc = (int)(fpx / 4 + 1);
+    if (maxc > MAXC_LIMIT) maxc = MAXC_LIMIT;
+    if (w > 65535 || h > 65535) return ck_fail(ctx, CK_ERR_ARG, "image side > 65535");
+    if (h < 3 || w < 3) return ck_fail(ctx, CK_ERR_ARG, "edge map smaller than 3x3");
+    CK_TRY(ck_ensure(ctx, ctx->ghost, npx));
+    CK_TRY(ck_ensure(ctx, ctx->labels, npx * 4));
+    CK_TRY(ck_ensure(ctx, ctx->labels2, npx * 4));
+    CK_TRY(ck_ensure(ctx, ctx->lists, npx * 8));
+    const size_t tab_bytes = sizeof(FrameTab) * (size_t)n;
+    CK_TRY(ck_ensure(ctx, ctx->misc, tab_bytes + 64));
+    CK_TRY(ck_ensure(ctx, ctx->comp, (size_t)n * maxc * (4 + 16 + 1 + 4)));
+    uint8_t* ez = (uint8_t*)ctx->ghost.p;
+    int32_t* L = (int32_t*)ctx->labels.p;
+    int32_t* compid = (int32_t*)ctx->labels2.p;
+    int32_t* elist = (int32_t*)ctx->lists.p;
+    int32_t* blist = elist + npx;
+    FrameTab* d_tab = (FrameTab*)ctx->misc.p;
+    int32_t* d_roots = (int32_t*)ctx->comp.p;
+    int32_t* d_aabb = d_roots + (size_t)n * maxc;
+    int32_t* d_nvert = d_aabb + (size_t)n * maxc * 4;
+    uint8_t* d_want = (uint8_t*)(d_nvert + (size_t)n * maxc);
+    const dim3 lgrid = list_grid(LIST_BLOCKS, n), lblock(256);
+    {
+        TimeScope ts(ctx, "survey_ccl");
+        CK_HIP(ctx, hipMemsetAsync(d_tab, 0, tab_bytes, ctx->stream));
+        const bool dwords = (w & 3) == 0 && ((uintptr_t)d_edges & 3) == 0;
+        if (dwords)
+            hipLaunchKernelGGL(prep_rows4_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
+        else
+            hipLaunchKernelGGL(prep_rows_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
+        hipLaunchKernelGGL(link_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
+                           (const FrameTab*)d_tab, (const int32_t*)elist, (const int*)nullptr);
+        hipLaunchKernelGGL(flatten_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
+                           (const FrameTab*)d_tab, (const int32_t*)elist, (const int*)nullptr);
+        hipLaunchKernelGGL(roots_list_kernel, lgrid, lblock, 0, ctx->stream, h, w, (const int32_t*)L, compid, d_tab, maxc,
+                           d_roots, d_aabb, (const int32_t*)elist);
+        hipLaunchKernelGGL(border_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, (const int32_t*)L,
+                           (const int32_t*)compid, maxc, d_tab, d_aabb, (const int32_t*)elist, blist);
+        CK_HIP(ctx, hipGetLastError());
+    }
+    std::vector<FrameTab> tab((size_t)n);
+    CK_HIP(ctx, hipMemcpyAsync(tab.data(), d_tab, tab_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int nc_max = 0;
+    size_t nb_total = 0;
+    for (int f = 0; f < n; f++) {
+        if (tab[f].overflow) return ck_fail(ctx, CK_ERR_CAPACITY, "edge map %d: more than %d external contours", f, maxc);
+        nc_max = std::max(nc_max, tab[f].n_roots);
+        nb_total += (size_t)tab[f].n_border;
+    }
+    out.assign((size_t)n, {});
+    if (!nc_max) return CK_OK;
+    {
+        TimeScope ts(ctx, "survey_trace");
+        hipLaunchKernelGGL(trace_count_kernel, dim3((nc_max + 63) / 64, n), dim3(64), 0, ctx->stream, (const uint8_t*)ez, h, w, d_tab,
+                           (const int32_t*)d_roots, maxc, d_nvert);
+        CK_HIP(ctx, hipGetLastError());
+    }
+    // roots and vertex counts (strided tables -> dense), then every outer-border pixel with its contour slot
+    const size_t cnt = (size_t)n * nc_max;
+    std::vector<int32_t> hroots(cnt), hnvert(cnt);
+    CK_HIP(ctx, hipMemcpy2DAsync(hroots.data(), (size_t)nc_max * 4, d_roots, (size_t)maxc * 4, (size_t)nc_max * 4, (size_t)n,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    CK_HIP(ctx, hipMemcpy2DAsync(hnvert.data(), (size_t)nc_max * 4, d_nvert, (size_t)maxc * 4, (size_t)nc_max * 4, (size_t)n,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    const int gcap = (int)std::max<size_t>(nb_total, 1);
+    CK_TRY(ck_ensure(ctx, ctx->pts, (size_t)gcap * 12 + 64));
+    int32_t* d_pts = (int32_t*)ctx->pts.p;
+    int32_t* d_counter = d_pts + (size_t)gcap * 3;
+    {
+        TimeScope ts(ctx, "survey_gather");
+        CK_HIP(ctx, hipMemsetAsync(d_want, 1, (size_t)n * nc_max, ctx->stream));
+        CK_HIP(ctx, hipMemsetAsync(d_counter, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(gather_points_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w,
+                           (const int32_t*)L, (const int32_t*)compid, maxc, (const uint8_t*)d_want, nc_max,
+                           (const FrameTab*)d_tab, (const int32_t*)blist, d_counter, gcap, d_pts, 1);
+        CK_HIP(ctx, hipGetLastError());
+    }
+    int npts = 0;
+    CK_HIP(ctx, hipMemcpyAsync(&npts, d_counter, 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK_HIP(ctx, hipMemcpyAsync(tab.data(), d_tab, tab_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f < n; f++)
+        if (tab[f].overflow) return ck_fail(ctx, CK_ERR_STATE, "edge map %d: the border follower did not close", f);
+    if (npts != (int)nb_total) return ck_fail(ctx, CK_ERR_STATE, "border gather: %d points for %zu border pixels", npts, nb_total);
+    std::vector<int32_t> hp((size_t)npts * 2), hf((size_t)npts);
+    if (npts) {
+        CK_HIP(ctx, hipMemcpyAsync(hp.data(), d_pts, (size_t)npts * 8, hipMemcpyDeviceToHost, ctx->stream));
+        CK_HIP(ctx, hipMemcpyAsync(hf.data(), d_pts + (size_t)gcap * 2, (size_t)npts * 4, hipMemcpyDeviceToHost, ctx->stream));
+        CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // slot -> position in cv2 order (root descending = reverse discovery)
+    std::vector<int> pos(cnt, -1);
+    for (int f = 0; f < n; f++) {
+        const int nc = tab[f].n_roots;
+        std::vector<int> order((size_t)nc);
+        for (int s = 0; s < nc; s++) order[s] = s;
+        const int32_t* hr = hroots.data() + (size_t)f * nc_max;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return hr[a] > hr[b]; });
+        out[f].resize((size_t)nc);
+        for (int k = 0; k < nc; k++) {
+            const int s = order[k];
+            pos[(size_t)f * nc_max + s] = k;
+            out[f][k].root = hr[s];
+            out[f][k].nvert = hnvert[(size_t)f * nc_max + s];
+        }
+    }
+    for (int i = 0; i < npts; i++) {
+        const int f = hf[i], s = hp[2 * (size_t)i + 1];
+        auto& c = out[f][pos[(size_t)f * nc_max + s]];
+        c.pts.push_back(hp[2 * (size_t)i] & 0xFFFF);
+        c.pts.push_back(hp[2 * (size_t)i] >> 16);
+    }
     return CK_OK;
 }

@@ -171,6 +171,26 @@ int ck_mog2_band_run(ck_ctx* ctx, int handle, const uint8_t* band, int n, int in
  * mask: n x 380 x 380 (non-zero = foreground); counts: n*361 int32 (pixels per getrect zone). */
 int ck_zone_counts(ck_ctx* ctx, const uint8_t* mask, int n, int in_space, int32_t* counts, int out_space);
 
+/* ---- SfContours.find_stones for n goban images in one call                         stone/sf_contours.py:48-111
+ * (with analyse_fg :207-249, extract_contours_fg :251-300, _filter_contours :186-205, _find_centers :302-330,
+ * find_color :128-184).  goban: n x side x side x 3 BGR, fg: n x side x side foreground masks (StonesFinder.get_foreground),
+ * both in `in_space`.  rects: HOST, 19*19*4 int32 = StonesFinder.getrect(r, c) as (x0, y0, x1, y1), x along rows -- the
+ * caller's grid, so a learnt PosGrid is honoured; rows [rs, re) and columns [cs, ce) are analysed, as the keyword
+ * arguments of the reference method say.  Outputs on the HOST: stones n*19*19 (0 E, 1 B, 2 W; E outside the range),
+ * zones (nullable) n*(re-rs)*(ce-cs)*4 int16 = the method's `zones` array, mask (nullable) n*hs*ws bytes = the hull
+ * mask of the analysed view (hs = x1 - x0, ws = y1 - y0 of the range's corner rectangles).
+ * CK_ERR_STATE where the reference itself raises (_find_centers dividing by a zero cell count). */
+int ck_contour_stones(ck_ctx* ctx, const uint8_t* goban, const uint8_t* fg, int n, int side, int in_space, const int32_t* rects,
+                      int rs, int re, int cs, int ce, uint8_t* stones, int16_t* zones, uint8_t* mask);
+
+/* ---- cv2.findContours(edges, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) as SfContours reads it   stone/sf_contours.py:82, 266
+ * For n edge maps (h x w, non-zero = edge): counts[f] = contours of map f; table: one row of 4 int32 per contour, map after
+ * map, each map's contours in the order cv2 returns them (last found first): x, y of the contour's first point, the
+ * length of its compressed vertex list (cont.shape[0]), the number of outer-border pixels; points (nullable): those
+ * pixels as x, y pairs, contour after contour (the set drawContours(thickness=1) paints).  All outputs on the HOST. */
+int ck_contours_external(ck_ctx* ctx, const uint8_t* edges, int n, int h, int w, int in_space,
+                         int32_t* counts, int32_t* table, int table_cap, int32_t* points, int points_cap);
+
 /* ======================================================================================================
  * Ordered (stateful) halves of the two finders -- host only, no GPU needed.  The per-frame finders call
  * them once per frame, the batch pipeline's fold calls them over the gathered per-frame records; the

@@ -64,6 +64,8 @@ int ora_find_external_sets(const uint8_t* edges, int h, int w, int32_t* labels_o
  * Convex hull (cv::convexHull clockwise=true ordering) + rotating calipers in float32.
  * pts: n x 2 int32.  out_wh[0..1] = box size (width,height) as float32. */
 void ora_min_area_rect(const int32_t* pts, int n, float* out_wh);
+void ora_min_area_rect_box(const int32_t* pts, int n, float* out_wha);
+int ora_convex_hull(const int32_t* pts, int n, int32_t* out_xy);
 
 /* imgutil.sort_contours_box + sorted_boxes[-3:]   core/imgutil.py:291-315, bf_auto.py:78-84
  * areas given in cv2 enumeration order (reverse discovery).  Emulates bisect.insort on

@@ -345,6 +345,48 @@ void ora_min_area_rect(const int32_t* pts, int n, float* out_wh)
     free(hull);
 }
 
+/* cv2.minAreaRect as the Python binding returns it: (w, h, angle in degrees); the centre is not used by any caller
+ * (sf_contours.py:201-203, 268-277).  n > 2: the calipers' first vector gives the width and the angle
+ * (atan2 in double, cast to float, then float * 180 / CV_PI in double, cast to float); n == 2: the segment. */
+void ora_min_area_rect_box(const int32_t* pts, int n, float* out_wha)
+{
+    out_wha[0] = out_wha[1] = out_wha[2] = 0.f;
+    if (n <= 0) return;
+    ipt* hull = (ipt*)malloc(sizeof(ipt) * (size_t)(n + 2));
+    int hn = hull_cv_order(pts, n, hull);
+    float angle = 0.f;
+    if (hn > 2) {
+        float* hx = (float*)malloc(sizeof(float) * (size_t)hn);
+        float* hy = (float*)malloc(sizeof(float) * (size_t)hn);
+        for (int i = 0; i < hn; i++) { hx[i] = (float)hull[i].x; hy[i] = (float)hull[i].y; }
+        float out[6];
+        rotating_calipers_minarea(hx, hy, hn, out);
+        out_wha[0] = (float)sqrt((double)out[2] * out[2] + (double)out[3] * out[3]);
+        out_wha[1] = (float)sqrt((double)out[4] * out[4] + (double)out[5] * out[5]);
+        angle = (float)atan2((double)out[3], (double)out[2]);
+        free(hy); free(hx);
+    } else if (hn == 2) {
+        double dx = (double)((float)hull[1].x - (float)hull[0].x);
+        double dy = (double)((float)hull[1].y - (float)hull[0].y);
+        out_wha[0] = (float)sqrt(dx * dx + dy * dy);
+        angle = (float)atan2(dy, dx);
+    }
+    out_wha[2] = (float)((double)(angle * 180.f) / 3.1415926535897932384626433832795);
+    free(hull);
+}
+
+/* cv2.convexHull(points) as a vertex set (strictly convex: collinear and duplicate points dropped); the order is
+ * the one hull_cv_order documents.  Returns the vertex count. */
+int ora_convex_hull(const int32_t* pts, int n, int32_t* out_xy)
+{
+    if (n <= 0) return 0;
+    ipt* hull = (ipt*)malloc(sizeof(ipt) * (size_t)(n + 2));
+    int hn = hull_cv_order(pts, n, hull);
+    for (int i = 0; i < hn; i++) { out_xy[2 * i] = hull[i].x; out_xy[2 * i + 1] = hull[i].y; }
+    free(hull);
+    return hn;
+}
+
 int ora_top3(const double* areas, int n, int* out_pos, double* biggest)
 {
     /* bisect.insort == insort_right on BoundingBox.__lt__ (area <): an element is placed

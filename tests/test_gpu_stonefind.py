@@ -1,0 +1,109 @@
+"""SfContours.find_stones on the GPU (ck_contour_stones; stone/sf_contours.py:48-330) against the oracle restatement
+(oracle/ora_stones.py): stones, the zones array and the hull mask bit for bit, on a filmed synthetic game whose
+foreground masks hold hands and fresh stones; and the contour survey underneath it (ck_contours_external) against the
+oracle's border follower -- start point, compressed vertex count and painted pixels of every contour, in cv2's order."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+DST = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
+
+
+@pytest.fixture(scope="module")
+def ck():
+    from camkifu_amd import capi
+    ctx = capi.Context(0)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def clip(ora):
+    """goban images + foreground masks of a filmed game (oracle warp + oracle MOG2), the frames worth looking at"""
+    from camkifu_amd import synth
+    n = 70
+    film, corners, truth, moves, hands = synth.film(n, 480, 640, seed=synth.SEED, quiet=40, move_every=10, hand_frames=5)
+    frames = film.numpy()
+    M = ora.get_perspective_transform(corners, DST)
+    model = ora.MOG2(380, 380, 3)
+    gobans, fgs = [], []
+    for f in range(n):
+        gob = ora.warp_perspective(frames[f], M)
+        fgs.append(model.apply(gob, 0.01 if f < 50 else 0.005))
+        gobans.append(gob)
+    pick = [45, 50, 52, 55, 61, 62, 65, 69]
+    return np.stack([gobans[f] for f in pick]), np.stack([fgs[f] for f in pick]), [truth[f] for f in pick]
+
+
+def _rects(ora):
+    return np.array([[ora.sf_getrect(r, c) for c in range(19)] for r in range(19)], np.int32)
+
+
+@pytest.mark.parametrize("shape,density,seed", [((40, 56), 0.15, 1), ((97, 131), 0.3, 2), ((120, 64), 0.55, 3), ((379, 379), 0.08, 4)])
+def test_contours_external_match_the_border_follower(ck, ora, shape, density, seed):
+    rng = np.random.default_rng(seed)
+    edges = ((rng.random((3,) + shape) < density) * 255).astype(np.uint8)
+    edges[1, 10:30, 12] = 255                      # a stroke, a box, a blob with a hole
+    edges[1, 5, 5:30] = 255
+    edges[2, 8:20, 8:20] = 255
+    edges[2, 11:14, 11:14] = 0
+    got = ck.contours_external(edges, want_points=True)
+    for k in range(3):
+        want = list(reversed(ora.find_external_suzuki(edges[k])))
+        assert len(got[k]) == len(want)
+        for g, w in zip(got[k], want):
+            assert g["start"] == tuple(int(v) for v in w["start"])
+            assert g["nvert"] == len(w["vert"])
+            assert set(map(tuple, g["pix"])) == set(map(tuple, w["pix"]))
+    one = ck.contours_external(edges[0])
+    assert [(c["start"], c["nvert"]) for c in one] == [(c["start"], c["nvert"]) for c in got[0]]
+
+
+def test_contour_stones_match_oracle(ck, ora, clip):
+    from oracle import ora_stones as S
+    gobans, fgs, truth = clip
+    rects = _rects(ora)
+    stones, zones, mask = ck.contour_stones(gobans, fgs, rects, want_all=True)
+    seen_fg = 0
+    for k in range(len(gobans)):
+        s, z, m, info = S.find_stones(gobans[k], fgs[k], want_all=True)
+        assert np.array_equal(mask[k], m), k
+        assert np.array_equal(zones[k], z), k
+        assert np.array_equal(stones[k], s), k
+        seen_fg += len(info["fg"])
+    assert seen_fg >= 3                                              # the foreground branch took part
+    assert (stones[0] == truth[0]).mean() > 0.97 and (stones[0] > 0).sum() > 20    # and the method finds the stones
+    # one image at a time, and from device memory
+    import torch
+    for k in (1, 4):
+        assert np.array_equal(ck.contour_stones(gobans[k], fgs[k], rects), stones[k])
+    dev = ck.contour_stones(torch.from_numpy(gobans[:3]).cuda(), torch.from_numpy(fgs[:3]).cuda(), rects)
+    assert np.array_equal(dev, stones[:3])
+
+
+@pytest.mark.parametrize("rng4", [(6, 13, 0, 7), (0, 7, 12, 19), (12, 19, 6, 13)])
+def test_contour_stones_on_a_subregion(ck, ora, clip, rng4):
+    """the rs / re / cs / ce keyword arguments (SfMeta's 3x3 split calls the method that way, sf_meta.py:211)"""
+    from oracle import ora_stones as S
+    gobans, fgs, _ = clip
+    rs, re, cs, ce = rng4
+    stones, zones, mask = ck.contour_stones(gobans[3:6], fgs[3:6], _rects(ora), rs, re, cs, ce, want_all=True)
+    for k in range(3):
+        s, z, m, _ = S.find_stones(gobans[3 + k], fgs[3 + k], rs, re, cs, ce, want_all=True)
+        assert np.array_equal(mask[k], m) and np.array_equal(zones[k], z) and np.array_equal(stones[k], s)
+
+
+def test_contour_stones_argument_errors(ck, ora):
+    from camkifu_amd import capi
+    rects = _rects(ora)
+    g = np.zeros((380, 380, 3), np.uint8)
+    fg = np.zeros((380, 380), np.uint8)
+    assert not ck.contour_stones(g, fg, rects).any()                 # nothing to see: all empty, no error
+    with pytest.raises(capi.CkError, match="error 1"):
+        ck.contour_stones(g, fg, rects, rs=5, re=5)
+    bad = rects.copy()
+    bad[18, 18, 2] = 500
+    with pytest.raises(capi.CkError, match="error 1"):
+        ck.contour_stones(g, fg, bad)
+    with pytest.raises(ValueError):
+        ck.contour_stones(g, fg[:100], rects)
