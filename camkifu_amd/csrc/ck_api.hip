@@ -32,12 +32,15 @@ int ck_ensure(ck_ctx* ctx, DevBuf& b, size_t bytes)
     return CK_OK;
 }
 
-int ck_ensure_pinned(ck_ctx* ctx, size_t bytes)
+int ck_ensure_pinned(ck_ctx* ctx, size_t bytes, int which)
 {
-    if (bytes <= ctx->host_pinned_cap) return CK_OK;
-    if (ctx->host_pinned) { CK_HIP(ctx, hipHostFree(ctx->host_pinned)); ctx->host_pinned = nullptr; ctx->host_pinned_cap = 0; }
-    CK_HIP(ctx, hipHostMalloc(&ctx->host_pinned, bytes, hipHostMallocDefault));
-    ctx->host_pinned_cap = bytes;
+    void*& p = which ? ctx->host_pinned2 : ctx->host_pinned;
+    size_t& cap = which ? ctx->host_pinned2_cap : ctx->host_pinned_cap;
+    if (bytes <= cap) return CK_OK;
+    if (p) { CK_HIP(ctx, hipHostFree(p)); p = nullptr; cap = 0; }
+    bytes += bytes / 4;                       // a little headroom: the survey's point count changes from batch to batch
+    CK_HIP(ctx, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    cap = bytes;
     return CK_OK;
 }
 
@@ -201,6 +204,7 @@ void ck_ctx_destroy(ck_ctx* ctx)
     for (auto& pe : ctx->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
+    if (ctx->host_pinned2) (void)hipHostFree(ctx->host_pinned2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

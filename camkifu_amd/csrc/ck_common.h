@@ -73,6 +73,8 @@ struct ck_ctx {
     DevBuf mats;
     void* host_pinned = nullptr;
     size_t host_pinned_cap = 0;
+    void* host_pinned2 = nullptr;    // second arena (contour survey) so that a caller's data in the first one survives
+    size_t host_pinned2_cap = 0;
 
     CnnWeights cnn;
     int* cnn_flag_host = nullptr;    // host-mapped flag: the split-precision kernels met a value outside the fp16 range
@@ -86,7 +88,7 @@ extern thread_local std::string g_ck_create_error;
 
 int ck_fail(ck_ctx* ctx, int code, const char* fmt, ...);
 int ck_ensure(ck_ctx* ctx, DevBuf& b, size_t bytes);
-int ck_ensure_pinned(ck_ctx* ctx, size_t bytes);
+int ck_ensure_pinned(ck_ctx* ctx, size_t bytes, int which = 0);
 
 #define CK_HIP(ctx, call)                                                                 \
     do {                                                                                  \

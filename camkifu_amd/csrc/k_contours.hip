@@ -490,6 +490,25 @@ __global__ __launch_bounds__(256) void gather_points_kernel(const uint8_t* __res
     }
 }
 
+// every outer-border pixel of every map with the slot of its contour, at a position known in advance (survey only)
+__global__ __launch_bounds__(256) void survey_points_kernel(int h, int w, const int32_t* __restrict__ labels, const int32_t* __restrict__ compid,
+                                                            const FrameTab* __restrict__ tab, const int32_t* __restrict__ blist,
+                                                            const int32_t* __restrict__ base, int32_t* __restrict__ pts /* x | y << 16, slot */)
+{
+    int f, bx;
+    list_frame_block(LIST_BLOCKS, f, bx);
+    const int nb = tab[f].n_border;
+    const size_t off = (size_t)f * h * w;
+    const int32_t* B = blist + off;
+    int32_t* out = pts + 2 * (size_t)base[f];
+    for (int i = bx * 256 + threadIdx.x; i < nb; i += LIST_BLOCKS * 256) {
+        const int p = B[i];
+        const int y = p / w, x = p - y * w;
+        out[2 * (size_t)i] = x | (y << 16);
+        out[2 * (size_t)i + 1] = compid[off + labels[off + p]];
+    }
+}
+
 // ---- F2. vertex count of every external contour as CHAIN_APPROX_SIMPLE would store it -------
 // (SfContours filters on `cont.shape[0]`, stone/sf_contours.py:197, 266.)  One lane per contour runs the library's
 // border follower from the pixel the raster scan would start it at -- the first pixel of the component, which is the
@@ -1041,7 +1060,6 @@ int k_contour_survey(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, s
     int32_t* d_roots = (int32_t*)ctx->comp.p;
     int32_t* d_aabb = d_roots + (size_t)n * maxc;
     int32_t* d_nvert = d_aabb + (size_t)n * maxc * 4;
-    uint8_t* d_want = (uint8_t*)(d_nvert + (size_t)n * maxc);
     const dim3 lgrid = list_grid(LIST_BLOCKS, n), lblock(256);
     {
         TimeScope ts(ctx, "survey_ccl");
@@ -1079,60 +1097,61 @@ int k_contour_survey(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, s
                            (const int32_t*)d_roots, maxc, d_nvert);
         CK_HIP(ctx, hipGetLastError());
     }
-    // roots and vertex counts (strided tables -> dense), then every outer-border pixel with its contour slot
+    // roots and vertex counts (strided tables -> dense), then every outer-border pixel with its contour slot: the border
+    // list of a map is already dense, so pixel i of map f lands at base[f] + i -- no counter, and the host gets the maps
+    // as contiguous segments it can bucket in parallel
     const size_t cnt = (size_t)n * nc_max;
     std::vector<int32_t> hroots(cnt), hnvert(cnt);
     CK_HIP(ctx, hipMemcpy2DAsync(hroots.data(), (size_t)nc_max * 4, d_roots, (size_t)maxc * 4, (size_t)nc_max * 4, (size_t)n,
                                  hipMemcpyDeviceToHost, ctx->stream));
     CK_HIP(ctx, hipMemcpy2DAsync(hnvert.data(), (size_t)nc_max * 4, d_nvert, (size_t)maxc * 4, (size_t)nc_max * 4, (size_t)n,
                                  hipMemcpyDeviceToHost, ctx->stream));
-    const int gcap = (int)std::max<size_t>(nb_total, 1);
-    CK_TRY(ck_ensure(ctx, ctx->pts, (size_t)gcap * 12 + 64));
+    std::vector<int32_t> base((size_t)n + 1, 0);
+    for (int f = 0; f < n; f++) base[f + 1] = base[f] + tab[f].n_border;
+    const size_t npts = nb_total;
+    CK_TRY(ck_ensure(ctx, ctx->pts, npts * 8 + (size_t)(n + 1) * 4 + 64));
     int32_t* d_pts = (int32_t*)ctx->pts.p;
-    int32_t* d_counter = d_pts + (size_t)gcap * 3;
+    int32_t* d_base = d_pts + npts * 2;
+    CK_TRY(ck_ensure_pinned(ctx, npts * 8 + 64, 1));
+    int32_t* hp = (int32_t*)ctx->host_pinned2;
     {
         TimeScope ts(ctx, "survey_gather");
-        CK_HIP(ctx, hipMemsetAsync(d_want, 1, (size_t)n * nc_max, ctx->stream));
-        CK_HIP(ctx, hipMemsetAsync(d_counter, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(gather_points_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w,
-                           (const int32_t*)L, (const int32_t*)compid, maxc, (const uint8_t*)d_want, nc_max,
-                           (const FrameTab*)d_tab, (const int32_t*)blist, d_counter, gcap, d_pts, 1);
+        CK_HIP(ctx, hipMemcpyAsync(d_base, base.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(survey_points_kernel, lgrid, lblock, 0, ctx->stream, h, w, (const int32_t*)L, (const int32_t*)compid,
+                           (const FrameTab*)d_tab, (const int32_t*)blist, (const int32_t*)d_base, d_pts);
         CK_HIP(ctx, hipGetLastError());
     }
-    int npts = 0;
-    CK_HIP(ctx, hipMemcpyAsync(&npts, d_counter, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (npts) CK_HIP(ctx, hipMemcpyAsync(hp, d_pts, npts * 8, hipMemcpyDeviceToHost, ctx->stream));
     CK_HIP(ctx, hipMemcpyAsync(tab.data(), d_tab, tab_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (base is a local: its upload is done too)
     for (int f = 0; f < n; f++)
         if (tab[f].overflow) return ck_fail(ctx, CK_ERR_STATE, "edge map %d: the border follower did not close", f);
-    if (npts != (int)nb_total) return ck_fail(ctx, CK_ERR_STATE, "border gather: %d points for %zu border pixels", npts, nb_total);
-    std::vector<int32_t> hp((size_t)npts * 2), hf((size_t)npts);
-    if (npts) {
-        CK_HIP(ctx, hipMemcpyAsync(hp.data(), d_pts, (size_t)npts * 8, hipMemcpyDeviceToHost, ctx->stream));
-        CK_HIP(ctx, hipMemcpyAsync(hf.data(), d_pts + (size_t)gcap * 2, (size_t)npts * 4, hipMemcpyDeviceToHost, ctx->stream));
-        CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    // slot -> position in cv2 order (root descending = reverse discovery)
-    std::vector<int> pos(cnt, -1);
-    for (int f = 0; f < n; f++) {
+    // per map: contours in cv2 order (root descending = reverse discovery), border pixels bucketed by counting
+    parallel_for(n, [&](int f) {
         const int nc = tab[f].n_roots;
-        std::vector<int> order((size_t)nc);
+        if (!nc) return;
+        std::vector<int> order((size_t)nc), pos((size_t)nc), fill((size_t)nc, 0);
         for (int s = 0; s < nc; s++) order[s] = s;
         const int32_t* hr = hroots.data() + (size_t)f * nc_max;
         std::sort(order.begin(), order.end(), [&](int a, int b) { return hr[a] > hr[b]; });
-        out[f].resize((size_t)nc);
+        auto& cv = out[f];
+        cv.resize((size_t)nc);
         for (int k = 0; k < nc; k++) {
             const int s = order[k];
-            pos[(size_t)f * nc_max + s] = k;
-            out[f][k].root = hr[s];
-            out[f][k].nvert = hnvert[(size_t)f * nc_max + s];
+            pos[s] = k;
+            cv[k].root = hr[s];
+            cv[k].nvert = hnvert[(size_t)f * nc_max + s];
         }
-    }
-    for (int i = 0; i < npts; i++) {
-        const int f = hf[i], s = hp[2 * (size_t)i + 1];
-        auto& c = out[f][pos[(size_t)f * nc_max + s]];
-        c.pts.push_back(hp[2 * (size_t)i] & 0xFFFF);
-        c.pts.push_back(hp[2 * (size_t)i] >> 16);
-    }
+        const int32_t* seg = hp + 2 * (size_t)base[f];
+        const int nb = base[f + 1] - base[f];
+        for (int i = 0; i < nb; i++) fill[seg[2 * i + 1]]++;
+        for (int s = 0; s < nc; s++) { cv[pos[s]].pts.resize(2 * (size_t)fill[s]); fill[s] = 0; }
+        for (int i = 0; i < nb; i++) {
+            const int s = seg[2 * i + 1];
+            int32_t* dst = cv[pos[s]].pts.data() + 2 * (size_t)fill[s]++;
+            dst[0] = seg[2 * i] & 0xFFFF;
+            dst[1] = seg[2 * i] >> 16;
+        }
+    });
     return CK_OK;
 }

@@ -18,6 +18,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <chrono>
 #include <thread>
 
 #include "ck_common.h"
@@ -174,6 +175,15 @@ int fg_contours(const std::vector<CkContour>& found, const uint8_t* sub_fg, int 
 int k_contour_stones(ck_ctx* ctx, const uint8_t* d_goban, const uint8_t* d_fg, int n, int side, const int32_t* rects,
                      int rs, int re, int cs, int ce, uint8_t* stones, int16_t* zones_out, uint8_t* mask_out)
 {
+    static const bool prof = getenv("CK_PROFILE_HOST") != nullptr;   // debugging aid: host-side lap times on stderr
+    auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!prof) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[contour_stones] %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_start).count());
+        t_start = now;
+    };
     const int R = re - rs, C = ce - cs, nz = R * C;
     const int x0 = rects[((size_t)rs * GS + cs) * 4], y0 = rects[((size_t)rs * GS + cs) * 4 + 1];
     const int x1 = rects[((size_t)(re - 1) * GS + ce - 1) * 4 + 2], y1 = rects[((size_t)(re - 1) * GS + ce - 1) * 4 + 3];
@@ -210,22 +220,26 @@ int k_contour_stones(ck_ctx* ctx, const uint8_t* d_goban, const uint8_t* d_fg, i
         hipLaunchKernelGGL(crop_bgr_kernel, dim3((ws * 3 + 255) / 256, hs, n), dim3(256), 0, ctx->stream, d_goban, side, x0, y0, hs, ws, d_sub);
         CK_HIP(ctx, hipGetLastError());
     }
-    std::vector<uint8_t> h_fg(npx);
-    CK_HIP(ctx, hipMemcpyAsync(h_fg.data(), d_subfg, npx, hipMemcpyDeviceToHost, ctx->stream));
+    CK_TRY(ck_ensure_pinned(ctx, npx));
+    const uint8_t* h_fg = (const uint8_t*)ctx->host_pinned;
+    CK_HIP(ctx, hipMemcpyAsync(ctx->host_pinned, d_subfg, npx, hipMemcpyDeviceToHost, ctx->stream));
     CK_TRY(k_canny_planar(ctx, (const uint8_t*)ctx->planes.p, n, hs, ws, pitch, 25, 75, (uint8_t*)ctx->map.p,
                           (int32_t*)ctx->labels.p, d_edges, nullptr));
+    lap("open + fg canny");
     CK_TRY(ck_goban_canny_dev(ctx, d_sub, n, hs, ws, d_edges + npx, nullptr));
+    lap("get_canny");
 
     // ---- C: external contours of the 2n maps -------------------------------------------------------------------------
     std::vector<std::vector<CkContour>> found;
     CK_TRY(k_contour_survey(ctx, d_edges, 2 * n, hs, ws, found));
+    lap("contour survey");
 
     // ---- D: which hulls make the mask -----------------------------------------------------------------------------
     std::vector<std::vector<int32_t>> spans((size_t)n);
     std::vector<int> bad((size_t)n, 0);
     frames_parallel(n, [&](int f) {
         std::vector<const CkContour*> kept;
-        if (fg_contours(found[f], h_fg.data() + (size_t)f * spx, hs, ws, radius, kept) < 0) { bad[f] = 1; return; }
+        if (fg_contours(found[f], h_fg + (size_t)f * spx, hs, ws, radius, kept) < 0) { bad[f] = 1; return; }
         for (const CkContour& c : found[(size_t)n + f]) {                    // _filter_contours
             if (c.nvert < 10) continue;
             const Box b = box_of(c);
@@ -248,6 +262,7 @@ int k_contour_stones(ck_ctx* ctx, const uint8_t* d_goban, const uint8_t* d_fg, i
                 }
         }
     });
+    lap("host geometry");
     for (int f = 0; f < n; f++)
         if (bad[f]) return ck_fail(ctx, CK_ERR_STATE, "image %d: a foreground contour thinner than a stone radius reached _find_centers "
                                                       "(the reference divides by zero there)", f);
@@ -277,6 +292,7 @@ int k_contour_stones(ck_ctx* ctx, const uint8_t* d_goban, const uint8_t* d_fg, i
     if (mask_out) CK_HIP(ctx, hipMemcpyAsync(mask_out, d_mask, npx, hipMemcpyDeviceToHost, ctx->stream));
     CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
+    lap("mask + zone sums");
     // ---- zone means (int16, truncated as numpy stores a float into an int16 slot) and colours, in raster order -------
     std::vector<int16_t> zones((size_t)nz * 4);
     for (int f = 0; f < n; f++) {
@@ -298,5 +314,6 @@ int k_contour_stones(ck_ctx* ctx, const uint8_t* d_goban, const uint8_t* d_fg, i
         ck_find_colors(zones.data(), R, C, st + (size_t)rs * GS + cs, GS);
         if (zones_out) memcpy(zones_out + (size_t)f * nz * 4, zones.data(), zones.size() * 2);
     }
+    lap("colours");
     return CK_OK;
 }

@@ -14,6 +14,7 @@ bfinders = [
 ]
 sfinders = [
     ("camkifu_amd.stone.sf_neural", "SfNeural"),
+    ("camkifu_amd.stone.sf_contours", "SfContours"),
     ("None", "None"),
 ]
 bf_loc = None

@@ -73,6 +73,15 @@ class OracleCtx:
             return ora.zone_counts(mask)
         return np.stack([ora.zone_counts(m) for m in mask])
 
+    def contour_stones(self, goban, fg, rects, rs=0, re=19, cs=0, ce=19, want_all=False):
+        from oracle import ora_stones
+        assert np.array_equal(np.asarray(rects).reshape(19, 19, 4), [[ora.sf_getrect(r, c) for c in range(19)] for r in range(19)])
+        goban, fg = np.asarray(goban), np.asarray(fg)
+        if goban.ndim == 3:
+            return ora_stones.find_stones(goban, fg, rs, re, cs, ce, want_all)[:3] if want_all else ora_stones.find_stones(goban, fg, rs, re, cs, ce)
+        res = [ora_stones.find_stones(g, m, rs, re, cs, ce, want_all) for g, m in zip(goban, fg)]
+        return tuple(np.stack([r[k] for r in res]) for k in range(3)) if want_all else np.stack(res)
+
     def cnn_set_weights(self, weights):
         self.weights = {k: np.asarray(v, np.float32) for k, v in weights.items()}
 
