@@ -19,6 +19,8 @@ CK_CNN_FP32, CK_CNN_BF16, CK_CNN_F16X2 = 0, 1, 2
 CK_CNN_DEFAULT = CK_CNN_F16X2            # what a new context computes in
 CK_BOARD_LINES, CK_BOARD_NO_CONTOUR, CK_BOARD_TOO_SMALL = 0, 1, 2
 
+ZONE_LINES = 32        # CK_ZONE_LINES
+
 EXPORTS = [
     "ck_ctx_create", "ck_ctx_destroy", "ck_last_error", "ck_backend", "ck_version", "ck_stream",
     "ck_timing_enable", "ck_timing_reset", "ck_timing_get",
@@ -27,7 +29,7 @@ EXPORTS = [
     "ck_mog2_create", "ck_mog2_apply", "ck_mog2_destroy",
     "ck_cnn_set_weights", "ck_cnn_set_mode", "ck_cnn_predict", "ck_stones_detect",
     "ck_cnn_regions", "ck_stones_run", "ck_zone_counts", "ck_mog2_band_run",
-    "ck_contour_stones", "ck_contours_external",
+    "ck_contour_stones", "ck_contours_external", "ck_find_intersections", "ck_update_grid",
     "ck_ordered_hull", "ck_boardfold_create", "ck_boardfold_destroy", "ck_boardfold_reset", "ck_boardfold_step",
     "ck_policy_create", "ck_policy_destroy", "ck_policy_run", "ck_policy_get_state", "ck_policy_set_state",
     "ck_policy_watch",
@@ -458,6 +460,35 @@ class Context:
             out.append(lst)
         return out[0] if single else out
 
+    # ---- StonesFinder.find_intersections ----------------------------------------------------
+    def find_intersections(self, goban, mtx, rects, want_lines=False):
+        """StonesFinder.find_intersections (stone/stonesfinder.py:516-552) for one goban image (side, side, 3) or a batch,
+        host or device; mtx (19, 19, 2) int16 PosGrid.mtx, rects (19, 19, 4) getrect table -> grid int16 (.., 19, 19, 2)
+        (with want_lines also: per image a dict {(r, c): [(x0, y0, x1, y1), ..]} of the lines found, and the Canny map)"""
+        single = len(goban.shape) == 3
+        n = 1 if single else int(goban.shape[0])
+        side = int(goban.shape[-2])
+        if tuple(goban.shape[-3:]) != (side, side, 3):
+            raise ValueError("goban %r: expected (.., s, s, 3)" % (tuple(goban.shape),))
+        mtx = np.ascontiguousarray(mtx, np.int16).reshape(19, 19, 2)
+        rects = np.ascontiguousarray(rects, np.int32).reshape(19, 19, 4)
+        p, sp, keep = _in(goban)
+        grid = np.zeros((n, 19, 19, 2), np.int16)
+        lines = counts = edges = None
+        lp = cp = ep = None
+        if want_lines:
+            lines = np.zeros((n, 361, ZONE_LINES, 4), np.int16)
+            counts = np.zeros((n, 361), np.int32)
+            edges = np.zeros((n, side, side), np.uint8)
+            lp, cp, ep = (a.ctypes.data_as(C.c_void_p) for a in (lines, counts, edges))
+        self._chk(lib().ck_find_intersections(self._h, p, n, side, sp, mtx.ctypes.data_as(C.c_void_p), rects.ctypes.data_as(C.c_void_p),
+                                              grid.ctypes.data_as(C.c_void_p), lp, cp, ep))
+        if not want_lines:
+            return grid[0] if single else grid
+        found = [{divmod(z, 19): [tuple(int(v) for v in lines[f, z, k]) for k in range(counts[f, z])]
+                  for z in np.nonzero(counts[f])[0]} for f in range(n)]
+        return (grid[0], found[0], edges[0]) if single else (grid, found, edges)
+
 
 def get_perspective_transform(src4, dst4):
     """K7, host only (board/boardfinder.py:43-45)."""
@@ -469,6 +500,18 @@ def get_perspective_transform(src4, dst4):
     if rc != 0:
         raise CkError("degenerate quadrilateral")
     return M.reshape(3, 3)
+
+
+def update_grid(lines, box, slot):
+    """update_grid (stone/stonesfinder.py:888-947), host only: lines as cv2.HoughLinesP returns them ((k, 1, 4) or (k, 4)),
+    box = getrect of the zone, slot = the int16 pair of the intersection, updated in place"""
+    seg = np.ascontiguousarray(np.asarray(lines).reshape(-1, 4), np.int32)
+    b = np.ascontiguousarray(box, np.int32)
+    out = np.ascontiguousarray(slot, np.int16).copy()
+    rc = lib().ck_update_grid(seg.ctypes.data_as(C.c_void_p), len(seg), b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ZeroDivisionError("float division by zero") if rc == 1 else CkError("ck_update_grid: error %d" % rc)
+    slot[:] = out
 
 
 def ordered_hull(points):

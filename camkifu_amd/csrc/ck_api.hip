@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <vector>
 #include "ck_common.h"
+#include "ck_stonegeom.h"
 
 thread_local std::string g_ck_create_error;
 
@@ -101,7 +102,7 @@ int ck_timing_collect(ck_ctx* ctx)
 }
 
 // OpenCV's getThreshVal_Otsu_8u restated (double arithmetic, the FLT_EPSILON guards, first maximum wins)
-static double otsu_level(const int* hist, size_t npx)
+double ck_otsu_level(const int* hist, size_t npx)
 {
     double mu = 0, scale = 1. / (double)npx;
     for (int i = 0; i < 256; i++) mu += i * (double)hist[i];
@@ -145,7 +146,7 @@ int ck_goban_canny_dev(ck_ctx* ctx, const uint8_t* d_in, int n, int h, int w, ui
     // cv2.Canny(median, otsu / 2, otsu): thresholds are floored (L1 gradient); one pair per frame, one batched call
     std::vector<int> thr((size_t)n * 2);
     for (int f = 0; f < n; f++) {
-        const double otsu = otsu_level(&hist[(size_t)f * 256], npx1);
+        const double otsu = ck_otsu_level(&hist[(size_t)f * 256], npx1);
         if (otsu_out) otsu_out[f] = otsu;
         thr[2 * f] = (int)std::floor(otsu / 2);
         thr[2 * f + 1] = (int)std::floor(otsu);
@@ -641,6 +642,44 @@ int ck_contours_external(ck_ctx* ctx, const uint8_t* edges, int n, int h, int w,
         }
     }
     return finish(ctx);
+}
+
+int ck_find_intersections(ck_ctx* ctx, const uint8_t* goban, int n, int side, int in_space, const int16_t* mtx, const int32_t* rects,
+                          int16_t* grid, int16_t* lines, int32_t* nlines, uint8_t* edges)
+{
+    if (!ctx) return CK_ERR_ARG;
+    if (!goban || !mtx || !rects || !grid || n <= 0) return ck_fail(ctx, CK_ERR_ARG, "NULL argument or n <= 0");
+    if (side < 19 * 4 || side > 4096) return ck_fail(ctx, CK_ERR_ARG, "goban image side %d", side);
+    CK_HIP(ctx, hipSetDevice(ctx->device));
+    const void* d_img;
+    CK_TRY(ck_to_device(ctx, goban, (size_t)n * side * side * 3, in_space, ctx->in_stage, &d_img));
+    std::vector<int16_t> own_lines;
+    std::vector<int32_t> own_counts;
+    if (!lines) { own_lines.resize((size_t)n * 361 * CK_ZONE_LINES * 4); lines = own_lines.data(); }
+    if (!nlines) { own_counts.resize((size_t)n * 361); nlines = own_counts.data(); }
+    CK_TRY(k_grid_lines(ctx, (const uint8_t*)d_img, n, side, rects, lines, nlines, edges));
+    int32_t seg[CK_ZONE_LINES * 4];
+    for (int f = 0; f < n; f++) {
+        int16_t* g = grid + (size_t)f * 361 * 2;
+        memcpy(g, mtx, 361 * 2 * sizeof(int16_t));
+        for (int z = 0; z < 361; z++) {
+            const int k = nlines[(size_t)f * 361 + z];
+            if (!k) continue;
+            const int16_t* l = lines + ((size_t)f * 361 + z) * CK_ZONE_LINES * 4;
+            for (int i = 0; i < k * 4; i++) seg[i] = l[i];
+            ck_update_grid_host(seg, k, rects + 4 * z, g + 2 * z);
+        }
+    }
+    return finish(ctx);
+}
+
+int ck_update_grid(const int32_t* lines, int k, const int32_t* box, int16_t* slot)
+{
+    if (!lines || !box || !slot || k < 0) return CK_ERR_ARG;
+    for (int i = 0; i < k; i++)
+        if (lines[4 * i] == lines[4 * i + 2] && lines[4 * i + 1] == lines[4 * i + 3]) return CK_ERR_ARG;   // zero length: the reference divides by zero
+    ck_update_grid_host(lines, k, box, slot);
+    return CK_OK;
 }
 
 int ck_mog2_create(ck_ctx* ctx, int h, int w, int* handle)

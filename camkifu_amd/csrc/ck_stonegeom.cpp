@@ -185,3 +185,51 @@ void ck_find_colors(const int16_t* zones, int R, int C, uint8_t* stones, int str
         for (int c = 0; c < C; c++)
             if (zones[((size_t)r * C + c) * 4]) find_color(r, c, zones, R, C, stones, stride);
 }
+
+// ---- update_grid (stonesfinder.py:888-947) ----------------------------------------------------------------------
+// lines: k x (x0, y0, x1, y1) as cv2.HoughLinesP returns them for the zone `box` = (x0, y0, x1, y1) of
+// StonesFinder.getrect (x along rows); slot: the int16 (x, y) of the intersection, updated in place.  Python float
+// arithmetic restated in its operation order (true divisions in double, int() truncation, math.acos / cos / sin).
+void ck_update_grid_host(const int32_t* lines, int k, const int32_t* box, int16_t* slot)
+{
+    const double margin = (double)std::min(box[2] - box[0], box[3] - box[1]) / 7;
+    auto inside = [&](double px, double py) {
+        return box[0] + margin < px && px < box[2] - margin && box[1] + margin < py && py < box[3] - margin;
+    };
+    std::vector<const int32_t*> kept;
+    for (int i = 0; i < k; i++) {
+        const int32_t* c = lines + 4 * (size_t)i;
+        const long long ddx = (long long)c[0] - c[2], ddy = (long long)c[1] - c[3];
+        const double theta = std::acos((double)(c[2] - c[0]) / std::sqrt((double)(ddx * ddx + ddy * ddy)));
+        double px, py;
+        if (0.995 < std::fabs(std::cos(theta))) {            // level line: does it pass the middle columns?
+            px = (double)(box[0] + box[2]) / 2;
+            py = (double)(c[0] + c[2]) / 2 + box[1];
+        } else if (0.995 < std::fabs(std::sin(theta))) {     // upright line: the middle rows?
+            px = (double)(c[1] + c[3]) / 2 + box[0];
+            py = (double)(box[3] + box[1]) / 2;
+        } else continue;
+        if (inside(px, py)) kept.push_back(c);
+    }
+    if (kept.empty()) return;
+    slot[0] = (int16_t)-slot[0];
+    slot[1] = (int16_t)-slot[1];
+    if (!(1 < kept.size() && kept.size() < 5)) return;
+    long long sx = 0, sy = 0, hits = 0;
+    for (size_t a = 0; a < kept.size(); a++)
+        for (size_t b = 0; b < kept.size(); b++) {
+            if (a == b) continue;
+            const int32_t *s = kept[a], *o = kept[b];
+            const long long d1x = s[2] - s[0], d1y = s[3] - s[1], d2x = o[2] - o[0], d2y = o[3] - o[1];
+            const double cross = (double)(d1x * d2y - d1y * d2x);
+            if (std::fabs(cross) < 2.220446049250313e-16) continue;          // sys.float_info.epsilon
+            const double t1 = (double)((long long)(o[0] - s[0]) * d2y - (long long)(o[1] - s[1]) * d2x) / cross;
+            const int ix = (int)(s[0] + t1 * (double)d1x), iy = (int)(s[1] + t1 * (double)d1y);
+            const long long qx = (long long)iy + box[0], qy = (long long)ix + box[1];    // crossing comes as (column, row)
+            if (inside((double)qx, (double)qy)) { sx += qx; sy += qy; hits++; }
+        }
+    if (hits) {
+        slot[0] = (int16_t)(int)((double)-sx / (double)hits);
+        slot[1] = (int16_t)(int)((double)-sy / (double)hits);
+    }
+}

@@ -10,3 +10,5 @@ void ck_raster_polygon(const int32_t* v, int nv, int* bx, int* by, int* bw, int*
 void ck_chamfer5(const uint8_t* img, int h, int w, std::vector<int32_t>& dist);
 int ck_has_stone_center(const int32_t* dist, int rows, int cols, double radius);
 void ck_find_colors(const int16_t* zones, int R, int C, uint8_t* stones, int stride);
+// update_grid (stonesfinder.py:888-947) for one intersection zone
+void ck_update_grid_host(const int32_t* lines, int k, const int32_t* box, int16_t* slot);

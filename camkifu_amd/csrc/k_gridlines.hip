@@ -1,0 +1,264 @@
+// k_gridlines.hip -- StonesFinder.find_intersections for a batch of goban images
+// (reference: src/camkifu/stone/stonesfinder.py:516-552; update_grid :888-947 runs on the host, ck_stonegeom.cpp).
+//
+//   gray = cvtColor(img, BGR2GRAY); level = Otsu(gray); canny = Canny(gray, level / 2, level)
+//   for each of the 361 intersection zones:  HoughLinesP(zone, 1, pi / 180, 3/4 side, minLineLength 2/3 side, maxLineGap 0)
+//
+// A  one kernel turns the interleaved image into three equal grey planes (K2's Canny kernel takes planes) and the
+//    grey histogram (LDS bins); the Otsu level is the library's double-precision scan on the host, one round trip
+//    for the whole batch; Canny is K2's kernel with per-image thresholds.
+// B  the progressive probabilistic Hough transform is serial in its points (each accepted line removes pixels the
+//    next draw may have hit) but the 361 x n zones are independent and tiny: ONE WAVE PER ZONE.  The 180 x numrho
+//    accumulator of a zone (16-bit counters) lives in LDS, the lanes share the 180 angles of every vote and
+//    un-vote, the random draw (cv::RNG, seeded the same for every call of the library function), the fixed-point walk
+//    along the winning line and the bookkeeping are wave-uniform.
+#include <math.h>
+
+#include "ck_common.h"
+#include "ck_stonegeom.h"
+
+namespace {
+
+constexpr int GS = 19;
+constexpr int ZMAX = 40;                 // largest zone side the LDS layout is sized for
+constexpr int NANG = 180;
+
+__global__ __launch_bounds__(256) void gray_planes_hist_kernel(const uint8_t* __restrict__ bgr, int h, int w, int pitch,
+                                                               uint8_t* __restrict__ planes, int* __restrict__ hist)
+{
+    __shared__ int bins[256];
+    const int f = blockIdx.y;
+    bins[threadIdx.x] = 0;
+    __syncthreads();
+    const int npx = h * w;
+    const uint8_t* src = bgr + (size_t)f * npx * 3;
+    uint8_t* dst = planes + (size_t)f * 3 * h * pitch;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) {
+        const int y = p / w, x = p - y * w;
+        const int g = (1868 * src[3 * (size_t)p] + 9617 * src[3 * (size_t)p + 1] + 4899 * src[3 * (size_t)p + 2] + (1 << 13)) >> 14;
+        const size_t o = (size_t)y * pitch + x;
+        dst[o] = (uint8_t)g;
+        dst[o + (size_t)h * pitch] = (uint8_t)g;
+        dst[o + (size_t)2 * h * pitch] = (uint8_t)g;
+        atomicAdd(&bins[g], 1);
+    }
+    __syncthreads();
+    if (bins[threadIdx.x]) atomicAdd(&hist[f * 256 + threadIdx.x], bins[threadIdx.x]);
+}
+
+__device__ __forceinline__ int wave_max_first(int val, int n)
+{
+    // largest val, smallest n among equals (the serial scan keeps the first angle that reaches the maximum)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int ov = __shfl_xor(val, d), on = __shfl_xor(n, d);
+        if (ov > val || (ov == val && on < n)) { val = ov; n = on; }
+    }
+    return (val << 8) | n;
+}
+
+// B: HoughLinesP of one zone per wave.  lines: up to CK_ZONE_LINES (x0, y0, x1, y1) int16 per zone, in the order found.
+__global__ __launch_bounds__(64) void hough_zones_kernel(const uint8_t* __restrict__ edges, int side, const int32_t* __restrict__ rects,
+                                                         const float* __restrict__ trig /* cos[180], sin[180] */, int numrho_max,
+                                                         int16_t* __restrict__ lines, int32_t* __restrict__ nlines, int* __restrict__ overflow)
+{
+    extern __shared__ int16_t acc[];                          // NANG x numrho counters, then the point list and the mask
+    const int z = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    const int x0 = rects[4 * z], y0 = rects[4 * z + 1], x1 = rects[4 * z + 2], y1 = rects[4 * z + 3];
+    const int height = x1 - x0, width = y1 - y0;              // the reference's x runs along rows
+    const int numrho = (width + height) * 2 + 1, half = (numrho - 1) / 2;
+    uint16_t* nzloc = reinterpret_cast<uint16_t*>(acc + NANG * numrho_max);
+    uint8_t* mask = reinterpret_cast<uint8_t*>(nzloc + ZMAX * ZMAX);
+    const int min_side = min(height, width);
+    const int threshold = (int)(min_side * 3 / 4.0), min_len = (int)(min_side * 2 / 3.0);     // int(min_side * 3 / 4), int(min_side * 2 / 3)
+    for (int i = lane; i < NANG * numrho; i += 64) acc[i] = 0;
+    // stage 1: the non-zero points in raster order
+    const uint8_t* img = edges + ((size_t)f * side + x0) * side + y0;
+    int count = 0;
+    for (int base = 0; base < height * width; base += 64) {
+        const int p = base + lane;
+        bool on = false;
+        if (p < height * width) {
+            const int i = p / width, j = p - i * width;
+            on = img[(size_t)i * side + j] != 0;
+            mask[p] = on ? 1 : 0;
+        }
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(on);
+        if (on) nzloc[count + __builtin_popcountll(b & ((1ull << lane) - 1ull))] = (uint16_t)p;
+        count += __builtin_popcountll(b);
+    }
+    __syncthreads();
+    float ct[3], st[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int n = lane + 64 * k;
+        ct[k] = n < NANG ? trig[n] : 0.f;
+        st[k] = n < NANG ? trig[NANG + n] : 0.f;
+    }
+    unsigned long long state = 0xFFFFFFFFFFFFFFFFull;          // RNG rng((uint64)-1)
+    int found = 0;
+    for (; count > 0; count--) {
+        state = (unsigned long long)(unsigned)state * 4164903690u + (state >> 32);
+        const int idx = (int)((unsigned)state % (unsigned)count);
+        const int p = nzloc[idx];
+        __syncthreads();
+        if (lane == 0) nzloc[idx] = nzloc[count - 1];
+        __syncthreads();
+        if (!mask[p]) continue;
+        const int i = p / width, j = p - i * width;
+        int best = threshold - 1, best_n = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int n = lane + 64 * k;
+            if (n < NANG) {
+                const int r = __float2int_rn((float)j * ct[k] + (float)i * st[k]) + half;
+                const int val = ++acc[n * numrho + r];
+                if (best < val) { best = val; best_n = n; }
+            }
+        }
+        const int packed = wave_max_first(best, best_n);
+        const int max_val = packed >> 8, max_n = packed & 255;
+        if (max_val < threshold) continue;
+        // walk from the point in both directions along the winning line (16.16 fixed point)
+        const float a = -trig[NANG + max_n], b = trig[max_n];
+        int xs = j, ys = i, dx0, dy0;
+        const bool xflag = fabsf(a) > fabsf(b);
+        if (xflag) {
+            dx0 = a > 0 ? 1 : -1;
+            dy0 = __float2int_rn(b * 65536.f / fabsf(a));
+            ys = (ys << 16) + (1 << 15);
+        } else {
+            dy0 = b > 0 ? 1 : -1;
+            dx0 = __float2int_rn(a * 65536.f / fabsf(b));
+            xs = (xs << 16) + (1 << 15);
+        }
+        int ex[2] = { j, j }, ey[2] = { i, i };
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            int x = xs, y = ys;
+            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+            for (;; x += dx, y += dy) {
+                const int j1 = xflag ? x : x >> 16, i1 = xflag ? y >> 16 : y;
+                if (j1 < 0 || j1 >= width || i1 < 0 || i1 >= height) break;
+                if (!mask[i1 * width + j1]) break;             // maxLineGap = 0: the first empty pixel ends the walk
+                ex[k] = j1; ey[k] = i1;
+            }
+        }
+        const bool good = abs(ex[1] - ex[0]) >= min_len || abs(ey[1] - ey[0]) >= min_len;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            int x = xs, y = ys;
+            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+            for (;; x += dx, y += dy) {
+                const int j1 = xflag ? x : x >> 16, i1 = xflag ? y >> 16 : y;
+                const int q = i1 * width + j1;
+                const bool on = mask[q] != 0;
+                __syncthreads();
+                if (on) {
+                    if (good) {
+#pragma unroll
+                        for (int kk = 0; kk < 3; kk++) {
+                            const int n = lane + 64 * kk;
+                            if (n < NANG) acc[n * numrho + __float2int_rn((float)j1 * ct[kk] + (float)i1 * st[kk]) + half]--;
+                        }
+                    }
+                    if (lane == 0) mask[q] = 0;
+                }
+                __syncthreads();
+                if (i1 == ey[k] && j1 == ex[k]) break;
+            }
+        }
+        if (good) {
+            if (found < CK_ZONE_LINES) {
+                if (lane == 0) {
+                    int16_t* o = lines + (((size_t)f * gridDim.x + z) * CK_ZONE_LINES + found) * 4;
+                    o[0] = (int16_t)ex[0]; o[1] = (int16_t)ey[0]; o[2] = (int16_t)ex[1]; o[3] = (int16_t)ey[1];
+                }
+            } else if (lane == 0) *overflow = 1;
+            found++;
+        }
+    }
+    if (lane == 0) nlines[(size_t)f * gridDim.x + z] = found;
+}
+
+}  // namespace
+
+int k_grid_lines(ck_ctx* ctx, const uint8_t* d_goban, int n, int side, const int32_t* rects, int16_t* lines, int32_t* nlines,
+                 uint8_t* edges_out)
+{
+    const int nz = GS * GS;
+    int zmax = 0;
+    for (int z = 0; z < nz; z++) {
+        const int32_t* q = rects + 4 * z;
+        if (q[0] < 0 || q[1] < 0 || q[2] > side || q[3] > side || q[2] <= q[0] || q[3] <= q[1])
+            return ck_fail(ctx, CK_ERR_ARG, "zone %d: rectangle (%d, %d, %d, %d) outside the %d image", z, q[0], q[1], q[2], q[3], side);
+        zmax = std::max(zmax, std::max(q[2] - q[0], q[3] - q[1]));
+    }
+    if (zmax > ZMAX) return ck_fail(ctx, CK_ERR_ARG, "intersection zone of %d pixels: at most %d", zmax, ZMAX);
+    const size_t fpx = (size_t)side * side, npx = fpx * n;
+    const int pitch = ck_pitch(side);
+    CK_TRY(ck_ensure(ctx, ctx->planes, (size_t)n * 3 * side * pitch));
+    CK_TRY(ck_ensure(ctx, ctx->misc, (size_t)n * 256 * 4 + 4096));
+    CK_TRY(ck_ensure(ctx, ctx->map, npx));
+    CK_TRY(ck_ensure(ctx, ctx->labels, npx * 4));
+    CK_TRY(ck_ensure(ctx, ctx->edges, npx));
+    int* d_hist = (int*)ctx->misc.p;
+    {
+        TimeScope ts(ctx, "grid_gray");
+        CK_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)n * 256 * 4, ctx->stream));
+        hipLaunchKernelGGL(gray_planes_hist_kernel, dim3(64, n), dim3(256), 0, ctx->stream, d_goban, side, side, pitch,
+                           (uint8_t*)ctx->planes.p, d_hist);
+        CK_HIP(ctx, hipGetLastError());
+    }
+    std::vector<int> hist((size_t)n * 256), thr((size_t)n * 2);
+    CK_HIP(ctx, hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f < n; f++) {
+        const double level = ck_otsu_level(&hist[(size_t)f * 256], fpx);
+        thr[2 * f] = (int)std::floor(level / 2);
+        thr[2 * f + 1] = (int)std::floor(level);
+    }
+    // small uploads share one buffer: thresholds, zone rectangles, trig table
+    std::vector<float> trig(2 * NANG);
+    {
+        const float theta = (float)(3.1415926535897932384626433832795 / 180);
+        for (int k = 0; k < NANG; k++) {
+            trig[k] = (float)cos((double)k * theta);
+            trig[NANG + k] = (float)sin((double)k * theta);
+        }
+    }
+    const size_t small = (size_t)n * 8 + (size_t)nz * 16 + trig.size() * 4 + 64;
+    CK_TRY(ck_ensure(ctx, ctx->mats, small));
+    int* d_thr = (int*)ctx->mats.p;
+    int32_t* d_rects = d_thr + (size_t)n * 2;
+    float* d_trig = (float*)(d_rects + (size_t)nz * 4);
+    int* d_over = (int*)(d_trig + trig.size());
+    CK_HIP(ctx, hipMemcpyAsync(d_thr, thr.data(), thr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    CK_HIP(ctx, hipMemcpyAsync(d_rects, rects, (size_t)nz * 16, hipMemcpyHostToDevice, ctx->stream));
+    CK_HIP(ctx, hipMemcpyAsync(d_trig, trig.data(), trig.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    CK_HIP(ctx, hipMemsetAsync(d_over, 0, 4, ctx->stream));
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));           // thr / trig are locals: the copies must be done before they go
+    CK_TRY(k_canny_planar(ctx, (const uint8_t*)ctx->planes.p, n, side, side, pitch, 0, 0, (uint8_t*)ctx->map.p,
+                          (int32_t*)ctx->labels.p, (uint8_t*)ctx->edges.p, nullptr, nullptr, d_thr));
+    const size_t line_bytes = (size_t)n * nz * CK_ZONE_LINES * 4 * sizeof(int16_t), cnt_bytes = (size_t)n * nz * 4;
+    CK_TRY(ck_ensure(ctx, ctx->pts, line_bytes + cnt_bytes + 64));
+    int16_t* d_lines = (int16_t*)ctx->pts.p;
+    int32_t* d_nlines = (int32_t*)((char*)ctx->pts.p + line_bytes);
+    {
+        TimeScope ts(ctx, "grid_hough");
+        const int numrho_max = 4 * zmax + 1;
+        const size_t lds = (size_t)NANG * numrho_max * 2 + (size_t)ZMAX * ZMAX * 2 + (size_t)ZMAX * ZMAX;
+        CK_HIP(ctx, hipFuncSetAttribute((const void*)hough_zones_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(hough_zones_kernel, dim3(nz, n), dim3(64), lds, ctx->stream, (const uint8_t*)ctx->edges.p, side,
+                           (const int32_t*)d_rects, (const float*)d_trig, numrho_max, d_lines, d_nlines, d_over);
+        CK_HIP(ctx, hipGetLastError());
+    }
+    int over = 0;
+    CK_HIP(ctx, hipMemcpyAsync(lines, d_lines, line_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CK_HIP(ctx, hipMemcpyAsync(nlines, d_nlines, cnt_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CK_HIP(ctx, hipMemcpyAsync(&over, d_over, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (edges_out) CK_HIP(ctx, hipMemcpyAsync(edges_out, ctx->edges.p, npx, hipMemcpyDeviceToHost, ctx->stream));
+    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (over) return ck_fail(ctx, CK_ERR_CAPACITY, "a zone gave more than %d lines", CK_ZONE_LINES);
+    return CK_OK;
+}

@@ -57,6 +57,32 @@ class PosGrid:
             self._zones = {key: hit}
         return hit
 
+    def learn(self, grid, rate=0.2):
+        """Drift correction (reference stonesfinder.py:1015-1043): `grid` is an updated copy of mtx (find_intersections'
+        answer, made positive); the mean displacement of the intersections that moved is blended into `adjust_vect` at
+        `rate`, and once more than 20 intersections have contributed the whole grid is shifted by it (truncated)."""
+        if not 0 < rate <= 1:
+            raise AssertionError("rate must lie in ]0, 1]")
+        shift = np.asarray(grid, np.int16) - self.mtx
+        if shift.min() < -200:
+            raise ValueError("Provided grid seems too far from original, at least for one point.")
+        movers = int(np.count_nonzero((shift != 0).any(-1)))
+        if not movers:
+            return
+        step = shift.sum(axis=(0, 1), dtype=np.float32)
+        step /= movers
+        keep = 1.0 - rate
+        self.adjust_vect *= keep                                   # float32 in place, as the reference's accumulator
+        self.adjust_vect += step * rate
+        self.adjust_contribs += movers
+        if self.adjust_contribs <= 20:
+            return
+        whole = self.adjust_vect.astype(np.int16)                   # truncated toward zero
+        print("Grid adjust vector : %s" % self.adjust_vect)
+        self.mtx += whole
+        self.adjust_vect.fill(0)
+        self.adjust_contribs = 0
+
 
 class DeletionWatch:
     """The user took a stone off (or moved it): that intersection is watched.  Over the next `samples` frames in which
@@ -219,6 +245,22 @@ class StonesFinder(VidProcessor):
     def get_foreground(self):
         return self._fg
 
+    # ---- empty intersections from grid lines ----------------------------------
+    def find_intersections(self, img, canvas=None):
+        """Which intersections show grid lines, hence no stone (reference stonesfinder.py:516-552): one library call
+        (ck_find_intersections: grey / Otsu / Canny and one HoughLinesP wave per zone on the GPU, update_grid on the
+        host) -> a copy of the grid with the positions where a line was found negated, and moved where a cross was.
+        `canvas` (the reference's drawing surface) is accepted and left alone."""
+        return self.ctx.find_intersections(np.ascontiguousarray(img, np.uint8), self._posgrid.mtx, self._posgrid.zones(1.0))
+
+    def get_intersections(self, img, display=False):
+        """cached per frame (reset in _doframe); the grid learns from every fresh answer (stonesfinder.py:554-576)"""
+        cached = self.intersections
+        if cached is None:
+            cached = self.intersections = self.find_intersections(img)
+            self._posgrid.learn(np.abs(cached))
+        return cached
+
     # ---- user corrections ------------------------------------------------------------------------
     def corrected(self, err_move, exp_move):
         pending = self.corrections
@@ -288,3 +330,8 @@ class StonesFinder(VidProcessor):
 
     def _window_name(self):
         return "camkifu.stone.stonesfinder.StonesFinder"
+
+
+def update_grid(lines, box, result_slot):
+    """reference stonesfinder.py:888-947, as a module function like there: the library's host routine"""
+    capi.update_grid(lines, box, result_slot)

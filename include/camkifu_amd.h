@@ -191,6 +191,22 @@ int ck_contour_stones(ck_ctx* ctx, const uint8_t* goban, const uint8_t* fg, int 
 int ck_contours_external(ck_ctx* ctx, const uint8_t* edges, int n, int h, int w, int in_space,
                          int32_t* counts, int32_t* table, int table_cap, int32_t* points, int points_cap);
 
+/* ---- StonesFinder.find_intersections for n goban images in one call                stone/stonesfinder.py:516-552
+ * grey image, Otsu level, Canny(gray, level / 2, level), then cv2.HoughLinesP(zone, 1, pi / 180, int(3/4 side),
+ * minLineLength=int(2/3 side), maxLineGap=0) in each of the 361 getrect zones and update_grid (:888-947) on what it finds.
+ * goban: n x side x side x 3 BGR in `in_space`; mtx: HOST 19*19*2 int16 = PosGrid.mtx; rects: HOST 19*19*4 int32 =
+ * StonesFinder.getrect(r, c).  Outputs on the HOST: grid n*19*19*2 int16 = the method's return value (positions negated
+ * where a line was found, moved where a cross was found); nullable: lines n*361*CK_ZONE_LINES*4 int16 (x0, y0, x1, y1 per
+ * line, in the order found), nlines n*361 int32, edges n*side*side (the Canny map). */
+#define CK_ZONE_LINES 32
+int ck_find_intersections(ck_ctx* ctx, const uint8_t* goban, int n, int side, int in_space, const int16_t* mtx, const int32_t* rects,
+                          int16_t* grid, int16_t* lines, int32_t* nlines, uint8_t* edges);
+
+/* update_grid for one zone (host only, no GPU needed)                                 stone/stonesfinder.py:888-947
+ * lines: k x (x0, y0, x1, y1) in the zone's own coordinates, box: getrect of the zone, slot: the intersection's int16
+ * (x, y), updated in place.  CK_ERR_ARG for a zero-length line (the reference divides by zero there). */
+int ck_update_grid(const int32_t* lines, int k, const int32_t* box, int16_t* slot);
+
 /* ======================================================================================================
  * Ordered (stateful) halves of the two finders -- host only, no GPU needed.  The per-frame finders call
  * them once per frame, the batch pipeline's fold calls them over the gathered per-frame records; the

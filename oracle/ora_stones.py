@@ -221,23 +221,24 @@ def stone_radius(size=380):
 
 
 def find_centers(dist, radius):
-    """sf_contours.py:302-330 -> list of (x, y)"""
-    dx, dy = dist.shape
-    nb_rows = int(round(dx / 2 / radius))
-    row_width = int(dx / nb_rows)
-    nb_cols = int(round(dy / 2 / radius))
-    col_width = int(dy / nb_cols)
+    """sf_contours.py:302-330 -> list of (x, y): the box is cut into cells of about one stone; a cell answers when the
+    farthest point from the contour lies within a third of the cell's smaller side of the cell centre"""
+    n_rows, n_cols = dist.shape
+    cells_down = int(round(n_rows / 2 / radius))          # Python's round: ties to even
+    cells_across = int(round(n_cols / 2 / radius))
+    cell_h = int(n_rows / cells_down)                     # ZeroDivisionError for a box thinner than a radius, as the reference
+    cell_w = int(n_cols / cells_across)
+    reach = min(cell_h, cell_w) / 3
     out = []
-    for row in range(nb_rows):
-        rs, re = row * row_width, (row + 1) * row_width
-        for col in range(nb_cols):
-            cs, ce = col * col_width, (col + 1) * col_width
-            sub = dist[rs:re + 1, cs:ce + 1]
-            k = int(np.argmax(sub))                   # first maximum, raster order
-            my, mx = divmod(k, sub.shape[1])
-            if min(row_width, col_width) / 3 < math.sqrt((mx - (ce - cs) / 2) ** 2 + (my - (re - rs) / 2) ** 2):
+    for a in range(cells_down):
+        top = a * cell_h
+        for b in range(cells_across):
+            left = b * cell_w
+            cell = dist[top:top + cell_h + 1, left:left + cell_w + 1]
+            my, mx = divmod(int(np.argmax(cell)), cell.shape[1])          # first maximum, raster order
+            if reach < math.sqrt((mx - cell_w / 2) ** 2 + (my - cell_h / 2) ** 2):
                 continue
-            out.append((cs + mx, rs + my))
+            out.append((left + mx, top + my))
     return out
 
 
@@ -293,45 +294,45 @@ def filter_contours(contours, radius):
         yield cont
 
 
+_AROUND = [(i, j) for i in (-1, 0, 1) for j in (-1, 0, 1) if (i, j) != (0, 0)]      # raster order, as the nested loops
+
+
 def find_color(r, c, zones, stones):
-    """sf_contours.py:128-184; `stones` (uint8 view, E/B/W = 0/1/2) is data and result slot"""
-    colors = set()
-    added = 0
-    for i in range(-1, 2):
-        if 0 <= r + i < zones.shape[0]:
-            for j in range(-1, 2):
-                if 0 == i and 0 == j:
-                    continue
-                if 0 <= c + j < zones.shape[1]:
-                    neigh = zones[r + i, c + j]
-                    raw = zones[r, c, 1:4].astype(np.int64) - neigh[1:4].astype(np.int64)
-                    sign = -1 if int(raw.sum()) < 0 else 1
-                    diff = sign * int(np.abs(raw).sum())
-                    if not neigh[0]:
-                        if 100 < abs(diff):
-                            colors.add(B if diff < 0 else W)
-                            added += 1
-                        elif abs(diff) < 70:
-                            colors.add(E)
-                            added = 3
-                    else:
-                        min_val = min(int(zones[r, c, 1:4].astype(np.int64).sum()), int(neigh[1:4].astype(np.int64).sum()))
-                        if i < 1 and j < 1:
-                            ns = int(stones[r + i, c + j])
-                            if ns not in (B, W):
-                                continue
-                            if abs(diff) < min_val * 0.1:
-                                colors.add(ns)
-                                added += 1
-                            elif min_val < abs(diff):
-                                colors.add(B if ns == W else W)
-                                added += 1
-                    if added == 3:
-                        break
-        if added == 3:
-            if len(colors) == 1:
-                stones[r, c] = colors.pop()
-            break
+    """sf_contours.py:128-184; `stones` (uint8 view, E/B/W = 0/1/2) is data and result slot.  The eight neighbours are
+    visited in raster order; each may cast a vote; the third vote (or one look-alike empty neighbour) ends the search,
+    and the zone takes a colour only if all votes agree."""
+    votes, cast = set(), 0
+    here = zones[r, c, 1:4].astype(np.int64)
+    for i, j in _AROUND:
+        rr, cc = r + i, c + j
+        if not (0 <= rr < zones.shape[0] and 0 <= cc < zones.shape[1]):
+            continue
+        other = zones[rr, cc, 1:4].astype(np.int64)
+        delta = here - other
+        gap = int(np.abs(delta).sum())                        # |diff|; the sign of the plain sum says darker or brighter
+        darker = int(delta.sum()) < 0
+        if not zones[rr, cc, 0]:                              # a neighbour seen as bare board
+            if gap > 100:
+                votes.add(B if darker else W)
+                cast += 1
+            elif gap < 70:
+                votes.add(E)
+                cast = 3
+        elif i < 1 and j < 1:                                 # a neighbour under a hull: only those already decided
+            theirs = int(stones[rr, cc])
+            if theirs not in (B, W):
+                continue
+            floor_ = min(int(here.sum()), int(other.sum()))
+            if gap < floor_ * 0.1:
+                votes.add(theirs)
+                cast += 1
+            elif floor_ < gap:
+                votes.add(B if theirs == W else W)
+                cast += 1
+        if cast == 3:
+            if len(votes) == 1:
+                stones[r, c] = votes.pop()
+            return
 
 
 def find_stones(img, fg, rs=0, re=GSIZE, cs=0, ce=GSIZE, want_all=False):
@@ -352,26 +353,20 @@ def find_stones(img, fg, rs=0, re=GSIZE, cs=0, ce=GSIZE, want_all=False):
     visible_sub = subimg * m3
     masked_sub = subimg * (1 - m3)
     zones = np.zeros((re - rs, ce - cs, 4), np.int16)
-    for r in range(zones.shape[0]):
-        for c in range(zones.shape[1]):
-            a0, b0, a1, b1 = getrect(r + rs, c + cs, size)
-            area = (a1 - a0) * (b1 - b0)
-            win = (slice(a0 - x0, a1 - x0), slice(b0 - y0, b1 - y0))
-            visible_area = int(mask[win].sum())
-            if 0.4 * area < visible_area:
-                zones[r, c, 0] = 1
-                src, norm = visible_sub[win], visible_area
-            else:
-                zones[r, c, 0] = 0
-                src, norm = masked_sub[win], area - visible_area
-            for k in range(3):
-                zones[r, c, k + 1] = int(int(src[:, :, k].sum()) / norm)
+    for zr, zc in np.ndindex(re - rs, ce - cs):
+        a0, b0, a1, b1 = getrect(zr + rs, zc + cs, size)
+        win = (slice(a0 - x0, a1 - x0), slice(b0 - y0, b1 - y0))
+        whole = (a1 - a0) * (b1 - b0)
+        seen = int(mask[win].sum())
+        under_hull = 0.4 * whole < seen                       # masked if more than 60 % of the zone is outside the hulls
+        src, norm = (visible_sub[win], seen) if under_hull else (masked_sub[win], whole - seen)
+        zones[zr, zc, 0] = 1 if under_hull else 0
+        zones[zr, zc, 1:] = [int(int(src[:, :, k].sum()) / norm) for k in range(3)]      # float mean, truncated into int16
     stones = np.zeros((GSIZE, GSIZE), np.uint8)
     view = stones[rs:re, cs:ce]
-    for r in range(zones.shape[0]):
-        for c in range(zones.shape[1]):
-            if zones[r, c, 0]:
-                find_color(r, c, zones, view)
+    for zr, zc in np.ndindex(re - rs, ce - cs):
+        if zones[zr, zc, 0]:
+            find_color(zr, zc, zones, view)
     if want_all:
         return stones, zones, mask, dict(fg=contours_fg, img=contours_img, canny=canny)
     return stones

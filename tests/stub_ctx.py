@@ -82,6 +82,14 @@ class OracleCtx:
         res = [ora_stones.find_stones(g, m, rs, re, cs, ce, want_all) for g, m in zip(goban, fg)]
         return tuple(np.stack([r[k] for r in res]) for k in range(3)) if want_all else np.stack(res)
 
+    def find_intersections(self, goban, mtx, rects, want_lines=False):
+        from oracle import ora_grid
+        goban = np.asarray(goban)
+        if goban.ndim == 3:
+            return ora_grid.find_intersections(goban, mtx, rects, want_lines)
+        res = [ora_grid.find_intersections(g, mtx, rects, want_lines) for g in goban]
+        return tuple(list(x) for x in zip(*res)) if want_lines else np.stack(res)
+
     def cnn_set_weights(self, weights):
         self.weights = {k: np.asarray(v, np.float32) for k, v in weights.items()}
 

@@ -206,3 +206,109 @@ def test_sfcontours_through_the_sequential_harness(quiet_game, monkeypatch):
     want = np.array([E, B, W], dtype=object)[truth]
     assert (got == want).mean() >= 0.97
     assert not controller.kifu.moves                  # as in the reference, the finder on its own submits nothing
+
+
+# ---- the grid-line search: find_intersections / update_grid / PosGrid.learn -------------------------------------
+def test_cv_rng_first_draws():
+    """cv::RNG((uint64)-1): multiply-with-carry with 4164903690; the first state is computed by hand"""
+    from oracle import ora_grid as G
+    r = G.CvRNG()
+    first = r.next()
+    assert r.state == (0xFFFFFFFF * 4164903690 + 0xFFFFFFFF) & 0xFFFFFFFFFFFFFFFF and first == r.state & 0xFFFFFFFF
+    draws = [G.CvRNG().uniform(0, k) for k in (1, 2, 10)]
+    assert draws[0] == 0 and all(0 <= d < k for d, k in zip(draws, (1, 2, 10)))
+
+
+def test_hough_lines_p_on_simple_zones():
+    from oracle import ora_grid as G
+    z = np.zeros((20, 20), np.uint8)
+    z[7, :] = 255
+    assert G.hough_lines_p(z, 15, 13) == [(0, 7, 19, 7)]
+    z[:] = 0
+    z[:, 12] = 255
+    (line,) = G.hough_lines_p(z, 15, 13)
+    assert {line[:2], line[2:]} == {(12, 0), (12, 19)}
+    z[:] = 0
+    z[7, 3:12] = 255                                    # too short for the vote threshold
+    assert G.hough_lines_p(z, 15, 13) == []
+    z[:] = 0
+    z[5, :] = 255
+    z[:, 5] = 255                                        # a cross: the second line lost its crossing pixel to the first
+    lines = G.hough_lines_p(z, 15, 13)
+    assert 1 <= len(lines) <= 2 and all(abs(l[2] - l[0]) >= 13 or abs(l[3] - l[1]) >= 13 for l in lines)
+
+
+def test_update_grid_library_matches_oracle():
+    """ck_update_grid (host only: no GPU needed) against the oracle on random line sets, every branch taken"""
+    from camkifu_amd import capi
+    from oracle import ora_grid as G
+    rng = np.random.default_rng(4)
+    box = (40, 60, 60, 80)
+    branches = set()
+    for _ in range(400):
+        k = int(rng.integers(1, 7))
+        lines = []
+        for _ in range(k):
+            kind = rng.integers(0, 4)
+            a, b = int(rng.integers(0, 6)), int(rng.integers(14, 20))
+            t = int(rng.integers(0, 20))
+            if kind == 0:
+                lines.append((a, t, b, t + int(rng.integers(-1, 2))))
+            elif kind == 1:
+                lines.append((t, a, t + int(rng.integers(-1, 2)), b))
+            elif kind == 2:
+                lines.append((a, a, b, b))
+            else:
+                lines.append(tuple(int(v) for v in rng.integers(0, 20, 4)))
+        lines = [l for l in lines if (l[0], l[1]) != (l[2], l[3])]
+        if not lines:
+            continue
+        want = np.array([50, 70], np.int16)
+        G.update_grid(lines, box, want)
+        got = np.array([50, 70], np.int16)
+        capi.update_grid(np.array(lines, np.int32).reshape(-1, 1, 4), box, got)
+        assert np.array_equal(got, want), (lines, got, want)
+        branches.add("same" if (want == (50, 70)).all() else "negated" if (want == (-50, -70)).all() else "moved")
+    assert branches == {"same", "negated", "moved"}
+    with pytest.raises(ZeroDivisionError):
+        capi.update_grid([(3, 3, 3, 3)], box, np.array([50, 70], np.int16))
+
+
+def test_posgrid_learn_matches_oracle():
+    from camkifu_amd.stone.stonesfinder import PosGrid
+    from oracle import ora_grid as G
+    pg, st = PosGrid(380), G.GridState(O.posgrid(380))
+    assert np.array_equal(pg.mtx, st.mtx)
+    rng = np.random.default_rng(2)
+    for step in range(12):
+        grid = pg.mtx.copy()
+        pick = rng.random((19, 19)) < 0.03 * (1 + step % 3)
+        grid[pick] += rng.integers(-3, 14, (int(pick.sum()), 2)).astype(np.int16)      # a drift, mostly one way
+        pg.learn(grid, 0.2)
+        st.learn(grid, 0.2)
+        assert np.array_equal(pg.mtx, st.mtx) and np.array_equal(pg.adjust_vect, st.adjust_vect) and pg.adjust_contribs == st.adjust_contribs
+    assert not np.array_equal(pg.mtx, O.posgrid(380))                # the grid did move at some point
+    far = pg.mtx.copy()
+    far[0, 0] -= 300
+    with pytest.raises(ValueError):
+        pg.learn(far)
+
+
+def test_get_intersections_through_the_finder(quiet_game, monkeypatch):
+    """StonesFinder.get_intersections: cached per frame, the grid learns from it (oracle-backed context)"""
+    from camkifu_amd import capi
+    from camkifu_amd.stone.sf_contours import SfContours
+    from oracle import ora_grid as G
+    from .stub_ctx import OracleCtx
+    _, _, truth, gob, _ = quiet_game
+
+    class Manager:
+        device, current_video, controller = 0, None, None
+
+    sf = SfContours(Manager(), ctx=OracleCtx())
+    first = sf.get_intersections(gob)
+    assert first is sf.get_intersections(gob)
+    rects = np.array([[O.sf_getrect(r, c) for c in range(19)] for r in range(19)], np.int32)
+    assert np.array_equal(first, G.find_intersections(gob, O.posgrid(380), rects))
+    empty_seen = first[:, :, 0] < 0
+    assert empty_seen.sum() > 100 and not (empty_seen & (truth > 0)).any()

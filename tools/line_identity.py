@@ -25,6 +25,9 @@ PAIRS = [
     ("camkifu_amd/pipeline.py", "stone/sf_neural.py"),
     ("oracle/ora_logic.py", "stone/sf_neural.py"),
     ("oracle/ora_logic.py", "core/imgutil.py"),
+    ("oracle/ora_stones.py", "stone/sf_contours.py"),
+    ("oracle/ora_grid.py", "stone/stonesfinder.py"),
+    ("oracle/ora_grid.py", "core/imgutil.py"),
 ]
 
 
