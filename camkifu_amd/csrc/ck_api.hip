@@ -7,6 +7,8 @@
 #include <cmath>
 #include <algorithm>
 #include <vector>
+#include <thread>
+
 #include "ck_common.h"
 #include "ck_stonegeom.h"
 
@@ -653,22 +655,30 @@ int ck_find_intersections(ck_ctx* ctx, const uint8_t* goban, int n, int side, in
     CK_HIP(ctx, hipSetDevice(ctx->device));
     const void* d_img;
     CK_TRY(ck_to_device(ctx, goban, (size_t)n * side * side * 3, in_space, ctx->in_stage, &d_img));
-    std::vector<int16_t> own_lines;
-    std::vector<int32_t> own_counts;
-    if (!lines) { own_lines.resize((size_t)n * 361 * CK_ZONE_LINES * 4); lines = own_lines.data(); }
-    if (!nlines) { own_counts.resize((size_t)n * 361); nlines = own_counts.data(); }
-    CK_TRY(k_grid_lines(ctx, (const uint8_t*)d_img, n, side, rects, lines, nlines, edges));
-    int32_t seg[CK_ZONE_LINES * 4];
-    for (int f = 0; f < n; f++) {
+    const int16_t* found;
+    const int32_t* counts;
+    CK_TRY(k_grid_lines(ctx, (const uint8_t*)d_img, n, side, rects, &found, &counts, edges));
+    if (lines) memcpy(lines, found, (size_t)n * 361 * CK_ZONE_LINES * 4 * sizeof(int16_t));
+    if (nlines) memcpy(nlines, counts, (size_t)n * 361 * sizeof(int32_t));
+    // update_grid, zone by zone; images are independent: a few host threads share them
+    auto one_image = [&](int f) {
+        int32_t seg[CK_ZONE_LINES * 4];
         int16_t* g = grid + (size_t)f * 361 * 2;
         memcpy(g, mtx, 361 * 2 * sizeof(int16_t));
         for (int z = 0; z < 361; z++) {
-            const int k = nlines[(size_t)f * 361 + z];
+            const int k = counts[(size_t)f * 361 + z];
             if (!k) continue;
-            const int16_t* l = lines + ((size_t)f * 361 + z) * CK_ZONE_LINES * 4;
+            const int16_t* l = found + ((size_t)f * 361 + z) * CK_ZONE_LINES * 4;
             for (int i = 0; i < k * 4; i++) seg[i] = l[i];
             ck_update_grid_host(seg, k, rects + 4 * z, g + 2 * z);
         }
+    };
+    const int nt = std::min(n, 8);
+    if (nt <= 1) one_image(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++) th.emplace_back([&, t]() { for (int f = t; f < n; f += nt) one_image(f); });
+        for (auto& t : th) t.join();
     }
     return finish(ctx);
 }

@@ -151,8 +151,9 @@ int k_contour_stones(ck_ctx* ctx, const uint8_t* d_goban, const uint8_t* d_fg, i
                      int rs, int re, int cs, int ce, uint8_t* stones, int16_t* zones_out, uint8_t* mask_out);
 double ck_otsu_level(const int* hist, size_t npx);                        // ck_api.hip: getThreshVal_Otsu_8u restated
 // StonesFinder.find_intersections, device half: Canny of the grey image + HoughLinesP of the 361 zones -> host tables
-int k_grid_lines(ck_ctx* ctx, const uint8_t* d_goban, int n, int side, const int32_t* rects, int16_t* lines, int32_t* nlines,
-                 uint8_t* edges_out);
+// (*lines_out / *nlines_out point into the context's pinned host arena: valid until the next call on this context)
+int k_grid_lines(ck_ctx* ctx, const uint8_t* d_goban, int n, int side, const int32_t* rects, const int16_t** lines_out,
+                 const int32_t** nlines_out, uint8_t* edges_out);
 int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int n, float* d_y, uint8_t* d_labels, double* d_conf,
                   int* d_nonfinite = nullptr, uint8_t* d_rlabel = nullptr, double* d_rconf = nullptr);
 int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space);

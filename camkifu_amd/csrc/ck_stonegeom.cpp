@@ -196,7 +196,9 @@ void ck_update_grid_host(const int32_t* lines, int k, const int32_t* box, int16_
     auto inside = [&](double px, double py) {
         return box[0] + margin < px && px < box[2] - margin && box[1] + margin < py && py < box[3] - margin;
     };
-    std::vector<const int32_t*> kept;
+    const int32_t* kept_buf[64];
+    struct { const int32_t** p; int n; bool empty() const { return n == 0; } size_t size() const { return (size_t)n; }
+             void push_back(const int32_t* c) { if (n < 64) p[n++] = c; } const int32_t* operator[](size_t i) const { return p[i]; } } kept = { kept_buf, 0 };
     for (int i = 0; i < k; i++) {
         const int32_t* c = lines + 4 * (size_t)i;
         const long long ddx = (long long)c[0] - c[2], ddy = (long long)c[1] - c[3];

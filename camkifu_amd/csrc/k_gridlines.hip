@@ -9,7 +9,7 @@
 //    for the whole batch; Canny is K2's kernel with per-image thresholds.
 // B  the progressive probabilistic Hough transform is serial in its points (each accepted line removes pixels the
 //    next draw may have hit) but the 361 x n zones are independent and tiny: ONE WAVE PER ZONE.  The 180 x numrho
-//    accumulator of a zone (16-bit counters) lives in LDS, the lanes share the 180 angles of every vote and
+//    accumulator of a zone (signed 8-bit counters) lives in LDS, the lanes share the 180 angles of every vote and
 //    un-vote, the random draw (cv::RNG, seeded the same for every call of the library function), the fixed-point walk
 //    along the winning line and the bookkeeping are wave-uniform.
 #include <math.h>
@@ -48,30 +48,35 @@ __global__ __launch_bounds__(256) void gray_planes_hist_kernel(const uint8_t* __
 
 __device__ __forceinline__ int wave_max_first(int val, int n)
 {
-    // largest val, smallest n among equals (the serial scan keeps the first angle that reaches the maximum)
+    // largest val, smallest n among equals (the serial scan keeps the first angle that reaches the maximum): one key
+    int key = (val << 8) | (255 - n);
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int ov = __shfl_xor(val, d), on = __shfl_xor(n, d);
-        if (ov > val || (ov == val && on < n)) { val = ov; n = on; }
-    }
-    return (val << 8) | n;
+    for (int d = 32; d >= 1; d >>= 1) key = max(key, __shfl_xor(key, d));
+    return (key & ~255) | (255 - (key & 255));
 }
 
 // B: HoughLinesP of one zone per wave.  lines: up to CK_ZONE_LINES (x0, y0, x1, y1) int16 per zone, in the order found.
+// A counter stays within +- the number of zone pixels in one line's band (< 64 for ZMAX = 40; it goes NEGATIVE where a
+// kept line takes back the votes of pixels that had not been drawn yet, as in the library): signed 8-bit counters, so
+// several zones share a CU's LDS.  The walk along the winning line is closed-form (step t of direction k is start + t * delta): every
+// lane tests one step, a ballot finds where the line ends -- no chain of dependent LDS reads.
 __global__ __launch_bounds__(64) void hough_zones_kernel(const uint8_t* __restrict__ edges, int side, const int32_t* __restrict__ rects,
-                                                         const float* __restrict__ trig /* cos[180], sin[180] */, int numrho_max,
+                                                         const float* __restrict__ trig /* cos[180], sin[180] */, int numrho_max, int zpx /* largest zone, pixels */,
                                                          int16_t* __restrict__ lines, int32_t* __restrict__ nlines, int* __restrict__ overflow)
 {
-    extern __shared__ int16_t acc[];                          // NANG x numrho counters, then the point list and the mask
+    extern __shared__ int8_t acc[];                            // NANG x numrho counters, then the mask and the point list
     const int z = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
     const int x0 = rects[4 * z], y0 = rects[4 * z + 1], x1 = rects[4 * z + 2], y1 = rects[4 * z + 3];
     const int height = x1 - x0, width = y1 - y0;              // the reference's x runs along rows
     const int numrho = (width + height) * 2 + 1, half = (numrho - 1) / 2;
-    uint16_t* nzloc = reinterpret_cast<uint16_t*>(acc + NANG * numrho_max);
-    uint8_t* mask = reinterpret_cast<uint8_t*>(nzloc + ZMAX * ZMAX);
+    uint8_t* mask = reinterpret_cast<uint8_t*>(acc) + ((NANG * numrho_max + 3) & ~3);
+    uint16_t* nzloc = reinterpret_cast<uint16_t*>(mask + zpx);
     const int min_side = min(height, width);
     const int threshold = (int)(min_side * 3 / 4.0), min_len = (int)(min_side * 2 / 3.0);     // int(min_side * 3 / 4), int(min_side * 2 / 3)
-    for (int i = lane; i < NANG * numrho; i += 64) acc[i] = 0;
+    {
+        uint32_t* a4 = reinterpret_cast<uint32_t*>(acc);
+        for (int i = lane; i < (NANG * numrho + 3) / 4; i += 64) a4[i] = 0;
+    }
     // stage 1: the non-zero points in raster order
     const uint8_t* img = edges + ((size_t)f * side + x0) * side + y0;
     int count = 0;
@@ -100,11 +105,11 @@ __global__ __launch_bounds__(64) void hough_zones_kernel(const uint8_t* __restri
     for (; count > 0; count--) {
         state = (unsigned long long)(unsigned)state * 4164903690u + (state >> 32);
         const int idx = (int)((unsigned)state % (unsigned)count);
-        const int p = nzloc[idx];
+        const int p = nzloc[idx], last = nzloc[count - 1];
+        const bool live = mask[p] != 0;
         __syncthreads();
-        if (lane == 0) nzloc[idx] = nzloc[count - 1];
-        __syncthreads();
-        if (!mask[p]) continue;
+        if (lane == 0) nzloc[idx] = (uint16_t)last;            // "remove" the point by overriding it with the last one
+        if (!live) continue;
         const int i = p / width, j = p - i * width;
         int best = threshold - 1, best_n = 0;
 #pragma unroll
@@ -116,11 +121,13 @@ __global__ __launch_bounds__(64) void hough_zones_kernel(const uint8_t* __restri
                 if (best < val) { best = val; best_n = n; }
             }
         }
-        const int packed = wave_max_first(best, best_n);
-        const int max_val = packed >> 8, max_n = packed & 255;
-        if (max_val < threshold) continue;
-        // walk from the point in both directions along the winning line (16.16 fixed point)
-        const float a = -trig[NANG + max_n], b = trig[max_n];
+        if (!__builtin_amdgcn_ballot_w64(best >= threshold)) continue;      // too weak a candidate (the usual case): next point
+        const int max_n = wave_max_first(best, best_n) & 255;
+        // the winning line's direction, from the lane that holds its angle
+        const int src = max_n & 63, kk = max_n >> 6;
+        const float cs_n = __shfl(kk == 0 ? ct[0] : (kk == 1 ? ct[1] : ct[2]), src);
+        const float sn_n = __shfl(kk == 0 ? st[0] : (kk == 1 ? st[1] : st[2]), src);
+        const float a = -sn_n, b = cs_n;
         int xs = j, ys = i, dx0, dy0;
         const bool xflag = fabsf(a) > fabsf(b);
         if (xflag) {
@@ -132,42 +139,39 @@ __global__ __launch_bounds__(64) void hough_zones_kernel(const uint8_t* __restri
             dx0 = __float2int_rn(a * 65536.f / fabsf(b));
             xs = (xs << 16) + (1 << 15);
         }
-        int ex[2] = { j, j }, ey[2] = { i, i };
+        // walk both ways over the remaining points: lane t looks at step t; maxLineGap = 0, so the first empty pixel
+        // (or the zone border) ends the line.  Step 0 is the point itself.
+        int qk[2], endt[2], ex[2], ey[2];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            int x = xs, y = ys;
-            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
-            for (;; x += dx, y += dy) {
-                const int j1 = xflag ? x : x >> 16, i1 = xflag ? y >> 16 : y;
-                if (j1 < 0 || j1 >= width || i1 < 0 || i1 >= height) break;
-                if (!mask[i1 * width + j1]) break;             // maxLineGap = 0: the first empty pixel ends the walk
-                ex[k] = j1; ey[k] = i1;
-            }
+            const int x = xs + lane * (k ? -dx0 : dx0), y = ys + lane * (k ? -dy0 : dy0);
+            const int j1 = xflag ? x : x >> 16, i1 = xflag ? y >> 16 : y;
+            const bool inb = j1 >= 0 && j1 < width && i1 >= 0 && i1 < height;
+            qk[k] = i1 * width + j1;
+            const bool ok = inb && mask[inb ? qk[k] : 0] != 0;
+            const unsigned long long stop = ~__builtin_amdgcn_ballot_w64(ok);      // a zone side is < 64: some lane always stops
+            endt[k] = __builtin_ctzll(stop) - 1;
+            ex[k] = __shfl(j1, endt[k]);
+            ey[k] = __shfl(i1, endt[k]);
         }
         const bool good = abs(ex[1] - ex[0]) >= min_len || abs(ey[1] - ey[0]) >= min_len;
+        if (good) {
+            // take the votes of the line's points back (the point itself once)
+            for (int k = 0; k < 2; k++)
+                for (int t = k; t <= endt[k]; t++) {
+                    const int q = __shfl(qk[k], t);
+                    const int i1 = q / width, j1 = q - i1 * width;
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            int x = xs, y = ys;
-            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
-            for (;; x += dx, y += dy) {
-                const int j1 = xflag ? x : x >> 16, i1 = xflag ? y >> 16 : y;
-                const int q = i1 * width + j1;
-                const bool on = mask[q] != 0;
-                __syncthreads();
-                if (on) {
-                    if (good) {
-#pragma unroll
-                        for (int kk = 0; kk < 3; kk++) {
-                            const int n = lane + 64 * kk;
-                            if (n < NANG) acc[n * numrho + __float2int_rn((float)j1 * ct[kk] + (float)i1 * st[kk]) + half]--;
-                        }
+                    for (int c = 0; c < 3; c++) {
+                        const int n = lane + 64 * c;
+                        if (n < NANG) acc[n * numrho + __float2int_rn((float)j1 * ct[c] + (float)i1 * st[c]) + half]--;
                     }
-                    if (lane == 0) mask[q] = 0;
                 }
-                __syncthreads();
-                if (i1 == ey[k] && j1 == ex[k]) break;
-            }
         }
+        __syncthreads();
+        if (lane <= endt[0]) mask[qk[0]] = 0;
+        if (lane <= endt[1]) mask[qk[1]] = 0;
+        __syncthreads();
         if (good) {
             if (found < CK_ZONE_LINES) {
                 if (lane == 0) {
@@ -183,8 +187,8 @@ __global__ __launch_bounds__(64) void hough_zones_kernel(const uint8_t* __restri
 
 }  // namespace
 
-int k_grid_lines(ck_ctx* ctx, const uint8_t* d_goban, int n, int side, const int32_t* rects, int16_t* lines, int32_t* nlines,
-                 uint8_t* edges_out)
+int k_grid_lines(ck_ctx* ctx, const uint8_t* d_goban, int n, int side, const int32_t* rects, const int16_t** lines_out,
+                 const int32_t** nlines_out, uint8_t* edges_out)
 {
     const int nz = GS * GS;
     int zmax = 0;
@@ -247,15 +251,20 @@ int k_grid_lines(ck_ctx* ctx, const uint8_t* d_goban, int n, int side, const int
     {
         TimeScope ts(ctx, "grid_hough");
         const int numrho_max = 4 * zmax + 1;
-        const size_t lds = (size_t)NANG * numrho_max * 2 + (size_t)ZMAX * ZMAX * 2 + (size_t)ZMAX * ZMAX;
+        const int zpx = (zmax * zmax + 3) & ~3;
+        const size_t lds = (((size_t)NANG * numrho_max + 3) & ~(size_t)3) + (size_t)zpx * 3;
         CK_HIP(ctx, hipFuncSetAttribute((const void*)hough_zones_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(hough_zones_kernel, dim3(nz, n), dim3(64), lds, ctx->stream, (const uint8_t*)ctx->edges.p, side,
-                           (const int32_t*)d_rects, (const float*)d_trig, numrho_max, d_lines, d_nlines, d_over);
+                           (const int32_t*)d_rects, (const float*)d_trig, numrho_max, zpx, d_lines, d_nlines, d_over);
         CK_HIP(ctx, hipGetLastError());
     }
     int over = 0;
-    CK_HIP(ctx, hipMemcpyAsync(lines, d_lines, line_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    CK_HIP(ctx, hipMemcpyAsync(nlines, d_nlines, cnt_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CK_TRY(ck_ensure_pinned(ctx, line_bytes + cnt_bytes + 64));       // the tables are mostly empty: a pinned landing area, read in place
+    int16_t* lines = (int16_t*)ctx->host_pinned;
+    int32_t* nlines = (int32_t*)((char*)ctx->host_pinned + line_bytes);
+    *lines_out = lines;
+    *nlines_out = nlines;
+    CK_HIP(ctx, hipMemcpyAsync(lines, d_lines, line_bytes + cnt_bytes, hipMemcpyDeviceToHost, ctx->stream));
     CK_HIP(ctx, hipMemcpyAsync(&over, d_over, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (edges_out) CK_HIP(ctx, hipMemcpyAsync(edges_out, ctx->edges.p, npx, hipMemcpyDeviceToHost, ctx->stream));
     CK_HIP(ctx, hipStreamSynchronize(ctx->stream));

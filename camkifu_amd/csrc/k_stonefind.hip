@@ -115,10 +115,11 @@ void frames_parallel(int n, F fn)
 
 struct Box { float w, h, angle; };
 
-Box box_of(const CkContour& c)
+// minAreaRect of a contour from its hull (the hull of a hull is itself: the big sort runs once per contour)
+Box box_of(const std::vector<int32_t>& hull)
 {
     float wha[3];
-    ck_min_area_rect_box(c.pts.data(), (int)(c.pts.size() / 2), wha);
+    ck_min_area_rect_box(hull.data(), (int)(hull.size() / 2), wha);
     return { wha[0], wha[1], wha[2] };
 }
 
@@ -131,13 +132,13 @@ int fg_contours(const std::vector<CkContour>& found, const uint8_t* sub_fg, int 
     std::vector<uint8_t> bits;
     for (const CkContour& c : found) {
         if (c.nvert < 10) continue;                                   // too few points to describe a stone
-        const Box b = box_of(c);
+        const std::vector<int32_t> hull = ck_hull_points(c.pts.data(), (int)(c.pts.size() / 2));
+        const Box b = box_of(hull);
         const double lo = std::min(b.w, b.h), hi = std::max(b.w, b.h);
         if (lo < 3.0 / 2 * radius) continue;                          // one side too small
         if (5 * radius < hi) continue;                                // two stones at most
         const double angle = (double)b.angle * (3.14159265358979323846 / 180.0);          // math.radians
         if (2.5 * radius < hi && std::max(std::fabs(std::cos(angle)), std::fabs(std::sin(angle))) < 0.97) continue;
-        const std::vector<int32_t> hull = ck_hull_points(c.pts.data(), (int)(c.pts.size() / 2));
         int bx, by, bw, bh;
         ck_raster_polygon(hull.data(), (int)(hull.size() / 2), &bx, &by, &bw, &bh, bits);
         long long sum = 0;
@@ -240,16 +241,18 @@ int k_contour_stones(ck_ctx* ctx, const uint8_t* d_goban, const uint8_t* d_fg, i
     frames_parallel(n, [&](int f) {
         std::vector<const CkContour*> kept;
         if (fg_contours(found[f], h_fg + (size_t)f * spx, hs, ws, radius, kept) < 0) { bad[f] = 1; return; }
+        std::vector<std::vector<int32_t>> hulls;
+        for (const CkContour* c : kept) hulls.push_back(ck_hull_points(c->pts.data(), (int)(c->pts.size() / 2)));
         for (const CkContour& c : found[(size_t)n + f]) {                    // _filter_contours
             if (c.nvert < 10) continue;
-            const Box b = box_of(c);
+            std::vector<int32_t> hull = ck_hull_points(c.pts.data(), (int)(c.pts.size() / 2));
+            const Box b = box_of(hull);
             if (10 * radius < std::max(b.w, b.h)) continue;
-            kept.push_back(&c);
+            hulls.push_back(std::move(hull));
         }
         std::vector<uint8_t> bits;
         auto& sp = spans[f];
-        for (const CkContour* c : kept) {
-            const std::vector<int32_t> hull = ck_hull_points(c->pts.data(), (int)(c->pts.size() / 2));
+        for (const std::vector<int32_t>& hull : hulls) {
             int bx, by, bw, bh;
             ck_raster_polygon(hull.data(), (int)(hull.size() / 2), &bx, &by, &bw, &bh, bits);
             for (int y = 0; y < bh; y++)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Timing of ck_contour_stones (SfContours.find_stones) on goban images resident in HBM: images/s
-at a few batch sizes, HIP-event time per stage, and (CK_PROFILE_HOST=1) the host laps of the call on stderr.
-    python tools/contour_stones_timing.py [--n 256] [--reps 5] [--cpu 2]"""
+"""Timing of SURVEY 8f rank 3 on goban images resident in HBM: ck_contour_stones (SfContours.find_stones) and
+ck_find_intersections (StonesFinder.find_intersections) -- images/s at a few batch sizes, HIP-event time per stage,
+the CPU oracle beside them, and (CK_PROFILE_HOST=1) the host laps of ck_contour_stones on stderr.
+    python tools/stonefind_timing.py [--n 256] [--reps 5] [--cpu 2]"""
 import argparse
 import json
 import os
@@ -64,7 +65,41 @@ def main():
         ref = [ora_stones.find_stones(a, b) for a, b in zip(gh, mh)]
         out["cpu_oracle"] = dict(images_per_s=round(args.cpu / (time.perf_counter() - t0), 2), kind="port", note="numpy + C restatement, one core")
         out["cpu_oracle"]["equal"] = bool(all(np.array_equal(r, s) for r, s in zip(ref, stones[len(stones) - args.cpu:])))
-    print(json.dumps(out))
+    # ---- find_intersections ----
+    mtx = PosGrid(380).mtx
+    gi = {}
+    for b in sorted({1, 64, n}):
+        if b > n:
+            continue
+        g = gobans[n - b:].contiguous()
+        ctx.find_intersections(g, mtx, rects)
+        t = []
+        for _ in range(args.reps):
+            t0 = time.perf_counter()
+            grid = ctx.find_intersections(g, mtx, rects)
+            t.append(time.perf_counter() - t0)
+        gi["batch_%d" % b] = dict(images_per_s=round(b / float(np.median(t)), 1), ms_per_call=round(1e3 * float(np.median(t)), 3))
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    ctx.find_intersections(gobans, mtx, rects)
+    stages = {}
+    for name in ("grid_gray", "canny_nms", "canny_hyst", "grid_hough"):
+        try:
+            ms, k = ctx.timing_get(name)
+            stages[name] = dict(us_per_image=round(1e3 * ms / n, 3), launches=k)
+        except Exception:
+            pass
+    ctx.timing_enable(False)
+    gi["stages_batch_%d" % n] = stages
+    gi["zones_seen_empty_per_image"] = round(float((grid[..., 0] < 0).sum()) / len(grid), 1)
+    if args.cpu:
+        from oracle import ora_grid
+        gh = gobans[n - args.cpu:].cpu().numpy()
+        t0 = time.perf_counter()
+        ref = [ora_grid.find_intersections(a, mtx, rects) for a in gh]
+        gi["cpu_oracle"] = dict(images_per_s=round(args.cpu / (time.perf_counter() - t0), 2), kind="port", note="numpy restatement, one core",
+                                equal=bool(all(np.array_equal(r, s) for r, s in zip(ref, grid[len(grid) - args.cpu:]))))
+    print(json.dumps({"contour_stones": out, "find_intersections": gi}))
 
 
 if __name__ == "__main__":
