@@ -459,6 +459,28 @@ def main():
                 ctx.timing_enable(False)
                 k1[name] = dict(us_per_frame=round(1e3 * ms / 8, 2), thresholds_per_tile=round(thresholds_per_tile(med), 2))
             out_line["k1_content"] = k1
+            # SURVEY 8f rank 3 on the same film: SfContours.find_stones and StonesFinder.find_intersections, 64 goban images
+            # per call, images resident in HBM (foreground masks from a model run over those frames in order)
+            from camkifu_amd.stone.stonesfinder import PosGrid
+            nb = min(64, F)
+            gob = torch.empty((nb, 380, 380, 3), dtype=torch.uint8, device=dev)
+            ctx.warp_perspective(frames[:nb], M, out=gob)
+            hbg = ctx.mog2_create(380, 380)
+            fgs = torch.stack([torch.as_tensor(ctx.mog2_apply(hbg, gob[i], 0.01)) for i in range(nb)]).to(dev)
+            ctx.mog2_destroy(hbg)
+            pg = PosGrid(380)
+            rank3 = {}
+            for name, call in (("find_stones", lambda: ctx.contour_stones(gob, fgs, pg.zones(1.0))),
+                               ("find_intersections", lambda: ctx.find_intersections(gob, pg.mtx, pg.zones(1.0)))):
+                call()
+                ts = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    res = call()
+                    ts.append(time.perf_counter() - t0)
+                rank3[name] = dict(value=round(nb / float(np.median(ts)), 1), unit="goban images/s", batch=nb)
+            rank3["find_stones"]["grid_agreement_with_truth_pct"] = round(100.0 * float((ctx.contour_stones(gob, fgs, pg.zones(1.0))[-1] == np.asarray(truth[nb - 1])).mean()), 2)
+            out_line["survey_8f_rank3"] = rank3
             cv = cv2_crosscheck(ctx, frames, M)
             out_line["cv2_version"] = cv.pop("cv2")
             if cv:
