@@ -12,6 +12,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3
 echo "bench stats done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -- python3 tools/board_serial.py > $O/board_serial.log 2> $O/prof_serial.err
 echo "serial stats done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stonefind -- python3 tools/stonefind_timing.py --reps 3 --cpu 0 > $O/stonefind_prof.json 2> $O/prof_stonefind.err
+echo "stonefind stats done"
+# the per-launch traces are large and not needed once the stats exist (gpurun merges back at most 64 MiB)
+find $O/prof_bench $O/prof_serial $O/prof_stonefind -name "*kernel_trace.csv" -delete 2>/dev/null || true
+find $O/prof_bench $O/prof_serial $O/prof_stonefind -name "*.db" -delete 2>/dev/null || true
 PMCARGS="--steps 1 --warmup 0 --frames 64 --lanes 1 --no-cpu-baseline --no-extras"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py $PMCARGS > /dev/null 2> $O/pmc_fetch.err
 echo "fetch done"
@@ -19,5 +24,9 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write --
 echo "write done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc_valu -- python3 bench.py $PMCARGS > /dev/null 2> $O/pmc_valu.err
 echo "valu done"
+find $O/pmc_fetch $O/pmc_write $O/pmc_valu -name "*.db" -delete 2>/dev/null || true
+du -sh $O | tail -1
 python bench.py > $O/bench_full.json 2> $O/bench_full.err
 echo "bench done"
+python tools/stonefind_timing.py > $O/stonefind_timing.json 2> $O/stonefind_timing.err
+echo "stonefind timing done"

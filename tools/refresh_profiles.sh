@@ -4,13 +4,13 @@
 set -e
 cd "$(dirname "$0")/.."
 R=${ROUND:-r02}
-rm -rf gpurun_out/prof_bench gpurun_out/prof_serial gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_valu
+rm -rf gpurun_out/prof_bench gpurun_out/prof_serial gpurun_out/prof_stonefind gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_valu
 /usr/local/graft/bin/gpurun --timeout 1100 -- 'timeout -k 10 1000 bash tools/collect_profiles.sh' > /tmp/collect.log 2>&1 || { tail -20 /tmp/collect.log; exit 1; }
 python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write 64 profiles/${R}_pmc_traffic.json gpurun_out/pmc_valu > /dev/null
 python - "$R" <<'PY'
 import csv, glob, json, sys
 R = sys.argv[1]
-for tag, d in (("bench", "prof_bench"), ("serial", "prof_serial")):
+for tag, d in (("bench", "prof_bench"), ("serial", "prof_serial"), ("stonefind", "prof_stonefind")):
     src = glob.glob("gpurun_out/%s/*/*kernel_stats.csv" % d)[0]
     rows = [r for r in csv.DictReader(open(src))]
     keep = [r for r in rows if "at::native" not in r["Name"] and "rocprim" not in r["Name"] and "__amd_rocclr" not in r["Name"]]
@@ -18,6 +18,7 @@ for tag, d in (("bench", "prof_bench"), ("serial", "prof_serial")):
         w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
         w.writeheader()
         w.writerows(keep)          # this package's kernels only (the renderer's torch kernels are dropped; percentages are of the whole run)
+open("profiles/%s_stonefind_timing.json" % R, "w").write([l for l in open("gpurun_out/stonefind_timing.json") if l.startswith("{")][-1])
 line = [l for l in open("gpurun_out/bench_full.json") if l.startswith("{")][-1]
 open("profiles/%s_bench.json" % R, "w").write(line)
 d = json.loads(line)
