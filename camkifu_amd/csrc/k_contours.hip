@@ -514,8 +514,10 @@ __global__ __launch_bounds__(256) void survey_points_kernel(int h, int w, const 
 // border follower from the pixel the raster scan would start it at -- the first pixel of the component, which is the
 // union-find root -- reading the edge bytes only: the marks the serial algorithm writes into its image steer where
 // LATER borders start, never the path of the one being followed.  A vertex is stored where the step direction changes.
-__constant__ int8_t TRACE_DX[8] = { 1, 1, 0, -1, -1, -1, 0, 1 };      // 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE (y grows downwards)
-__constant__ int8_t TRACE_DY[8] = { 0, -1, -1, -1, 0, 1, 1, 1 };
+// step of direction d: 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE (y grows downwards); two bits per direction in a register
+// constant -- a table in memory would put a load with a per-lane index into every step of the follower
+__device__ __forceinline__ int trace_dx(int d) { return (int)((0x901Au >> (2 * d)) & 3u) - 1; }     // 1, 1, 0, -1, -1, -1, 0, 1
+__device__ __forceinline__ int trace_dy(int d) { return (int)((0xA901u >> (2 * d)) & 3u) - 1; }     // 0, -1, -1, -1, 0, 1, 1, 1
 
 __global__ __launch_bounds__(64) void trace_count_kernel(const uint8_t* __restrict__ ez, int h, int w, FrameTab* __restrict__ tab,
                                                          const int32_t* __restrict__ roots, int maxc, int32_t* __restrict__ nvert)
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(64) void trace_count_kernel(const uint8_t* __restri
     int dir = 4, first = -1;
     do {                                             // clockwise from west: the first neighbour on the border
         dir = (dir - 1) & 7;
-        const int q = p0 + TRACE_DY[dir] * w + TRACE_DX[dir];
+        const int q = p0 + trace_dy(dir) * w + trace_dx(dir);
         if (e[q]) { first = q; break; }
     } while (dir != 4);
     int count = 1;                                   // an isolated pixel is a contour of one point
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(64) void trace_count_kernel(const uint8_t* __restri
             int nxt;
             for (;;) {                               // counter-clockwise from the pixel we came from
                 dir = (dir + 1) & 7;
-                nxt = cur + TRACE_DY[dir] * w + TRACE_DX[dir];
+                nxt = cur + trace_dy(dir) * w + trace_dx(dir);
                 if (e[nxt]) break;
             }
             if (dir != prev_dir) { count++; prev_dir = dir; }
@@ -552,6 +554,75 @@ __global__ __launch_bounds__(64) void trace_count_kernel(const uint8_t* __restri
         if (step >= cap) tab[f].overflow = 1;
     }
     nvert[(size_t)f * maxc + s] = count;
+}
+
+// The same follower with the edge map of its workgroup bit-packed in LDS (one workgroup per map: 379 x 379 pixels are
+// 18 KB of bits).  A step reads the eight neighbour bits at once (independent LDS reads, one latency) and finds the next
+// border pixel with a rotate + count-trailing-zeros instead of up to seven dependent loads from L2: the kernel is bound by
+// its longest contour, so latency per step is what counts.
+__global__ __launch_bounds__(256) void trace_count_lds_kernel(const uint8_t* __restrict__ ez, int h, int w, FrameTab* __restrict__ tab,
+                                                              const int32_t* __restrict__ roots, int maxc, int32_t* __restrict__ nvert)
+{
+    extern __shared__ uint32_t bits[];                         // h rows of W dwords
+    const int f = blockIdx.x;
+    const int W = (w + 31) >> 5;
+    const uint8_t* e = ez + (size_t)f * h * w;
+    for (int i = threadIdx.x; i < h * W + 1; i += 256) bits[i] = 0;      // (+ one word the last window may touch)
+    __syncthreads();
+    // pack: the map as one flat byte array, eight coalesced loads in flight per thread; edge pixels are few, each sets its
+    // bit with an LDS atomic
+    const int npx = h * w;
+    for (int base = 0; base < npx; base += 256 * 8) {
+        uint8_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int i = base + k * 256 + threadIdx.x; v[k] = i < npx ? e[i] : 0; }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (v[k]) {
+                const int i = base + k * 256 + threadIdx.x, y = i / w, x = i - y * w;
+                atomicOr(&bits[y * W + (x >> 5)], 1u << (x & 31));
+            }
+    }
+    __syncthreads();
+    const int nr = min(tab[f].n_roots, maxc);
+    auto around = [&](int x, int y) {                          // bit d = neighbour in direction d
+        // three rows, each a 3-bit window x-1 .. x+1 cut out of two consecutive words (the second word only matters when
+        // the window straddles it; past the last word of a row it is never looked at)
+        const int xl = x - 1, sh = xl & 31;
+        const uint32_t* r = bits + (y - 1) * W + (xl >> 5);
+        const uint32_t t0 = (uint32_t)(((unsigned long long)r[0] | ((unsigned long long)r[1] << 32)) >> sh) & 7u;
+        const uint32_t t1 = (uint32_t)(((unsigned long long)r[W] | ((unsigned long long)r[W + 1] << 32)) >> sh) & 7u;
+        const uint32_t t2 = (uint32_t)(((unsigned long long)r[2 * W] | ((unsigned long long)r[2 * W + 1] << 32)) >> sh) & 7u;
+        return (t1 >> 2) | ((t0 >> 2) << 1) | (((t0 >> 1) & 1u) << 2) | ((t0 & 1u) << 3) | ((t1 & 1u) << 4) | ((t2 & 1u) << 5) |
+               (((t2 >> 1) & 1u) << 6) | ((t2 >> 2) << 7);
+    };
+    for (int s = threadIdx.x; s < nr; s += 256) {
+        const int p0 = roots[(size_t)f * maxc + s];
+        const int y0 = p0 / w, x0 = p0 - y0 * w;
+        uint32_t m = around(x0, y0);
+        int count = 1;                                         // an isolated pixel is a contour of one point
+        if (m) {
+            int dir = 4;
+            do { dir = (dir - 1) & 7; } while (!((m >> dir) & 1u));         // clockwise from west: the first neighbour on the border
+            const int fx = x0 + trace_dx(dir), fy = y0 + trace_dy(dir);
+            int x = x0, y = y0, prev_dir = dir ^ 4;
+            count = 0;
+            const long long cap = 8ll * h * w;
+            long long step = 0;
+            for (; step < cap; step++) {
+                const uint32_t rot = ((m | (m << 8)) >> (dir + 1)) & 0xFFu;   // counter-clockwise from the pixel we came from
+                dir = (dir + 1 + __builtin_ctz(rot)) & 7;
+                const int nx = x + trace_dx(dir), ny = y + trace_dy(dir);
+                if (dir != prev_dir) { count++; prev_dir = dir; }
+                if (nx == x0 && ny == y0 && x == fx && y == fy) break;
+                x = nx; y = ny;
+                dir = (dir + 4) & 7;
+                m = around(x, y);
+            }
+            if (step >= cap) tab[f].overflow = 1;
+        }
+        nvert[(size_t)f * maxc + s] = count;
+    }
 }
 
 // ---- G. ghost image + Hough point list ------------------------------------------------------
@@ -1093,8 +1164,13 @@ int k_contour_survey(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, s
     if (!nc_max) return CK_OK;
     {
         TimeScope ts(ctx, "survey_trace");
-        hipLaunchKernelGGL(trace_count_kernel, dim3((nc_max + 63) / 64, n), dim3(64), 0, ctx->stream, (const uint8_t*)ez, h, w, d_tab,
-                           (const int32_t*)d_roots, maxc, d_nvert);
+        const size_t bit_bytes = (size_t)h * ((w + 31) / 32) * 4 + 4;
+        if (bit_bytes <= 64 * 1024)                            // goban-sized maps: follow the borders in LDS
+            hipLaunchKernelGGL(trace_count_lds_kernel, dim3(n), dim3(256), bit_bytes, ctx->stream, (const uint8_t*)ez, h, w, d_tab,
+                               (const int32_t*)d_roots, maxc, d_nvert);
+        else
+            hipLaunchKernelGGL(trace_count_kernel, dim3((nc_max + 63) / 64, n), dim3(64), 0, ctx->stream, (const uint8_t*)ez, h, w, d_tab,
+                               (const int32_t*)d_roots, maxc, d_nvert);
         CK_HIP(ctx, hipGetLastError());
     }
     // roots and vertex counts (strided tables -> dense), then every outer-border pixel with its contour slot: the border
