@@ -107,3 +107,55 @@ def test_contour_stones_argument_errors(ck, ora):
         ck.contour_stones(g, fg, bad)
     with pytest.raises(ValueError):
         ck.contour_stones(g, fg[:100], rects)
+
+
+def _blobs(rng, n):
+    fg = np.zeros((380, 380), np.uint8)
+    yy, xx = np.mgrid[0:380, 0:380]
+    for _ in range(n):
+        cy, cx = rng.integers(30, 350, 2)
+        ry, rx = rng.integers(6, 30, 2)
+        fg[((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1] = 255
+    fg[rng.random((380, 380)) < 0.01] = 255
+    return fg
+
+
+def test_contour_stones_on_hostile_images(ck, ora):
+    """nothing like a goban: uniform noise, a random mosaic (hundreds of accepted hulls, many overlapping), a mask full
+    of ellipses and specks, an all-foreground mask -- same answers as the oracle, stage by stage"""
+    from oracle import ora_stones as S
+    rng = np.random.default_rng(11)
+    noise = rng.integers(0, 256, (380, 380, 3), dtype=np.uint8)
+    mosaic = np.kron(rng.integers(0, 256, (38, 38, 3), dtype=np.uint8), np.ones((10, 10, 1), np.uint8))
+    imgs = np.stack([noise, mosaic, mosaic[::-1].copy(), noise // 2])
+    fgs = np.stack([_blobs(rng, 12), _blobs(rng, 25), np.full((380, 380), 255, np.uint8), _blobs(rng, 3)])
+    rects = _rects(ora)
+    stones, zones, mask = ck.contour_stones(imgs, fgs, rects, want_all=True)
+    hulls = 0
+    for k in range(len(imgs)):
+        s, z, m, info = S.find_stones(imgs[k], fgs[k], want_all=True)
+        assert np.array_equal(mask[k], m), k
+        assert np.array_equal(zones[k], z), k
+        assert np.array_equal(stones[k], s), k
+        hulls += len(info["fg"]) + len(info["img"])
+    assert hulls > 500
+
+
+def test_find_intersections_on_hostile_images(ck, ora):
+    from oracle import ora_grid as G
+    rng = np.random.default_rng(12)
+    noise = rng.integers(0, 256, (380, 380, 3), dtype=np.uint8)
+    mosaic = np.kron(rng.integers(0, 256, (38, 38, 3), dtype=np.uint8), np.ones((10, 10, 1), np.uint8))
+    stripes = np.zeros((380, 380, 3), np.uint8)
+    stripes[:, ::7] = 255
+    stripes[::5, :] = 128
+    imgs = np.stack([noise, mosaic, stripes])
+    mtx = ora.posgrid(380)
+    rects = _rects(ora)
+    grid, found, edges = ck.find_intersections(imgs, mtx, rects, want_lines=True)
+    lines = 0
+    for k in range(len(imgs)):
+        g, f, e = G.find_intersections(imgs[k], mtx, rects, want_lines=True)
+        assert np.array_equal(edges[k], e) and found[k] == f and np.array_equal(grid[k], g), k
+        lines += sum(len(v) for v in f.values())
+    assert lines > 300
