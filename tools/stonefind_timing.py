@@ -65,6 +65,25 @@ def main():
         ref = [ora_stones.find_stones(a, b) for a, b in zip(gh, mh)]
         out["cpu_oracle"] = dict(images_per_s=round(args.cpu / (time.perf_counter() - t0), 2), kind="port", note="numpy + C restatement, one core")
         out["cpu_oracle"]["equal"] = bool(all(np.array_equal(r, s) for r, s in zip(ref, stones[len(stones) - args.cpu:])))
+    # two contexts in flight (two host threads, ctypes drops the GIL): one call's host geometry overlaps the other's kernels
+    import threading
+    ctx2 = capi.Context(0)
+    halves = [(gobans[:n // 2].contiguous(), fgs[:n // 2].contiguous()), (gobans[n // 2:].contiguous(), fgs[n // 2:].contiguous())]
+    for c, (g, m) in zip((ctx, ctx2), halves):
+        c.contour_stones(g, m, rects)
+    rounds = 6
+
+    def worker(c, g, m):
+        for _ in range(rounds):
+            c.contour_stones(g, m, rects)
+    th = [threading.Thread(target=worker, args=(c, g, m)) for c, (g, m) in zip((ctx, ctx2), halves)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    out["two_contexts_in_flight"] = dict(images_per_s=round(rounds * n / (time.perf_counter() - t0), 1), batch_per_context=n // 2)
+    ctx2.close()
     # ---- find_intersections ----
     mtx = PosGrid(380).mtx
     gi = {}
