@@ -312,3 +312,29 @@ def test_get_intersections_through_the_finder(quiet_game, monkeypatch):
     assert np.array_equal(first, G.find_intersections(gob, O.posgrid(380), rects))
     empty_seen = first[:, :, 0] < 0
     assert empty_seen.sum() > 100 and not (empty_seen & (truth > 0)).any()
+
+
+def test_hull_and_min_area_rect_against_independent_geometry():
+    """the strictly convex hull against qhull (scipy), the rotating-calipers box against a float64 search over the hull's
+    edge directions (the minimum-area rectangle has a side collinear with a hull edge)"""
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(21)
+    for trial in range(40):
+        pts = rng.integers(0, 60, (int(rng.integers(5, 80)), 2))
+        hull = S.convex_hull(pts)
+        if len(hull) < 3:
+            continue
+        q = ConvexHull(pts.astype(np.float64))
+        assert set(map(tuple, hull)) == set(map(tuple, pts[q.vertices])), trial
+        w, h, angle = S.min_area_rect_box(pts)
+        hv = hull.astype(np.float64)
+        best = None
+        for a, b in zip(hv, np.roll(hv, -1, 0)):
+            d = (b - a) / np.hypot(*(b - a))
+            along, across = hv @ d, hv @ np.array([-d[1], d[0]])
+            cand = (along.max() - along.min()) * (across.max() - across.min())
+            if best is None or cand < best[0]:
+                best = (cand, sorted((along.max() - along.min(), across.max() - across.min())))
+        assert abs(w * h - best[0]) <= 1e-3 * max(1.0, best[0]), trial
+        assert np.allclose(sorted((w, h)), best[1], rtol=1e-4, atol=1e-3), trial
+        assert -90.0 <= angle <= 0.0 or angle == 0.0
