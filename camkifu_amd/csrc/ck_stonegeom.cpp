@@ -37,11 +37,11 @@ void ck_raster_polygon(const int32_t* v, int nv, int* bx, int* by, int* bw, int*
         int ax = v[2 * i] - x0, ay = v[2 * i + 1] - y0;
         int cx = v[2 * ((i + 1) % nv)] - x0, cy = v[2 * ((i + 1) % nv) + 1] - y0;
         if (ay != cy) {
-            const long long num = ((long long)cx - ax) << 16, den = cy - ay;
+            const long long num = ((long long)cx - ax) * 65536, den = cy - ay;
             const long long q = (num < 0 ? -num : num) / (den < 0 ? -den : den);
             const long long dx = ((num < 0) == (den < 0)) ? q : -q;
-            if (ay < cy) edges.push_back({ ay, cy, (long long)ax << 16, dx });
-            else edges.push_back({ cy, ay, (long long)cx << 16, dx });
+            if (ay < cy) edges.push_back({ ay, cy, (long long)ax * 65536, dx });
+            else edges.push_back({ cy, ay, (long long)cx * 65536, dx });
         }
         // outline: start from the left end; the major axis advances every step, the minor one has moved
         // ceil((2 * minor * i - major) / (2 * major)) pixels after i steps
