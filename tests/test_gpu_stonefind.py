@@ -159,3 +159,37 @@ def test_find_intersections_on_hostile_images(ck, ora):
         assert np.array_equal(edges[k], e) and found[k] == f and np.array_equal(grid[k], g), k
         lines += sum(len(v) for v in f.values())
     assert lines > 300
+
+
+def test_rank3_entry_points_at_batch_256(ck, ora):
+    """256 goban images of a filmed game per call (the bench's batch): the same answers as image-by-image calls and as a
+    second run, three images checked against the oracle; both entry points"""
+    import torch
+    from camkifu_amd import synth
+    from oracle import ora_grid as G
+    from oracle import ora_stones as S
+    n = 256
+    film, corners, truth, moves, hands = synth.film(n, 480, 640, seed=synth.SEED + 3, quiet=50, move_every=12, hand_frames=6, device="cuda")
+    M = ora.get_perspective_transform(corners, DST)
+    gobans = torch.empty((n, 380, 380, 3), dtype=torch.uint8, device="cuda")
+    ck.warp_perspective(film, M, out=gobans)
+    h = ck.mog2_create(380, 380)
+    fgs = torch.stack([torch.as_tensor(ck.mog2_apply(h, gobans[f], 0.01 if f < 50 else 0.005)) for f in range(n)]).cuda()
+    ck.mog2_destroy(h)
+    rects, mtx = _rects(ora), ora.posgrid(380)
+    stones, zones, mask = ck.contour_stones(gobans, fgs, rects, want_all=True)
+    again = ck.contour_stones(gobans, fgs, rects)
+    assert np.array_equal(again, stones)
+    grid = ck.find_intersections(gobans, mtx, rects)
+    assert np.array_equal(ck.find_intersections(gobans, mtx, rects), grid)
+    gh, fh = gobans.cpu().numpy(), fgs.cpu().numpy()
+    for k in (0, 77, 128, 255):
+        assert np.array_equal(ck.contour_stones(gh[k], fh[k], rects), stones[k]), k
+        assert np.array_equal(ck.find_intersections(gh[k], mtx, rects), grid[k]), k
+    for k in (60, 131, 250):
+        s, z, m, _ = S.find_stones(gh[k], fh[k], want_all=True)
+        assert np.array_equal(stones[k], s) and np.array_equal(zones[k], z) and np.array_equal(mask[k], m), k
+        assert np.array_equal(grid[k], G.find_intersections(gh[k], mtx, rects)), k
+    calm = [f for f in range(60, n) if not hands[f]]
+    agree = np.mean([(stones[f] == np.asarray(truth[f])).mean() for f in calm])
+    assert agree > 0.97
