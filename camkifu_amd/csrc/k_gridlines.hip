@@ -196,6 +196,8 @@ int k_grid_lines(ck_ctx* ctx, const uint8_t* d_goban, int n, int side, const int
         const int32_t* q = rects + 4 * z;
         if (q[0] < 0 || q[1] < 0 || q[2] > side || q[3] > side || q[2] <= q[0] || q[3] <= q[1])
             return ck_fail(ctx, CK_ERR_ARG, "zone %d: rectangle (%d, %d, %d, %d) outside the %d image", z, q[0], q[1], q[2], q[3], side);
+        if (std::min(q[2] - q[0], q[3] - q[1]) < 4)
+            return ck_fail(ctx, CK_ERR_ARG, "zone %d: %d x %d pixels, at least 4 x 4", z, q[2] - q[0], q[3] - q[1]);
         zmax = std::max(zmax, std::max(q[2] - q[0], q[3] - q[1]));
     }
     if (zmax > ZMAX) return ck_fail(ctx, CK_ERR_ARG, "intersection zone of %d pixels: at most %d", zmax, ZMAX);
