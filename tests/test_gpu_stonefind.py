@@ -39,7 +39,8 @@ def _rects(ora):
     return np.array([[ora.sf_getrect(r, c) for c in range(19)] for r in range(19)], np.int32)
 
 
-@pytest.mark.parametrize("shape,density,seed", [((40, 56), 0.15, 1), ((97, 131), 0.3, 2), ((120, 64), 0.55, 3), ((379, 379), 0.08, 4)])
+@pytest.mark.parametrize("shape,density,seed", [((40, 56), 0.15, 1), ((97, 131), 0.3, 2), ((120, 64), 0.55, 3), ((379, 379), 0.08, 4),
+                                                ((600, 1000), 0.2, 5)])       # the last one is too big for the LDS follower: global-memory path
 def test_contours_external_match_the_border_follower(ck, ora, shape, density, seed):
     rng = np.random.default_rng(seed)
     edges = ((rng.random((3,) + shape) < density) * 255).astype(np.uint8)
