@@ -244,7 +244,7 @@ def main():
 
     # ---- timed region: two batches in flight ------------------------------------------------------------------------
     def run_steps(p, k, batch):
-        DEPTH = 2
+        DEPTH = int(os.environ.get("CK_BENCH_DEPTH", "2"))      # batches in flight (developer knob; 3 measured no faster)
         tickets = [p.submit(batch, n_total) for _ in range(min(DEPTH, k))]
         for i in range(k):
             t = tickets.pop(0)
