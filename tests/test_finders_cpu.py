@@ -138,6 +138,9 @@ def test_finders_take_the_host_applications_base_classes(tmp_path):
             HOST = True
             def __init__(self, vmanager, learn_bg=True):
                 self.vmanager, self.total_f_processed, self.bg_init_frames = vmanager, 0, 3
+                self._fg = None
+            def get_foreground(self): return self._fg
+            def getrect(self, r, c, cursor=1.0): return 20 * r, 20 * c, min(20 * r + 20, 379), min(20 * c + 20, 379)
     """))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent("""
@@ -156,6 +159,24 @@ def test_finders_take_the_host_applications_base_classes(tmp_path):
             def cnn_set_weights(self, w): pass
         sf = SfNeural(object(), ctx=Ctx())
         assert sf.HOST and sf.policy is not None and sf.bg_init_frames == 3
+        # SfContours on the host's base: the zone table comes from the host's getrect, one library call per find_stones
+        from camkifu_amd.stone.sf_contours import SfContours
+        from camkifu_amd.golib_shim import B, W, E
+        assert issubclass(SfContours, hs.StonesFinder)
+        class Rec:
+            def contour_stones(self, img, fg, rects, rs, re, cs, ce):
+                self.seen = (img.shape, fg.shape, np.asarray(rects).shape, tuple(np.asarray(rects)[18, 18]), rs, re, cs, ce)
+                out = np.zeros((19, 19), np.uint8); out[3, 4] = 1; out[5, 6] = 2
+                return out
+        rec = Rec()
+        sc = SfContours(object(), ctx=rec)
+        sc._fg = np.zeros((380, 380), np.uint8)
+        got = sc.find_stones(np.zeros((380, 380, 3), np.uint8), rs=2, re=9)
+        assert rec.seen == ((380, 380, 3), (380, 380), (19, 19, 4), (360, 360, 379, 379), 2, 9, 0, 19)
+        assert got[3, 4] == B and got[5, 6] == W and got[0, 0] == E and got.dtype == object
+        sc.total_f_processed = 5
+        sc._find(np.zeros((380, 380, 3), np.uint8))
+        assert sc.last_stones is not None and sc.last_stones[5, 6] == W
         print("host bases ok")
     """)
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), root]))
