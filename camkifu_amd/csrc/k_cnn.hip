@@ -93,6 +93,10 @@ constexpr float H2_WSCALE = 256.f;      // split-precision mode: weights are sto
 
 #pragma clang fp contract(off)
 
+#ifndef H2C2S_TB
+#define H2C2S_TB 24      // pooling tiles (4x4 output pixels) per conv2 workgroup: 24 = 3 tile rows x 3 workgroups per patch (14.9 us
+                         // per frame); 32 = 4 x 2 (fewer weight loads per MFMA, but one workgroup per CU: 16.4 us); 16 = 2 x 4: 16.6 us
+#endif
 #ifndef CK_H2_OPMAJOR
 #define CK_H2_OPMAJOR 0     // developer knob: product-major order of the split-precision MFMAs inside a k-step (same sums bit for bit;
                             // measured: 14.8 vs 14.9 us per frame when held to 128 VGPRs, 16.6 at 130 -- the chain order is not the limit)
@@ -1689,7 +1693,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             // 8x8 pooling tiles of 4x4 pixels: workgroups of whole tile rows, pooled output 16x16x32
             if (h2) {
 #if H2C2_SWZ
-                hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, 24, 3, 8, 2, true, H2C2S_PF, H2C2S_SB, true, H2_FUSE1 != 0>), dim3(np, 3), dim3(512), (size_t)lds_pad_conv2(), ctx->stream,
+                hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, H2C2S_TB, 64 / H2C2S_TB + (64 % H2C2S_TB != 0), 8, 2, true, H2C2S_PF, H2C2S_SB, true, H2_FUSE1 != 0>), dim3(np, 64 / H2C2S_TB + (64 % H2C2S_TB != 0)), dim3(512), (size_t)lds_pad_conv2(), ctx->stream,
                                    (const float*)a1, (const uint16_t*)W.c2w_h2.p, (const float*)W.c2b.p, p2, 1.f / H2_WSCALE, d_nonfinite,
                                    gob, (const uint16_t*)W.c1w_h2.p, (const float*)W.c1b.p);
 #else
