@@ -438,6 +438,7 @@ def main():
             "host_ms_per_step": dict(host_ms, note="rank 0, overlapped with the GPU work of the next batch; fold = "
                                                    "ck_boardfold_step + ck_policy_run over all %d records" % n_total),
             "board_found_by_fold": board_found,
+            "board_records_looked_at_pct": round(100.0 * pipe.board.looked / max(1, pipe.board.seen), 1) if rank == 0 else None,
             "cnn_weights": "trained on synthetic boards (%s, Keras-1 HDF5 layout)" % os.path.relpath(KERAS_MODEL_FILE, ROOT),
         }
         out_line.update(quality)

@@ -139,6 +139,7 @@ class BoardFold:
         self.frame = np.zeros((h, w, 0), np.uint8)          # what _detect needs of a frame once the image chain ran: its shape
         self.refresh_frames = 10 * cvconf.file_fps if refresh_frames is None else refresh_frames
         self.hold = 0
+        self.seen = self.looked = 0                          # records offered / records _detect was called with
 
     @property
     def mtx(self):
@@ -147,9 +148,11 @@ class BoardFold:
     def step(self, rec):
         """rec: one REC row (or a dict with status / n_lines / lines ...)"""
         f = self.finder
+        self.seen += 1
         if self.hold > 0:
             self.hold -= 1
         else:
+            self.looked += 1
             k = min(int(rec["n_lines"]), LMAX, len(rec["lines"]))
             f.corners.frame = self.frame
             hit = f._detect(self.frame, record=dict(status=int(rec["status"]), n_lines=k, lines=np.asarray(rec["lines"])[:k]))
@@ -168,6 +171,7 @@ class BoardFold:
             if self.hold > 0:                                # nothing is looked at during the hold-off
                 skip = min(self.hold, n - k)
                 self.hold -= skip
+                self.seen += skip
                 self.finder.total_f_processed += skip
                 k += skip
                 continue
