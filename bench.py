@@ -287,6 +287,25 @@ def main():
                                         note="same timed region with CK_CNN_FP32 (k-ordered f32 MFMA chain)")
             for _, c in lanes:
                 c.cnn_set_mode(mode)
+        # (1b) hold-off-aware scheduling (one rank): the reference does not run K1..K6 during the hold-off after a hit
+        # (bf_auto.py:43-49); here the fold computes only the board records it looks at.  NOT the headline workload
+        # (that one is the per-frame hot path on every frame); same game record required.
+        if world == 1:
+            lazy = pipeline.FastFilePipeline(H, W, ControllerHeadless(), rank=pr, world=pw, device=cdev, lanes=lanes, ctx_bg=ctx_bg,
+                                             board_lazy=True)
+            lazy.process_batch(frames, n_total)
+            if lazy.mtx is None:
+                lazy.mtx = M_true
+            same = lazy.process_batch(frames, n_total) == requests
+            k = max(4, args.steps // 2)
+            dlz = timed(lazy, k, 2, frames)
+            extras["holdoff_aware"] = dict(value=round(n_total * k / dlz, 2), unit="frames/s", steps=k, same_game_record=bool(same),
+                                           host_ms_per_step={kk: round(1e3 * v / k, 3) for kk, v in lazy.host_seconds.items()},
+                                           board_records_computed_pct=round(100.0 * lazy.board.fetched / max(1, lazy.board.seen), 1),
+                                           note="NOT the headline, and slower as built: K1-K6 run only for the frames the board fold looks "
+                                                "at (windows predicted from the hold-off, one launch per batch), but that launch sits on the "
+                                                "fold's thread, one context, ~70 us per frame with its host round trips, while the eager path "
+                                                "spreads full batches over two lanes; stones path on every frame")
         # (2) PCIe-inclusive: the batch starts as I420 in PINNED host memory (what a video-file reader holds), is
         # uploaded and converted lane by lane (ck_i420_to_bgr), answers come back to the host; two batches in flight
         if world == 1:

@@ -128,6 +128,16 @@ class _Group:
         return list(torch.split(recv, [int(r) for r in recv_sizes]))
 
 
+def _take(frames, indices):
+    """the frames with those indices, contiguous (a slice when they are consecutive)"""
+    if len(indices) and indices[-1] - indices[0] + 1 == len(indices):
+        return frames[indices[0]:indices[-1] + 1]
+    if hasattr(frames, "index_select"):
+        import torch
+        return frames.index_select(0, torch.as_tensor(indices, device=frames.device))
+    return np.ascontiguousarray(np.asarray(frames)[list(indices)])
+
+
 class BoardFold:
     """Ordered replay of the board finder on per-frame records: BoardFinderAuto._detect is called with the record in
     place of the GPU call.  The 10 s wall-clock hold-off after a hit (bf_auto.py:43-49) is a frame count here."""
@@ -139,7 +149,8 @@ class BoardFold:
         self.frame = np.zeros((h, w, 0), np.uint8)          # what _detect needs of a frame once the image chain ran: its shape
         self.refresh_frames = 10 * cvconf.file_fps if refresh_frames is None else refresh_frames
         self.hold = 0
-        self.seen = self.looked = 0                          # records offered / records _detect was called with
+        self.seen = self.looked = self.fetched = 0           # records offered / records _detect was called with / computed lazily
+        self.episode = 8                                     # frames the last detection took (run_lazy's prediction)
 
     @property
     def mtx(self):
@@ -177,6 +188,51 @@ class BoardFold:
                 continue
             self.step(recs[k])
             k += 1
+        return self.mtx
+
+    def run_lazy(self, n, fetch, chunk=8):
+        """The same fold over a batch of n frames whose board records do not exist yet: `fetch(indices)` computes the
+        records of those frames (-> BOARD_DTYPE array, lines (len(indices), cap, 2)) and is only asked for frames this
+        fold is going to look at.  During the hold-off the reference does not run K1..K6 at all (bf_auto.py:43-49);
+        this is that, batch-wise.  The frames looked at are predictable -- from the frame the hold-off expires on until
+        the next hit, which on a steady camera comes after as many frames as last time -- so the windows of a whole batch
+        are requested in ONE call (small launches are latency-bound); a hit that comes later than predicted costs an
+        extra call of `chunk` frames, one that comes earlier leaves a few computed records unused.  Same calls to `step`
+        in the same order as `run` over the full records, hence the same corners."""
+        span = max(chunk, self.episode + 2)
+        want, k, hold = [], 0, self.hold
+        while k < n:                                         # the prediction: hold-off, then `span` frames, a hit, ...
+            if hold > 0:
+                skip = min(hold, n - k)
+                k, hold = k + skip, hold - skip
+                continue
+            want.extend(range(k, min(n, k + span)))
+            k, hold = k + max(1, self.episode), self.refresh_frames
+        cache = {}
+
+        def load(indices):
+            res, lines = fetch(indices)
+            self.fetched += len(indices)
+            for j, f in enumerate(indices):
+                cache[f] = (int(res["status"][j]), int(res["n_lines"][j]), lines[j])
+        if want:
+            load(want)
+        k = run = 0
+        while k < n:
+            if self.hold > 0:
+                skip = min(self.hold, n - k)
+                self.hold -= skip
+                self.seen += skip
+                self.finder.total_f_processed += skip
+                k += skip
+                continue
+            if k not in cache:
+                load([f for f in range(k, min(n, k + chunk)) if f not in cache])
+            status, n_lines, lines = cache[k]
+            self.step(dict(status=status, n_lines=n_lines, lines=lines))
+            k, run = k + 1, run + 1
+            if self.hold > 0:
+                self.episode, run = run, 0                   # frames it took from the end of the hold-off to this hit
         return self.mtx
 
 
@@ -268,26 +324,26 @@ class GpuCore:
                 self._served += 1
                 self._turn.notify_all()
 
-    def __call__(self, frames, mtx, rates, seq=None):
+    def __call__(self, frames, mtx, rates, seq=None, board=True):
         turn = {"open": seq is not None}
 
         def take_turn(fn):
             turn["open"] = False
             return self._in_order(seq, fn)
         try:
-            return self._batch(frames, mtx, rates, take_turn)
+            return self._batch(frames, mtx, rates, take_turn, board)
         finally:
             if turn["open"]:                                 # failed (or had nothing for the model) before its turn:
                 self._in_order(seq, lambda: None)            # the batches behind must not wait for it forever
 
-    def _batch(self, frames, mtx, rates, take_turn):
+    def _batch(self, frames, mtx, rates, take_turn, want_board=True):
         n = len(frames)
         if n == 0:
             return ((np.zeros(0, capi.BOARD_DTYPE), np.zeros((0, LMAX, 2), np.float32)), np.zeros((0, 10, 10), np.uint8),
                     np.zeros((0, 10, 10)), None, None)
         cuts = self._cuts(n)
         parts = [frames[cuts[i]:cuts[i + 1]] for i in range(len(self.lanes))]
-        board_f = [pb.submit(cb.board_detect, fr, -1, LMAX, True) if len(fr) else None
+        board_f = [pb.submit(cb.board_detect, fr, -1, LMAX, True) if len(fr) and want_board else None
                    for (pb, _), (cb, _), fr in zip(self.pools, self.lanes, parts)]
         rl, rc, fg, gobans = np.zeros((n, 10, 10), np.uint8), np.zeros((n, 10, 10)), None, None
         if mtx is not None:
@@ -318,6 +374,8 @@ class GpuCore:
                     rl[cuts[i]:cuts[i + 1]], rc[cuts[i]:cuts[i + 1]] = f.result()
             if self.local_model:
                 fg, gobans = self._host(fg_f.result()), None
+        if not want_board:                                   # the fold will ask for the records it looks at (run_lazy)
+            return (np.zeros(n, capi.BOARD_DTYPE), np.zeros((n, LMAX, 2), np.float32)), rl, rc, fg, gobans
         res = [f.result() for f in board_f if f is not None]
         board = (np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res]))
         return board, rl, rc, fg, gobans
@@ -338,7 +396,7 @@ class FastFilePipeline:
     handed back when world > 1, for the pixel-sharded background model."""
 
     def __init__(self, h, w, controller, ctx=None, rank=0, world=1, device=None, compute=None, ctx_board=None,
-                 bg_init_frames=50, band_model=None, lanes=None, ctx_bg=None):
+                 bg_init_frames=50, band_model=None, lanes=None, ctx_bg=None, board_lazy=False):
         from concurrent.futures import ThreadPoolExecutor
         self.h, self.w = h, w
         self.rank, self.world = rank, world
@@ -357,6 +415,10 @@ class FastFilePipeline:
         self.band_model = band_model                          # callable(gobans_band (n, rows, 380, 3), rates) -> counts (n, band, 19)
         self.errors = []
         self.host_seconds = dict(pack=0.0, collectives=0.0, fold=0.0)
+        # hold-off-aware mode (one rank): the GPU core leaves the board path out and the fold computes, through the first
+        # lane's board context, only the records it looks at.  With frames dealt across ranks the fold would have to ask
+        # other ranks for theirs: not built, the full records are computed then.
+        self.board_lazy = bool(board_lazy) and world == 1 and hasattr(self.compute, "lanes")
 
     # ---- pixel-sharded background model (world > 1) -------------------------------------------------------
     def _band_counts(self, gobans, n_total, rates):
@@ -396,6 +458,8 @@ class FastFilePipeline:
     # ---- one batch --------------------------------------------------------------------------------------
     def _guarded(self, frames, mtx, rates, n_mine, seq):
         try:
+            if self.board_lazy:
+                return self.compute(frames, mtx, rates, seq, board=False), None
             if seq is not None:
                 return self.compute(frames, mtx, rates, seq), None
             return self.compute(frames, mtx, rates), None
@@ -413,13 +477,13 @@ class FastFilePipeline:
         mine = shard_indices(n_total, self.rank, self.world)
         rates_for_core = rates if self.world == 1 else rates[mine]
         seq = self.compute.ticket() if hasattr(self.compute, "ticket") else None
-        return self._runner.submit(self._guarded, my_frames, mtx, rates_for_core, len(mine), seq), mtx, rates, n_total
+        return self._runner.submit(self._guarded, my_frames, mtx, rates_for_core, len(mine), seq), mtx, rates, n_total, my_frames
 
     def finish(self, ticket):
         """records, collectives, fold (rank 0), transform broadcast -> the fold's per-frame request lists on rank 0,
         None elsewhere"""
         import time
-        fut, mtx, rates, n_total = ticket
+        fut, mtx, rates, n_total, my_frames = ticket
         (board, rl, rc, fg, gobans), failure = fut.result()
         if failure is not None:
             self.errors.append(failure)
@@ -448,7 +512,7 @@ class FastFilePipeline:
             raise RuntimeError("a rank failed in the GPU core of this batch: %s" % (self.errors[-1:] or "see its log"))
         emitted, new = None, None
         if self.rank == 0:
-            emitted = self.fold(full, counts, mtx is not None)
+            emitted = self.fold(full, counts, mtx is not None, frames=my_frames if self.board_lazy else None)
             new = self.board.mtx
         t3 = time.perf_counter()
         if self.world > 1:
@@ -470,9 +534,14 @@ class FastFilePipeline:
     def process_batch(self, my_frames, n_total):
         return self.finish(self.submit(my_frames, n_total))
 
-    def fold(self, full, counts, have_mtx=True):
-        """ordered replay of both finders on the gathered records of one batch (rank 0)"""
-        self.board.run(full)
+    def fold(self, full, counts, have_mtx=True, frames=None):
+        """ordered replay of both finders on the gathered records of one batch (rank 0); with `frames` (hold-off-aware
+        mode) the board records are computed on demand instead of read from `full`"""
+        if frames is not None:
+            ctx_board = self.compute.lanes[0][0]
+            self.board.run_lazy(len(full), lambda idx: ctx_board.board_detect(_take(frames, idx), -1, LMAX, True))
+        else:
+            self.board.run(full)
         if not have_mtx:
             return [()] * len(full)
         return self.stones.run(full["region_label"], full["region_conf"], counts)

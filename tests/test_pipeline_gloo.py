@@ -239,3 +239,43 @@ def test_rank0_host_cost_per_frame_does_not_grow_with_world(capsys):
     per_rec = {w: (got[w][1]["pack"] + got[w][1]["fold"]) / got[w][3] for w in got}
     assert per_rec[8] <= 2.0 * per_rec[1] + 0.01, per_rec            # ms per record: flat (generous slack for a busy box)
     assert got[8][1]["fold"] < 25.0                                    # 256 records folded in a few ms
+
+
+def test_lazy_board_fold_equals_the_eager_one():
+    """BoardFold.run_lazy (records computed only for the frames the fold looks at: the reference skips K1..K6 during its
+    hold-off) against BoardFold.run over the full records: same corners, same transform, same counters, batch after
+    batch -- with steady inputs, with hits that come later than predicted, with frames that show no board"""
+    from camkifu_amd import capi
+    from camkifu_amd.pipeline import BoardFold, LMAX
+    from tests.test_fold_cpu import _hough_like, _sides
+    rng = np.random.default_rng(8)
+    h, w = 1080, 1920
+    sides = _sides(rng, h, w)
+    eager, lazy = BoardFold(h, w), BoardFold(h, w)
+    asked = []
+    for batch in range(8):
+        n = int(rng.integers(40, 200))
+        res = np.zeros(n, capi.BOARD_DTYPE)
+        lines = np.zeros((n, LMAX, 2), np.float32)
+        for f in range(n):
+            if batch == 3 and f == 10:
+                sides = _sides(rng, h, w)                            # the camera is bumped
+            blind = batch == 5 and f < 120                           # nothing to see for a while: detection takes long
+            ls = _hough_like(rng, sides, h, w, 1)[:LMAX]
+            res["status"][f] = 1 if blind else int(rng.choice([0, 0, 0, 0, 2]))
+            res["n_lines"][f] = 0 if blind else len(ls)
+            lines[f, :len(ls)] = 0 if blind else ls
+        recs = [dict(status=int(res["status"][f]), n_lines=int(res["n_lines"][f]), lines=lines[f]) for f in range(n)]
+        eager.run(recs)
+
+        def fetch(idx):
+            asked.append(len(idx))
+            assert len(set(idx)) == len(idx) and min(idx) >= 0 and max(idx) < n
+            return res[list(idx)], lines[list(idx)]
+        lazy.run_lazy(n, fetch)
+        a, b = eager.finder, lazy.finder
+        assert (eager.mtx is None) == (lazy.mtx is None) and (eager.mtx is None or np.array_equal(eager.mtx, lazy.mtx))
+        assert a.corners.hull == b.corners.hull and a.total_f_processed == b.total_f_processed
+        assert (eager.hold, eager.seen, eager.looked) == (lazy.hold, lazy.seen, lazy.looked)
+    assert eager.mtx is not None and lazy.looked <= lazy.fetched < 0.6 * lazy.seen      # most records were never computed
+    assert len(asked) < 48        # one request per batch plus a few late hits, plus the blind stretch (120 frames in chunks of 8)
