@@ -13,6 +13,16 @@
 #include "ck_stonegeom.h"
 
 thread_local std::string g_ck_create_error;
+static thread_local const ck_ctx* g_ck_busy_ctx = nullptr;     // the context that refused this thread's last call
+
+unsigned long long ck_thread_token()
+{
+    static std::atomic<unsigned long long> next{1};
+    static thread_local unsigned long long mine = 0;
+    if (!mine) mine = next.fetch_add(1);
+    return mine;
+}
+void ck_note_busy(const ck_ctx* ctx) { g_ck_busy_ctx = ctx; }
 
 int ck_fail(ck_ctx* ctx, int code, const char* fmt, ...)
 {
@@ -203,6 +213,9 @@ void ck_ctx_destroy(ck_ctx* ctx)
     for (auto& m : ctx->mog2) {
         DevBuf* mb[] = { &m.weight, &m.variance, &m.mean, &m.nmodes };
         for (DevBuf* b : mb) if (b->p) (void)hipFree(b->p);
+        if (m.rates_host) (void)hipHostFree(m.rates_host);
+        if (m.rates_dev) (void)hipFree(m.rates_dev);
+        if (m.rates_done) (void)hipEventDestroy(m.rates_done);
     }
     for (auto& pe : ctx->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -212,26 +225,44 @@ void ck_ctx_destroy(ck_ctx* ctx)
     delete ctx;
 }
 
-const char* ck_last_error(const ck_ctx* ctx) { return ctx ? ctx->err.c_str() : g_ck_create_error.c_str(); }
+const char* ck_last_error(const ck_ctx* ctx)
+{
+    if (!ctx) return g_ck_create_error.c_str();
+    if (g_ck_busy_ctx == ctx) {              // this thread's call was refused: ctx->err belongs to the thread inside
+        g_ck_busy_ctx = nullptr;
+        return "the context is in use by another thread (a ck_ctx is single-threaded: one context per finder / thread)";
+    }
+    return ctx->err.c_str();
+}
 int ck_backend(const ck_ctx*) { return CK_BACKEND_HIP; }
 void* ck_stream(ck_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
-int ck_timing_enable(ck_ctx* ctx, int on) { if (!ctx) return CK_ERR_ARG; ctx->timing = on != 0; return CK_OK; }
+int ck_timing_enable(ck_ctx* ctx, int on)
+{
+    CK_API_BEGIN(ctx)
+    ctx->timing = on != 0;
+    return CK_OK;
+    CK_API_END(ctx)
+}
 int ck_timing_reset(ck_ctx* ctx)
 {
+    CK_API_BEGIN(ctx)
     if (!ctx) return CK_ERR_ARG;
     ck_timing_collect(ctx);
     ctx->slots.clear();
     return CK_OK;
+    CK_API_END(ctx)
 }
 int ck_timing_get(ck_ctx* ctx, const char* name, double* total_ms, int* launches)
 {
+    CK_API_BEGIN(ctx)
     if (!ctx || !name) return CK_ERR_ARG;
     ck_timing_collect(ctx);
     auto it = ctx->slots.find(name);
     if (total_ms) *total_ms = it == ctx->slots.end() ? 0.0 : it->second.ms;
     if (launches) *launches = it == ctx->slots.end() ? 0 : it->second.launches;
     return CK_OK;
+    CK_API_END(ctx)
 }
 
 static int check_img(ck_ctx* ctx, const void* p, int n, int h, int w)
@@ -258,6 +289,7 @@ int ck_median15(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_spa
 
 int ck_median(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int ksize, int in_space, uint8_t* out, int out_space)
 {
+    CK_API_BEGIN(ctx)
     CK_TRY(check_img(ctx, bgr, n, h, w));
     if (!out) return ck_fail(ctx, CK_ERR_ARG, "out is NULL");
     if (ksize < 3 || ksize > 17 || !(ksize & 1)) return ck_fail(ctx, CK_ERR_ARG, "median window %d: odd sizes 3..17 only", ksize);
@@ -272,11 +304,13 @@ int ck_median(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int ksize, i
     CK_TRY(k_planar_to_interleaved(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, d_out));
     if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, out, d_out, bytes, CK_HOST));
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 int ck_canny(ck_ctx* ctx, const uint8_t* img3, int n, int h, int w, int in_space,
              int low, int high, uint8_t* edges, uint8_t* map_out, int out_space)
 {
+    CK_API_BEGIN(ctx)
     CK_TRY(check_img(ctx, img3, n, h, w));
     if (!edges) return ck_fail(ctx, CK_ERR_ARG, "edges is NULL");
     const size_t npx = (size_t)n * h * w;
@@ -300,11 +334,13 @@ int ck_canny(ck_ctx* ctx, const uint8_t* img3, int n, int h, int w, int in_space
         if (map_out) CK_TRY(ck_from_device(ctx, map_out, d_mapout, npx, CK_HOST));
     }
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 int ck_goban_canny(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space, uint8_t* edges, int out_space,
                    double* otsu_out)
 {
+    CK_API_BEGIN(ctx)
     CK_TRY(check_img(ctx, bgr, n, h, w));
     if (!edges) return ck_fail(ctx, CK_ERR_ARG, "edges is NULL");
     const size_t npx = (size_t)n * h * w;
@@ -315,6 +351,7 @@ int ck_goban_canny(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_
     CK_TRY(ck_goban_canny_dev(ctx, (const uint8_t*)d_in, n, h, w, d_edges, otsu_out));
     if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, edges, d_edges, npx, CK_HOST));
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 static int board_edges_dev(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, uint8_t* d_edges,
@@ -333,6 +370,7 @@ static int board_edges_dev(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int 
 
 int ck_board_edges(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space, uint8_t* edges, int out_space)
 {
+    CK_API_BEGIN(ctx)
     CK_TRY(check_img(ctx, bgr, n, h, w));
     if (!edges) return ck_fail(ctx, CK_ERR_ARG, "edges is NULL");
     const size_t npx = (size_t)n * h * w;
@@ -343,12 +381,14 @@ int ck_board_edges(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_
     CK_TRY(board_edges_dev(ctx, (const uint8_t*)d_in, n, h, w, d_edges));
     if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, edges, d_edges, npx, CK_HOST));
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 int ck_board_lines(ck_ctx* ctx, const uint8_t* edges, int n, int h, int w, int in_space,
                    int hough_thresh, float* lines, int cap, ck_board_result* res,
                    uint8_t* ghost_out, int ghost_space)
 {
+    CK_API_BEGIN(ctx)
     CK_TRY(check_img(ctx, edges, n, h, w));
     if (!lines || !res || cap <= 0) return ck_fail(ctx, CK_ERR_ARG, "lines/res NULL or cap <= 0");
     if (h < 3 || w < 3) return ck_fail(ctx, CK_ERR_ARG, "image smaller than 3x3");
@@ -364,11 +404,13 @@ int ck_board_lines(ck_ctx* ctx, const uint8_t* edges, int n, int h, int w, int i
     CK_TRY(k_board_lines(ctx, (const uint8_t*)d_in, n, h, w, hough_thresh, lines, cap, res, d_ghost));
     if (ghost_out && ghost_space == CK_HOST) CK_TRY(ck_from_device(ctx, ghost_out, d_ghost, npx, CK_HOST));
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 int ck_board_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
                     int hough_thresh, float* lines, int cap, ck_board_result* res)
 {
+    CK_API_BEGIN(ctx)
     CK_TRY(check_img(ctx, bgr, n, h, w));
     if (!lines || !res || cap <= 0) return ck_fail(ctx, CK_ERR_ARG, "lines/res NULL or cap <= 0");
     if (h < 3 || w < 3) return ck_fail(ctx, CK_ERR_ARG, "image smaller than 3x3");
@@ -384,6 +426,7 @@ int ck_board_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in
     CK_TRY(k_board_lines(ctx, (const uint8_t*)ctx->edges.p, n, h, w, hough_thresh, lines, cap, res, nullptr,
                          (const int*)ctx->bflag.p));
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 static int upload_minv(ck_ctx* ctx, const double* M, int m_count, int n, const double** d_minv)
@@ -402,6 +445,7 @@ static int upload_minv(ck_ctx* ctx, const double* M, int m_count, int n, const d
 
 int ck_i420_to_bgr(ck_ctx* ctx, const uint8_t* i420, int n, int h, int w, int in_space, uint8_t* bgr, int out_space)
 {
+    CK_API_BEGIN(ctx)
     CK_TRY(check_img(ctx, i420, n, h, w));
     if (!bgr) return ck_fail(ctx, CK_ERR_ARG, "bgr is NULL");
     if ((h & 1) || (w & 1)) return ck_fail(ctx, CK_ERR_ARG, "I420 needs even dimensions, got %dx%d", w, h);
@@ -413,11 +457,13 @@ int ck_i420_to_bgr(ck_ctx* ctx, const uint8_t* i420, int n, int h, int w, int in
     CK_TRY(k_i420_to_bgr(ctx, (const uint8_t*)d_in, n, h, w, d_out));
     if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, bgr, d_out, obytes, CK_HOST));
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 int ck_warp_perspective(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
                         const double* M, int m_count, int dsize, uint8_t* out, int out_space)
 {
+    CK_API_BEGIN(ctx)
     CK_TRY(check_img(ctx, bgr, n, h, w));
     if (!out || dsize <= 0) return ck_fail(ctx, CK_ERR_ARG, "out NULL or dsize <= 0");
     const void* d_in;
@@ -430,23 +476,28 @@ int ck_warp_perspective(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, in
     CK_TRY(k_warp(ctx, (const uint8_t*)d_in, n, h, w, d_minv, m_count, dsize, d_out));
     if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, out, d_out, obytes, CK_HOST));
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 int ck_cnn_set_weights(ck_ctx* ctx, const float* const weights[12], int space)
 {
+    CK_API_BEGIN(ctx)
     if (!ctx || !weights) return CK_ERR_ARG;
     for (int i = 0; i < 12; i++) if (!weights[i]) return ck_fail(ctx, CK_ERR_ARG, "weights[%d] is NULL", i);
     CK_HIP(ctx, hipSetDevice(ctx->device));
     CK_TRY(k_cnn_pack_weights(ctx, weights, space));
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 int ck_cnn_set_mode(ck_ctx* ctx, int mode)
 {
+    CK_API_BEGIN(ctx)
     if (!ctx) return CK_ERR_ARG;
     if (mode != CK_CNN_FP32 && mode != CK_CNN_BF16 && mode != CK_CNN_F16X2) return ck_fail(ctx, CK_ERR_ARG, "unknown cnn mode %d", mode);
     ctx->cnn_mode = mode;
     return CK_OK;
+    CK_API_END(ctx)
 }
 
 // where the region outputs of a call go (all optional)
@@ -504,6 +555,7 @@ static int cnn_finish(ck_ctx* ctx, const uint8_t* d_goban, int n, float* y, uint
 int ck_cnn_predict(ck_ctx* ctx, const uint8_t* goban, int n, int in_space,
                    float* y, uint8_t* labels, double* conf, int out_space)
 {
+    CK_API_BEGIN(ctx)
     if (!ctx) return CK_ERR_ARG;
     if (!goban || n <= 0) return ck_fail(ctx, CK_ERR_ARG, "goban NULL or n <= 0");
     CK_HIP(ctx, hipSetDevice(ctx->device));
@@ -511,11 +563,13 @@ int ck_cnn_predict(ck_ctx* ctx, const uint8_t* goban, int n, int in_space,
     CK_TRY(ck_to_device(ctx, goban, (size_t)n * 380 * 380 * 3, in_space, ctx->in_stage, &d_in));
     CK_TRY(cnn_predict_dev(ctx, (const uint8_t*)d_in, n, y, labels, conf, out_space));
     return cnn_finish(ctx, (const uint8_t*)d_in, n, y, labels, conf, out_space);
+    CK_API_END(ctx)
 }
 
 int ck_stones_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
                      const double* M, int m_count, uint8_t* labels, double* conf, int out_space)
 {
+    CK_API_BEGIN(ctx)
     CK_TRY(check_img(ctx, bgr, n, h, w));
     const void* d_in;
     CK_TRY(ck_to_device(ctx, bgr, (size_t)n * h * w * 3, in_space, ctx->in_stage, &d_in));
@@ -525,11 +579,13 @@ int ck_stones_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int i
     CK_TRY(k_warp(ctx, (const uint8_t*)d_in, n, h, w, d_minv, m_count, 380, (uint8_t*)ctx->goban.p));
     CK_TRY(cnn_predict_dev(ctx, (const uint8_t*)ctx->goban.p, n, nullptr, labels, conf, out_space));
     return cnn_finish(ctx, (const uint8_t*)ctx->goban.p, n, nullptr, labels, conf, out_space);
+    CK_API_END(ctx)
 }
 
 int ck_cnn_regions(ck_ctx* ctx, const uint8_t* goban, int n, int in_space, uint8_t* region_label, double* region_conf,
                    int out_space)
 {
+    CK_API_BEGIN(ctx)
     if (!ctx) return CK_ERR_ARG;
     if (!goban || n <= 0 || !region_label || !region_conf) return ck_fail(ctx, CK_ERR_ARG, "NULL argument or n <= 0");
     CK_HIP(ctx, hipSetDevice(ctx->device));
@@ -538,12 +594,14 @@ int ck_cnn_regions(ck_ctx* ctx, const uint8_t* goban, int n, int in_space, uint8
     RegionOut ro; ro.label = region_label; ro.conf = region_conf;
     CK_TRY(cnn_predict_dev(ctx, (const uint8_t*)d_in, n, nullptr, nullptr, nullptr, out_space, ro));
     return cnn_finish(ctx, (const uint8_t*)d_in, n, nullptr, nullptr, nullptr, out_space, ro);
+    CK_API_END(ctx)
 }
 
 int ck_stones_run(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space, const double* M, int m_count,
                   int mog2_handle, const double* learning_rates, uint8_t* region_label, double* region_conf,
                   int32_t* fgcount, uint8_t* labels, double* conf, int out_space)
 {
+    CK_API_BEGIN(ctx)
     CK_TRY(check_img(ctx, bgr, n, h, w));
     if (!region_label || !region_conf) return ck_fail(ctx, CK_ERR_ARG, "region outputs are NULL");
     const bool bg = mog2_handle >= 0;
@@ -567,11 +625,13 @@ int ck_stones_run(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_s
     RegionOut ro; ro.label = region_label; ro.conf = region_conf;
     CK_TRY(cnn_predict_dev(ctx, (const uint8_t*)ctx->goban.p, n, nullptr, labels, conf, out_space, ro));
     return cnn_finish(ctx, (const uint8_t*)ctx->goban.p, n, nullptr, labels, conf, out_space, ro);
+    CK_API_END(ctx)
 }
 
 int ck_mog2_band_run(ck_ctx* ctx, int handle, const uint8_t* band, int n, int in_space, const double* learning_rates,
                      int last_band, int32_t* counts, int out_space)
 {
+    CK_API_BEGIN(ctx)
     if (!ctx) return CK_ERR_ARG;
     if (handle < 0 || handle >= (int)ctx->mog2.size() || !ctx->mog2[handle].alive)
         return ck_fail(ctx, CK_ERR_ARG, "bad mog2 handle %d", handle);
@@ -586,10 +646,12 @@ int ck_mog2_band_run(ck_ctx* ctx, int handle, const uint8_t* band, int n, int in
     CK_TRY(k_mog2_run(ctx, st, (const uint8_t*)d_in, n, learning_rates, d_cnt, nullptr, last_band ? st.h - 1 : -1, st.w - 1));
     if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, counts, d_cnt, (size_t)n * zones * sizeof(int32_t), CK_HOST));
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 int ck_zone_counts(ck_ctx* ctx, const uint8_t* mask, int n, int in_space, int32_t* counts, int out_space)
 {
+    CK_API_BEGIN(ctx)
     if (!ctx) return CK_ERR_ARG;
     if (!mask || !counts || n <= 0) return ck_fail(ctx, CK_ERR_ARG, "NULL argument or n <= 0");
     CK_HIP(ctx, hipSetDevice(ctx->device));
@@ -600,11 +662,13 @@ int ck_zone_counts(ck_ctx* ctx, const uint8_t* mask, int n, int in_space, int32_
     CK_TRY(k_zone_counts(ctx, (const uint8_t*)d_in, n, 380, d_cnt));
     if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, counts, d_cnt, (size_t)n * 361 * sizeof(int32_t), CK_HOST));
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 int ck_contour_stones(ck_ctx* ctx, const uint8_t* goban, const uint8_t* fg, int n, int side, int in_space, const int32_t* rects,
                       int rs, int re, int cs, int ce, uint8_t* stones, int16_t* zones, uint8_t* mask)
 {
+    CK_API_BEGIN(ctx)
     if (!ctx) return CK_ERR_ARG;
     if (!goban || !fg || !rects || !stones || n <= 0) return ck_fail(ctx, CK_ERR_ARG, "NULL argument or n <= 0");
     if (side < 19 * 4 || side > 4096) return ck_fail(ctx, CK_ERR_ARG, "goban image side %d", side);
@@ -617,11 +681,13 @@ int ck_contour_stones(ck_ctx* ctx, const uint8_t* goban, const uint8_t* fg, int 
     CK_TRY(ck_to_device(ctx, fg, px, in_space, ctx->in_stage2, &d_fg));
     CK_TRY(k_contour_stones(ctx, (const uint8_t*)d_img, (const uint8_t*)d_fg, n, side, rects, rs, re, cs, ce, stones, zones, mask));
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 int ck_contours_external(ck_ctx* ctx, const uint8_t* edges, int n, int h, int w, int in_space,
                          int32_t* counts, int32_t* table, int table_cap, int32_t* points, int points_cap)
 {
+    CK_API_BEGIN(ctx)
     CK_TRY(check_img(ctx, edges, n, h, w));
     if (!counts || !table || table_cap <= 0) return ck_fail(ctx, CK_ERR_ARG, "NULL table");
     const void* d_in;
@@ -644,11 +710,13 @@ int ck_contours_external(ck_ctx* ctx, const uint8_t* edges, int n, int h, int w,
         }
     }
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 int ck_find_intersections(ck_ctx* ctx, const uint8_t* goban, int n, int side, int in_space, const int16_t* mtx, const int32_t* rects,
                           int16_t* grid, int16_t* lines, int32_t* nlines, uint8_t* edges)
 {
+    CK_API_BEGIN(ctx)
     if (!ctx) return CK_ERR_ARG;
     if (!goban || !mtx || !rects || !grid || n <= 0) return ck_fail(ctx, CK_ERR_ARG, "NULL argument or n <= 0");
     if (side < 19 * 4 || side > 4096) return ck_fail(ctx, CK_ERR_ARG, "goban image side %d", side);
@@ -673,14 +741,9 @@ int ck_find_intersections(ck_ctx* ctx, const uint8_t* goban, int n, int side, in
             ck_update_grid_host(seg, k, rects + 4 * z, g + 2 * z);
         }
     };
-    const int nt = std::min(n, 8);
-    if (nt <= 1) one_image(0);
-    else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; t++) th.emplace_back([&, t]() { for (int f = t; f < n; f += nt) one_image(f); });
-        for (auto& t : th) t.join();
-    }
+    ck_parallel_for(n, 8, one_image);
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 int ck_update_grid(const int32_t* lines, int k, const int32_t* box, int16_t* slot)
@@ -694,6 +757,7 @@ int ck_update_grid(const int32_t* lines, int k, const int32_t* box, int16_t* slo
 
 int ck_mog2_create(ck_ctx* ctx, int h, int w, int* handle)
 {
+    CK_API_BEGIN(ctx)
     if (!ctx || !handle || h <= 0 || w <= 0) return CK_ERR_ARG;
     CK_HIP(ctx, hipSetDevice(ctx->device));
     int idx = -1;
@@ -709,11 +773,13 @@ int ck_mog2_create(ck_ctx* ctx, int h, int w, int* handle)
     CK_HIP(ctx, hipMemsetAsync(st.nmodes.p, 0, npx, ctx->stream));
     *handle = idx;
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 int ck_mog2_apply(ck_ctx* ctx, int handle, const uint8_t* img3, int in_space,
                   double learning_rate, uint8_t* fgmask, int out_space)
 {
+    CK_API_BEGIN(ctx)
     if (!ctx) return CK_ERR_ARG;
     if (handle < 0 || handle >= (int)ctx->mog2.size() || !ctx->mog2[handle].alive)
         return ck_fail(ctx, CK_ERR_ARG, "bad mog2 handle %d", handle);
@@ -728,13 +794,16 @@ int ck_mog2_apply(ck_ctx* ctx, int handle, const uint8_t* img3, int in_space,
     CK_TRY(k_mog2_apply(ctx, st, (const uint8_t*)d_in, learning_rate, d_fg));
     if (out_space == CK_HOST) CK_TRY(ck_from_device(ctx, fgmask, d_fg, npx, CK_HOST));
     return finish(ctx);
+    CK_API_END(ctx)
 }
 
 int ck_mog2_destroy(ck_ctx* ctx, int handle)
 {
+    CK_API_BEGIN(ctx)
     if (!ctx || handle < 0 || handle >= (int)ctx->mog2.size()) return CK_ERR_ARG;
     ctx->mog2[handle].alive = false;
     return CK_OK;
+    CK_API_END(ctx)
 }
 
 }  // extern "C"

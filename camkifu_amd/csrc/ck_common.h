@@ -4,8 +4,12 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
+#include <exception>
 #include <map>
+#include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/camkifu_amd.h"
@@ -29,6 +33,12 @@ struct Mog2State {
     int h = 0, w = 0, nframes = 0;
     DevBuf weight, variance, mean, nmodes;
     bool alive = false;
+    // learning rates of an ordered run: the model's own pinned staging + device copy (k_mog2_run)
+    float* rates_host = nullptr;
+    float* rates_dev = nullptr;
+    size_t rates_cap = 0;
+    hipEvent_t rates_done = nullptr;
+    bool rates_busy = false;
 };
 
 struct CnnWeights {
@@ -42,6 +52,10 @@ struct CnnWeights {
 };
 
 struct ck_ctx {
+    // One thread at a time (include/camkifu_amd.h): `owner` is the token of the thread inside an entry point, 0 when
+    // nobody is; a second thread gets CK_ERR_STATE instead of a silent race on the stream and the scratch buffers.
+    std::atomic<unsigned long long> owner{0};
+    int depth = 0;                   // entry points calling entry points on the owner's thread
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -98,11 +112,78 @@ int ck_ensure_pinned(ck_ctx* ctx, size_t bytes, int which = 0);
                            hipGetErrorString(e__), __FILE__, __LINE__);                   \
     } while (0)
 
+// ---- entry-point bracket: the one-thread-per-context contract, enforced, and nothing thrown across the C ABI ----
+unsigned long long ck_thread_token();
+void ck_note_busy(const ck_ctx* ctx);              // ck_last_error(ctx) on this thread then explains the refusal
+struct CtxCall {
+    ck_ctx* ctx;
+    int code = CK_OK;
+    explicit CtxCall(ck_ctx* c) : ctx(c)
+    {
+        if (!ctx) { code = CK_ERR_ARG; return; }
+        const unsigned long long me = ck_thread_token();
+        unsigned long long nobody = 0;
+        if (ctx->owner.load(std::memory_order_acquire) == me) { ctx->depth++; return; }
+        if (!ctx->owner.compare_exchange_strong(nobody, me, std::memory_order_acq_rel)) {
+            ck_note_busy(ctx);
+            code = CK_ERR_STATE;
+            ctx = nullptr;
+            return;
+        }
+        ctx->depth = 1;
+    }
+    ~CtxCall()
+    {
+        if (ctx && --ctx->depth == 0) ctx->owner.store(0, std::memory_order_release);
+    }
+};
+#define CK_API_BEGIN(ctx)                         \
+    CtxCall call__(ctx);                          \
+    if (call__.code != CK_OK) return call__.code; \
+    try {
+#define CK_API_END(ctx)                                                                                   \
+    } catch (const std::exception& e__) {                                                                 \
+        return ck_fail((ctx), CK_ERR_STATE, "C++ exception inside the library: %s", e__.what());          \
+    } catch (...) {                                                                                       \
+        return ck_fail((ctx), CK_ERR_STATE, "unknown C++ exception inside the library");                  \
+    }
+
 #define CK_TRY(call)                     \
     do {                                 \
         int rc__ = (call);               \
         if (rc__ != CK_OK) return rc__;  \
     } while (0)
+
+// Host loop over independent items on a few threads.  The caller works too; a helper that cannot be started (thread
+// limit) is simply absent; an exception inside a helper is carried back and rethrown on the caller's thread, where
+// the entry point's bracket turns it into an error code.
+template <typename F>
+void ck_parallel_for(int n, int max_threads, F fn)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)(hw ? hw : 4);
+    if (nt > max_threads) nt = max_threads;
+    if (nt > n) nt = n;
+    if (nt <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    std::atomic<int> next{0};
+    std::atomic<bool> failed{false};
+    auto worker = [&]() {
+        try {
+            for (int i; !failed.load(std::memory_order_relaxed) && (i = next.fetch_add(1)) < n;) fn(i);
+        } catch (...) {
+            failed.store(true);
+        }
+    };
+    std::vector<std::thread> th;
+    try {
+        th.reserve(nt - 1);
+        for (int t = 1; t < nt; t++) th.emplace_back(worker);
+    } catch (...) {
+    }
+    worker();
+    for (auto& t : th) t.join();
+    if (failed.load()) throw std::runtime_error("a host worker thread failed (out of memory?)");
+}
 
 // timing brackets: record HIP events on the ctx stream around a group of launches
 struct TimeScope {

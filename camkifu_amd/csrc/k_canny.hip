@@ -160,17 +160,20 @@ __global__ __launch_bounds__(256) void canny_nms_kernel(const uint8_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------
-// Packed variant of the kernel above (the one launched; -DNMS_PACKED=0 builds the scalar one).  Same results; the
-// scalar kernel is VALU-bound at ~178 lane-ops per pixel, this one needs about a third of that:
-//   * gradient phase in packed 16-bit math (v_pk_*): a thread owns 4 adjacent columns as two u16 pairs and walks
-//     3 gradient rows down its 5 pixel rows; one v_perm per tap pair widens the bytes, the separable Sobel, the
-//     |dx| + |dy| magnitude and the first-maximum channel choice (mask by saturating subtract, v_bfi) all work on
-//     pairs.  Columns outside the image are replicated when the tile is staged, so no tap is clamped here.
-//   * the sector (two 32-bit fixed-point tangent tests) is computed in the NMS phase, and only by waves that hold a
-//     pixel above the low threshold -- after the median filter most of a frame is flat.
+// Packed variant of the kernel above (the one launched; -DNMS_PACKED=0 builds the scalar one).  Same results.  The
+// kernel is VALU-bound, so what counts is instructions per pixel (round 2: ~105 lane-ops per pixel, 60 of them in the
+// gradient phase; this version: see DESIGN.md 4):
+//   * gradient phase in packed 16-bit math (v_pk_*): a thread owns 4 adjacent columns as two u16 pairs and walks PK
+//     gradient rows down its PK + 2 pixel rows (the horizontal pass is amortised over PK rows); one v_perm per tap pair
+//     widens the bytes, `2 a + b` is one v_pk_mad.  What it keeps per pixel is ONE 16-bit key = magnitude * 4 + (3 -
+//     channel): the maximum over the three keys is the largest |dx| + |dy| and, on ties, the first channel -- no dx / dy
+//     selects, no dx / dy arrays in LDS.
+//   * NMS phase: a quad of pixels with no key above the low threshold (most of a median-filtered frame) costs one
+//     packed max, two compares and the map store.  A candidate re-derives dx, dy of its channel from the 8 taps still in
+//     the pixel tile, then runs the two fixed-point tangent tests.
 // Tile: 64 x (15 PK - 2) output pixels per 256-thread workgroup (17 column quads x 15 row segments of PK gradient rows).
 #ifndef NMS_PK
-#define NMS_PK 2
+#define NMS_PK 4
 #endif
 constexpr int PK = NMS_PK;                   // gradient rows per thread
 constexpr int PGR = 15 * PK;                 // gradient rows (1-px halo)
@@ -183,6 +186,27 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 widen(uint32_t hi, uint32_t lo, uint32_t sel)
 {
     return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, sel));
+}
+// 2 a + c on both halves in one instruction (the compiler turns the multiplication into a shift and adds separately)
+__device__ __forceinline__ u16x2 mad2(u16x2 a, u16x2 c)
+{
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, a)), "v"(__builtin_bit_cast(uint32_t, c)));
+    return __builtin_bit_cast(u16x2, r);
+}
+__device__ __forceinline__ s16x2 mad2(s16x2 a, s16x2 c)
+{
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, a)), "v"(__builtin_bit_cast(uint32_t, c)));
+    return __builtin_bit_cast(s16x2, r);
+}
+// 4 m + TAG on both halves
+template <int TAG>
+__device__ __forceinline__ u16x2 key_of(u16x2 m)
+{
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, 4, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, m)), "n"(TAG));
+    return __builtin_bit_cast(u16x2, r);
 }
 
 __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __restrict__ planes, int h, int w, int pitch,
@@ -214,9 +238,8 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
     __shared__ uint32_t smem[PXW > CBUF ? PXW : CBUF];
     uint32_t (*pxw)[PLH][LWD] = reinterpret_cast<uint32_t (*)[PLH][LWD]>(smem);
     int32_t* cbuf = reinterpret_cast<int32_t*>(smem);
-    __shared__ __attribute__((aligned(8))) uint16_t mag[PGR][PGW];
-    __shared__ __attribute__((aligned(16))) int16_t gxy[2][PGR][PGW];       // dx, dy of the chosen channel; later the tile-local parents
-    int16_t (*gdx)[PGW] = gxy[0], (*gdy)[PGW] = gxy[1];
+    __shared__ __attribute__((aligned(8))) uint16_t mag[PGR][PGW];          // keys: magnitude * 4 + (3 - channel)
+    __shared__ __attribute__((aligned(16))) int lab[PTH * TW];              // tile-local union-find parents
     __shared__ int ccount, cbase;
     const int ox = bxi * TW, oy = byi * PTH;
     const int tid = threadIdx.x;
@@ -224,26 +247,37 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
     if (tid == 0) ccount = 0;
 
     const uint32_t plane = (uint32_t)h * pitch;
-    for (int i = tid; i < PLH * LWD; i += 256) {
-        const int r = i / LWD, cd = i % LWD;
-        int y = oy - 2 + r;
-        y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-        const int x = ox - 4 + 4 * cd;                 // pitch is a multiple of 64 and ox of 64: aligned
-        const uint8_t* row = base + (uint32_t)(y * pitch);
-        if (x >= 0 && x + 3 < w) {
+    if (ox >= 4 && ox + TW + 4 <= w && oy >= 2 && oy + PTH + 2 <= h) {
+        // interior tile (all but the frame's rim): no clamping, one address computation per dword triple
+        const uint8_t* org = base + (uint32_t)((oy - 2) * pitch) + (ox - 4);
+        for (int i = tid; i < PLH * LWD; i += 256) {
+            const int r = i / LWD, cd = i - r * LWD;
+            const uint8_t* q = org + (uint32_t)(r * pitch) + 4 * cd;
 #pragma unroll
-            for (int c = 0; c < 3; c++) pxw[c][r][cd] = *reinterpret_cast<const uint32_t*>(row + c * plane + x);
-        } else {
+            for (int c = 0; c < 3; c++) pxw[c][r][cd] = *reinterpret_cast<const uint32_t*>(q + c * plane);
+        }
+    } else {
+        for (int i = tid; i < PLH * LWD; i += 256) {
+            const int r = i / LWD, cd = i % LWD;
+            int y = oy - 2 + r;
+            y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+            const int x = ox - 4 + 4 * cd;                 // pitch is a multiple of 64 and ox of 64: aligned
+            const uint8_t* row = base + (uint32_t)(y * pitch);
+            if (x >= 0 && x + 3 < w) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                uint32_t v = 0;
+                for (int c = 0; c < 3; c++) pxw[c][r][cd] = *reinterpret_cast<const uint32_t*>(row + c * plane + x);
+            } else {
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    int xc = x + k;
-                    xc = xc < 0 ? 0 : (xc > w - 1 ? w - 1 : xc);
-                    v |= (uint32_t)row[c * plane + xc] << (8 * k);
+                for (int c = 0; c < 3; c++) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        int xc = x + k;
+                        xc = xc < 0 ? 0 : (xc > w - 1 ? w - 1 : xc);
+                        v |= (uint32_t)row[c * plane + xc] << (8 * k);
+                    }
+                    pxw[c][r][cd] = v;
                 }
-                pxw[c][r][cd] = v;
             }
         }
     }
@@ -269,39 +303,30 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
                 const u16x2 p12 = widen(B, A, 0x0c020c01u), p23 = widen(B, A, 0x0c030c02u), p34 = widen(B, A, 0x0c040c03u),
                             p45 = widen(B, A, 0x0c050c04u), p56 = widen(B, A, 0x0c060c05u);
                 hdP[k % 3][c] = __builtin_bit_cast(s16x2, (u16x2)(p34 - p12));
-                hsP[k % 3][c] = p23 * (unsigned short)2 + p12 + p34;
+                hsP[k % 3][c] = mad2(p23, p12) + p34;
                 hdQ[k % 3][c] = __builtin_bit_cast(s16x2, (u16x2)(p56 - p34));
-                hsQ[k % 3][c] = p45 * (unsigned short)2 + p34 + p56;
+                hsQ[k % 3][c] = mad2(p45, p34) + p56;
             }
             if (k >= 2) {
                 const int gr = seg * PK + k - 2;       // gradient row  <->  y = oy - 1 + gr
                 const int y = oy - 1 + gr;
                 const unsigned short ym = (y >= 0 && y < h) ? 0xFFFF : 0;
-                auto grad = [&](const s16x2 (&hd)[3][3], const u16x2 (&hs)[3][3], u16x2 xm, u16x2& best, s16x2& bdx, s16x2& bdy) {
+                auto key3 = [&](const s16x2 (&hd)[3][3], const u16x2 (&hs)[3][3]) {
+                    u16x2 best;
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        const s16x2 dx = hd[(k - 2) % 3][c] + hd[(k - 1) % 3][c] * (short)2 + hd[k % 3][c];
+                        const s16x2 dx = mad2(hd[(k - 1) % 3][c], hd[(k - 2) % 3][c]) + hd[k % 3][c];
                         const s16x2 dy = __builtin_bit_cast(s16x2, (u16x2)(hs[k % 3][c] - hs[(k - 2) % 3][c]));
                         const u16x2 m = __builtin_bit_cast(u16x2, (s16x2)(__builtin_elementwise_max(dx, -dx) + __builtin_elementwise_max(dy, -dy)));
-                        if (c == 0) { best = m; bdx = dx; bdy = dy; }
-                        else {
-                            // strictly greater takes over (the first maximum wins, as in the scalar loop)
-                            const s16x2 gt = (__builtin_bit_cast(s16x2, best) - __builtin_bit_cast(s16x2, m)) >> (short)15;   // magnitudes < 2^15
-                            const uint32_t g = __builtin_bit_cast(uint32_t, gt);
-                            best = __builtin_elementwise_max(best, m);
-                            bdx = __builtin_bit_cast(s16x2, (__builtin_bit_cast(uint32_t, dx) & g) | (__builtin_bit_cast(uint32_t, bdx) & ~g));
-                            bdy = __builtin_bit_cast(s16x2, (__builtin_bit_cast(uint32_t, dy) & g) | (__builtin_bit_cast(uint32_t, bdy) & ~g));
-                        }
+                        // the largest key = the largest magnitude, and among equals the first channel
+                        if (c == 0) best = key_of<3>(m);
+                        else if (c == 1) best = __builtin_elementwise_max(best, key_of<2>(m));
+                        else best = __builtin_elementwise_max(best, key_of<1>(m));
                     }
-                    best = best & xm & ym;             // outside the image the magnitude is 0
+                    return best;
                 };
-                u16x2 bP, bQ;
-                s16x2 dxP, dyP, dxQ, dyQ;
-                grad(hdP, hsP, xmP, bP, dxP, dyP);
-                grad(hdQ, hsQ, xmQ, bQ, dxQ, dyQ);
+                const u16x2 bP = key3(hdP, hsP) & xmP & ym, bQ = key3(hdQ, hsQ) & xmQ & ym;   // outside the image: 0
                 *reinterpret_cast<uint2*>(&mag[gr][4 * cj]) = make_uint2(__builtin_bit_cast(uint32_t, bP), __builtin_bit_cast(uint32_t, bQ));
-                *reinterpret_cast<uint2*>(&gdx[gr][4 * cj]) = make_uint2(__builtin_bit_cast(uint32_t, dxP), __builtin_bit_cast(uint32_t, dxQ));
-                *reinterpret_cast<uint2*>(&gdy[gr][4 * cj]) = make_uint2(__builtin_bit_cast(uint32_t, dyP), __builtin_bit_cast(uint32_t, dyQ));
             }
         }
     }
@@ -310,6 +335,8 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
     // NMS: one thread = 4 consecutive pixels of one row (one dword of the map)
     const int TG22 = 13573;   // (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
     const uint16_t* magf = &mag[0][0];
+    const uint8_t* pxb = reinterpret_cast<const uint8_t*>(smem);
+    const unsigned lowkey = (unsigned)(low < 0 ? 0 : (low > 8191 ? 8191 : low)) * 4u + 3u;     // m > low  <=>  key > 4 low + 3
     constexpr int NQ = (PTH * 16 + 255) / 256;
     int km[NQ];
 #pragma unroll
@@ -324,25 +351,35 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
         if (y < h) {
             const int i0 = (r + 1) * PGW + col0 + 2;   // output pixel (r, col)  <->  gradient (r + 1, array column col + 2)
             const uint32_t m01 = *reinterpret_cast<const uint32_t*>(magf + i0), m23 = *reinterpret_cast<const uint32_t*>(magf + i0 + 2);
-            const int mk[4] = {(int)(m01 & 0xFFFF), (int)(m01 >> 16), (int)(m23 & 0xFFFF), (int)(m23 >> 16)};
+            const uint32_t top = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, m01), __builtin_bit_cast(u16x2, m23)));
+            const bool any = (low < 0) || (top & 0xFFFFu) > lowkey || (top >> 16) > lowkey;      // keys beyond the image are 0
+            if (__builtin_amdgcn_ballot_w64(any) != 0 && any) {
+                const unsigned kk[4] = {m01 & 0xFFFFu, m01 >> 16, m23 & 0xFFFFu, m23 >> 16};
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int m = mk[k];
-                const bool candp = m > low && ox + col0 + k < w;
-                if (__builtin_amdgcn_ballot_w64(candp) == 0) continue;      // whole wave flat here
-                if (candp) {
-                    const int i = i0 + k;
-                    const int bdx = (&gdx[0][0])[i], bdy = (&gdy[0][0])[i];
-                    const int ax = abs(bdx), ay = abs(bdy) << 15;
-                    const int tg22x = ax * TG22;
-                    int o, m2 = m;
-                    if (ay < tg22x) { o = 1; m2 = m + 1; }                             // sector 0: left, right (>=)
-                    else if (ay > tg22x + (ax << 16)) { o = PGW; m2 = m + 1; }         // sector 1: up, down (>=)
-                    else o = ((bdx ^ bdy) < 0) ? PGW - 1 : PGW + 1;                    // diagonals
-                    if (m > magf[i - o] && m2 > magf[i + o]) {
-                        const uint32_t v = m > high ? 2u : 0u;
-                        mapw = (mapw & ~(0xFFu << (8 * k))) | (v << (8 * k));
-                        keepmask |= 1 << k;
+                for (int k = 0; k < 4; k++) {
+                    const int m = (int)(kk[k] >> 2);
+                    if (m > low && ox + col0 + k < w) {
+                        const int i = i0 + k;
+                        // dx, dy of the chosen channel from its 8 taps: gradient (gr, idx) = pixel-tile rows gr .. gr + 2,
+                        // bytes idx + 1 .. idx + 3 of the row
+                        const int c = 3 - (int)(kk[k] & 3u);
+                        const uint8_t* t0 = pxb + ((c * PLH + r + 1) * LWD) * 4 + col0 + k + 3;
+                        const uint8_t* t1 = t0 + LWD * 4;
+                        const uint8_t* t2 = t1 + LWD * 4;
+                        const int a00 = t0[0], a01 = t0[1], a02 = t0[2], a10 = t1[0], a12 = t1[2], a20 = t2[0], a21 = t2[1], a22 = t2[2];
+                        const int bdx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
+                        const int bdy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
+                        const int ax = abs(bdx), ay = abs(bdy) << 15;
+                        const int tg22x = ax * TG22;
+                        int o, m2 = m;
+                        if (ay < tg22x) { o = 1; m2 = m + 1; }                             // sector 0: left, right (>=)
+                        else if (ay > tg22x + (ax << 16)) { o = PGW; m2 = m + 1; }         // sector 1: up, down (>=)
+                        else o = ((bdx ^ bdy) < 0) ? PGW - 1 : PGW + 1;                    // diagonals
+                        if (m > (int)(magf[i - o] >> 2) && m2 > (int)(magf[i + o] >> 2)) {
+                            const uint32_t v = m > high ? 2u : 0u;
+                            mapw = (mapw & ~(0xFFu << (8 * k))) | (v << (8 * k));
+                            keepmask |= 1 << k;
+                        }
                     }
                 }
             }
@@ -366,9 +403,6 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
     // neighbours inside this tile, so the global pass (canny_link_kernel) only has to visit the candidates on the
     // tile's left, right and top edges.  Hooking is by smaller index and local order = raster order, so a local root
     // is the first pixel of its local component, as the global structure wants.
-    __syncthreads();                                   // magnitudes and gradients are dead: their space holds the parents
-    int* lab = reinterpret_cast<int*>(&gxy[0][0][0]);
-    static_assert(sizeof(gxy) >= PTH * TW * 4, "parents fit the gradient arrays");
 #pragma unroll
     for (int it = 0; it < NQ; it++) {
         const int q = tid + 256 * it;
@@ -382,7 +416,7 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
         v.w = (km[it] & 8) ? ((km[it] & 4) ? v.z : 4 * q + 3) : -1;
         *reinterpret_cast<int4*>(lab + 4 * q) = v;
     }
-    __syncthreads();
+    __syncthreads();                                   // parents in place; the pixel tile is dead from here on (cbuf)
     auto lfind = [&](int a) {
         int p = __hip_atomic_load(lab + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         while (p != a) { a = p; p = __hip_atomic_load(lab + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -418,6 +452,8 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
         }
     }
     __syncthreads();
+#else
+    __syncthreads();                                   // the pixel tile is dead from here on (cbuf)
 #endif
 #pragma unroll
     for (int it = 0; it < NQ; it++) {

@@ -51,7 +51,7 @@ __device__ __forceinline__ void mix_store(const Mix& m, float* __restrict__ gw_,
 }
 
 // one frame's update of one pixel (Zivkovic's update with the library defaults); returns "background"
-__device__ __forceinline__ bool mix_update(Mix& m, const float data[3], float alphaT, float prune)
+__device__ __forceinline__ bool mix_update(Mix& m, const float x0, const float x1, const float x2, float alphaT, float prune)
 {
 #pragma clang fp contract(off)
     const float Tb = 16.f, Tg = 9.f, TB = 0.9f;
@@ -72,9 +72,9 @@ __device__ __forceinline__ bool mix_update(Mix& m, const float data[3], float al
             int dst = mode;
             if (!fitsPDF) {
                 const float var = gv[mode];
-                const float d0 = mean[mode][0] - data[0];
-                const float d1 = mean[mode][1] - data[1];
-                const float d2 = mean[mode][2] - data[2];
+                const float d0 = mean[mode][0] - x0;
+                const float d1 = mean[mode][1] - x1;
+                const float d2 = mean[mode][2] - x2;
                 const float dist2 = d0 * d0 + d1 * d1 + d2 * d2;
                 if (totalWeight < TB && dist2 < Tb * var) background = true;
                 if (dist2 < Tg * var) {
@@ -103,7 +103,10 @@ __device__ __forceinline__ bool mix_update(Mix& m, const float data[3], float al
                 }
             }
             if (weight < -prune) { weight = 0.f; bound--; }
-            gw[dst] = weight;
+            // `dst` is a run-time value: a plain gw[dst] would send the whole mixture to scratch memory
+#pragma unroll
+            for (int k = 0; k < NMIX; k++)
+                if (k <= mode) gw[k] = (k == dst) ? weight : gw[k];
             totalWeight += weight;
         }
     }
@@ -126,8 +129,14 @@ __device__ __forceinline__ bool mix_update(Mix& m, const float data[3], float al
         // write into slot `mode`, then bubble up while alphaT is not smaller than the one above
         int dst = mode;
 #pragma unroll
-        for (int k = 0; k < NMIX; k++)
-            if (k == mode) { gw[k] = nw; gv[k] = varInit; mean[k][0] = data[0]; mean[k][1] = data[1]; mean[k][2] = data[2]; }
+        for (int k = 0; k < NMIX; k++) {              // selects, not branches: the compiler turns an if-chain on a
+            const bool here = k == mode;              // run-time slot into a pointer to a scratch copy of the mixture
+            gw[k] = here ? nw : gw[k];
+            gv[k] = here ? varInit : gv[k];
+            mean[k][0] = here ? x0 : mean[k][0];
+            mean[k][1] = here ? x1 : mean[k][1];
+            mean[k][2] = here ? x2 : mean[k][2];
+        }
 #pragma unroll
         for (int i = NMIX - 1; i > 0; i--) {
             if (i <= nmodes - 1 && i == dst && !(alphaT < gw[i - 1])) {
@@ -153,10 +162,8 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t* __restrict__ i
     if (px >= npx) return;
     Mix m;
     mix_load(m, gw_, gv_, mean_, nmodes_, npx, px);
-    float data[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) data[c] = (float)img[(size_t)px * 3 + c];
-    const bool background = mix_update(m, data, alphaT, prune);
+    const uint8_t* q = img + (size_t)px * 3;
+    const bool background = mix_update(m, (float)q[0], (float)q[1], (float)q[2], alphaT, prune);
     mix_store(m, gw_, gv_, mean_, nmodes_, npx, px);
     fg[px] = background ? 0 : 255;
 }
@@ -191,29 +198,40 @@ __global__ __launch_bounds__(ZTHREADS) void mog2_run_kernel(const uint8_t* __res
     Mix m;
     if (live) mix_load(m, gw_, gv_, mean_, nmodes_, npx, px);
     bool background = true;
-    // frames in groups of four: the twelve byte loads of a group are issued together (one round of memory latency per
-    // four updates instead of one per update), the updates then run back to back
+    // Frames in groups of GRP, software-pipelined: the byte loads of group g + 1 are in flight while the updates of
+    // group g run back to back.  The pixel loads do not depend on the mixture state -- only the update is a chain.
     constexpr int GRP = 4;
+    uint8_t cur[GRP][3], nxt[GRP][3];
+    const uint8_t* base = gobans + (size_t)(live ? px : 0) * 3;
+    const size_t fstride = (size_t)npx * 3;
+#pragma unroll
+    for (int j = 0; j < GRP; j++) {
+        const uint8_t* q = base + (size_t)(j < nframes ? j : nframes - 1) * fstride;
+#pragma unroll
+        for (int c = 0; c < 3; c++) cur[j][c] = q[c];
+    }
     for (int f0 = 0; f0 < nframes; f0 += GRP) {
-        uint8_t raw[GRP][3];
 #pragma unroll
         for (int j = 0; j < GRP; j++) {
-            const int f = f0 + j < nframes ? f0 + j : nframes - 1;
-            const uint8_t* q = gobans + ((size_t)f * npx + (live ? px : 0)) * 3;
+            const int f = f0 + GRP + j < nframes ? f0 + GRP + j : nframes - 1;
+            const uint8_t* q = base + (size_t)f * fstride;
 #pragma unroll
-            for (int c = 0; c < 3; c++) raw[j][c] = q[c];
+            for (int c = 0; c < 3; c++) nxt[j][c] = q[c];
         }
 #pragma unroll
         for (int j = 0; j < GRP; j++) {
             const int f = f0 + j;
             if (f < nframes) {                              // uniform across the workgroup
-                const float data[3] = { (float)raw[j][0], (float)raw[j][1], (float)raw[j][2] };
                 const float2 r = rates[f];
-                if (live) background = mix_update(m, data, r.x, r.y);
+                if (live) background = mix_update(m, (float)cur[j][0], (float)cur[j][1], (float)cur[j][2], r.x, r.y);
                 const unsigned long long fgmask = __ballot(counted && !background);
                 if ((t & 63) == 0 && fgmask) atomicAdd(&zcount[f], __popcll(fgmask));
             }
         }
+#pragma unroll
+        for (int j = 0; j < GRP; j++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) cur[j][c] = nxt[j][c];
     }
     if (live) {
         mix_store(m, gw_, gv_, mean_, nmodes_, npx, px);
@@ -260,18 +278,31 @@ int k_mog2_run(ck_ctx* ctx, Mog2State& st, const uint8_t* d_gobans, int n, const
 {
     TimeScope ts(ctx, "mog2");
     if (n > 8192) return ck_fail(ctx, CK_ERR_CAPACITY, "mog2 run: %d frames in one run (max 8192)", n);
-    std::vector<float> rates((size_t)n * 2);
-    for (int f = 0; f < n; f++) {
+    for (int f = 0; f < n; f++)                                     // validate BEFORE the model's frame count moves
         if (learning_rates[f] >= 1) return ck_fail(ctx, CK_ERR_ARG, "mog2 run: learning rate >= 1 (model reset) inside a run");
-        mog2_rate(st, learning_rates[f], &rates[2 * (size_t)f], &rates[2 * (size_t)f + 1]);
+    // the rates travel through the model's OWN pinned + device buffers (not the context's shared scratch)
+    const size_t rbytes = (size_t)n * 2 * sizeof(float);
+    if (st.rates_cap < rbytes) {
+        if (st.rates_host) CK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // a queued run may still read the old ones
+        if (st.rates_host) (void)hipHostFree(st.rates_host);
+        if (st.rates_dev) (void)hipFree(st.rates_dev);
+        st.rates_host = nullptr; st.rates_dev = nullptr; st.rates_cap = 0;
+        const size_t cap = rbytes < 4096 ? 4096 : rbytes * 2;
+        CK_HIP(ctx, hipHostMalloc((void**)&st.rates_host, cap, hipHostMallocDefault));
+        CK_HIP(ctx, hipMalloc((void**)&st.rates_dev, cap));
+        st.rates_cap = cap;
+    } else if (st.rates_busy) {
+        CK_HIP(ctx, hipEventSynchronize(st.rates_done));                        // previous upload has left the host buffer
     }
-    CK_TRY(ck_ensure(ctx, ctx->mats, rates.size() * sizeof(float)));
-    CK_HIP(ctx, hipMemcpyAsync(ctx->mats.p, rates.data(), rates.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    CK_HIP(ctx, hipStreamSynchronize(ctx->stream));                 // `rates` is a local
+    if (!st.rates_done) CK_HIP(ctx, hipEventCreateWithFlags(&st.rates_done, hipEventDisableTiming));
+    for (int f = 0; f < n; f++) mog2_rate(st, learning_rates[f], &st.rates_host[2 * (size_t)f], &st.rates_host[2 * (size_t)f + 1]);
+    CK_HIP(ctx, hipMemcpyAsync(st.rates_dev, st.rates_host, rbytes, hipMemcpyHostToDevice, ctx->stream));
+    CK_HIP(ctx, hipEventRecord(st.rates_done, ctx->stream));
+    st.rates_busy = true;
     const int zones = ((st.h + ZONE - 1) / ZONE) * ((st.w + ZONE - 1) / ZONE);
     hipLaunchKernelGGL(mog2_run_kernel, dim3(zones), dim3(ZTHREADS), (size_t)n * sizeof(int), ctx->stream,
                        d_gobans, n, st.h, st.w, skip_row, skip_col, (float*)st.weight.p, (float*)st.variance.p, (float*)st.mean.p,
-                       (uint8_t*)st.nmodes.p, (const float2*)ctx->mats.p, d_fgcount, d_last_fg);
+                       (uint8_t*)st.nmodes.p, (const float2*)st.rates_dev, d_fgcount, d_last_fg);
     CK_HIP(ctx, hipGetLastError());
     return CK_OK;
 }

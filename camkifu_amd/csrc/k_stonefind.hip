@@ -100,18 +100,7 @@ __global__ __launch_bounds__(64) void zone_sums_kernel(const uint8_t* __restrict
 }
 
 template <typename F>
-void frames_parallel(int n, F fn)
-{
-    unsigned hw = std::thread::hardware_concurrency();
-    int nt = (int)(hw ? hw : 4);
-    if (nt > 16) nt = 16;
-    if (nt > n) nt = n;
-    if (nt <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; t++)
-        th.emplace_back([=]() { for (int i = t; i < n; i += nt) fn(i); });
-    for (auto& t : th) t.join();
-}
+void frames_parallel(int n, F fn) { ck_parallel_for(n, 16, fn); }
 
 struct Box { float w, h, angle; };
 

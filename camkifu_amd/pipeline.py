@@ -289,10 +289,33 @@ class GpuCore:
 
     def __init__(self, lanes, bg_ctx=None, local_model=True):
         from concurrent.futures import ThreadPoolExecutor
-        self.lanes = [(b if b is not None else s, s) for b, s in lanes]
-        self.pools = [(ThreadPoolExecutor(1), ThreadPoolExecutor(1)) for _ in self.lanes]
-        self.bg_ctx = bg_ctx if bg_ctx is not None else self.lanes[0][1]
-        self.bg_pool = ThreadPoolExecutor(1)                 # FIFO: batches go through the model in submission order
+        # A context belongs to ONE thread (the library refuses a second one: CK_ERR_STATE).  A lane given without a board
+        # context, or a core given without a model context, gets one of its own when the stones context is a real
+        # capi.Context; with stand-in contexts (tests) the orphan work shares the stones context AND its thread.
+        self.lanes, self.pools = [], []
+        for b, s in lanes:
+            ps = ThreadPoolExecutor(1)
+            if b is None and isinstance(s, capi.Context):
+                b = capi.Context(s.device)
+            if b is None or b is s:
+                self.lanes.append((s, s))
+                self.pools.append((ps, ps))
+            else:
+                self.lanes.append((b, s))
+                self.pools.append((ThreadPoolExecutor(1), ps))
+        first = self.lanes[0][1]
+        if bg_ctx is None and local_model and isinstance(first, capi.Context):
+            bg_ctx = capi.Context(first.device)
+        if bg_ctx is None:
+            bg_ctx = first
+        self.bg_ctx, self.bg_pool = bg_ctx, None
+        for (b, s), (pb, ps) in zip(self.lanes, self.pools):          # the model's context is a lane's: use that lane's thread
+            if bg_ctx is b:
+                self.bg_pool = pb
+            elif bg_ctx is s:
+                self.bg_pool = ps
+        if self.bg_pool is None:
+            self.bg_pool = ThreadPoolExecutor(1)             # FIFO: batches go through the model in submission order
         self.local_model, self._handle = local_model, None
         import threading
         self._turn, self._issued, self._served = threading.Condition(), 0, 0
@@ -386,14 +409,35 @@ class GpuCore:
         return self.bg_ctx.mog2_band_run(self._handle, gobans, rates, last_band=True)
 
 
+class _Ticket:
+    """one batch on its way through the stages: GPU core -> exchange (records, transform, bands, counts) -> stones fold"""
+    __slots__ = ("core", "exchange", "mtx", "rates", "n_total", "frames", "have_mtx")
+
+    def __init__(self, core, mtx, rates, n_total, frames):
+        self.core, self.exchange = core, None
+        self.mtx, self.rates, self.n_total, self.frames = mtx, rates, n_total, frames
+        self.have_mtx = mtx is not None
+
+
 class FastFilePipeline:
     """process_batch(my_frames, n_total): this rank's shard of a batch -> (on rank 0) the requests the fold emitted.
-    submit() / finish() split it so that the host part of batch k (records, collectives, fold) overlaps the GPU part
-    of batch k + 1; the transform a batch is warped with is the one known when it is submitted.
 
-    `compute(frames, mtx, learning_rates)` is the per-shard GPU core (default: GpuCore over the given contexts).  It
-    returns (board, region_label, region_conf, fgcount or None, gobans or None); `gobans` (n x 380 x 380 x 3) is only
-    handed back when world > 1, for the pixel-sharded background model."""
+    A batch goes through three stages, each on its own thread, so that batch k's stones fold overlaps batch k + 1's
+    exchange, which overlaps batch k + 2's GPU core (submit() / finish() keep two batches in flight):
+
+      1. GPU core (`compute`, default GpuCore over the given contexts): board path + stones path of this rank's frames.
+      2. exchange, ONE thread per rank that issues every collective, batch after batch in submission order, so all
+         ranks issue the same collectives in the same order: records packed -> all-gather -> (rank 0) the ordered board
+         fold, which only needs the records -> the transform broadcast -> all-to-all of goban bands -> this rank's band
+         of the background model through the whole batch in frame order, on the model's OWN context (`ctx_bg`, never
+         a lane's) -> all-gather of the foreground counts.
+      3. stones fold on rank 0 (finish(), the caller's thread): the library's ordered policy over records + counts.
+
+    The transform a batch is warped with is the one published by the last finish() before its submit(), whatever the
+    threads' timing: same results at any world size and any overlap.
+
+    `compute(frames, mtx, learning_rates)` returns (board, region_label, region_conf, fgcount or None, gobans or None);
+    `gobans` (n x 380 x 380 x 3) is only handed back when world > 1, for the pixel-sharded background model."""
 
     def __init__(self, h, w, controller, ctx=None, rank=0, world=1, device=None, compute=None, ctx_board=None,
                  bg_init_frames=50, band_model=None, lanes=None, ctx_bg=None, board_lazy=False):
@@ -401,11 +445,13 @@ class FastFilePipeline:
         self.h, self.w = h, w
         self.rank, self.world = rank, world
         self.group = _Group(rank, world, device)
-        self.ctx = ctx if ctx is not None else (lanes[0][1] if lanes else None)
+        self.ctx = ctx if ctx is not None else (lanes[0][1] if lanes else None)      # frame source helper (process_y4m)
+        self.ctx_bg = ctx_bg
         if compute is None:
             compute = GpuCore(lanes or [(ctx_board, ctx)], bg_ctx=ctx_bg, local_model=(world == 1))
         self.compute = compute
         self._runner = ThreadPoolExecutor(2)                  # two batches may be inside the GPU core at once
+        self._comm = ThreadPoolExecutor(1)                    # stage 2: every collective of this rank, in batch order
         self.board = BoardFold(h, w)
         self.stones = StonesFold(controller, bg_init_frames)
         self.bg_init_frames, self.stone_frames = bg_init_frames, 0      # frames the stones path has been given (every rank counts)
@@ -414,17 +460,20 @@ class FastFilePipeline:
         self.band = band_rows(world)[rank]
         self.band_model = band_model                          # callable(gobans_band (n, rows, 380, 3), rates) -> counts (n, band, 19)
         self.errors = []
-        self.host_seconds = dict(pack=0.0, collectives=0.0, fold=0.0)
-        # hold-off-aware mode (one rank): the GPU core leaves the board path out and the fold computes, through the first
-        # lane's board context, only the records it looks at.  With frames dealt across ranks the fold would have to ask
-        # other ranks for theirs: not built, the full records are computed then.
+        self.host_seconds = dict(pack=0.0, collectives=0.0, band_model=0.0, fold=0.0, fold_board=0.0, fold_stones=0.0,
+                                 gather=0.0, bcast=0.0, band_exchange=0.0, counts_gather=0.0)
+        # hold-off-aware mode (one rank): the GPU core leaves the board path out and the board fold computes, through the
+        # lanes' board contexts (on their own threads), only the records it looks at.  With frames dealt across ranks
+        # the fold would have to ask other ranks for theirs: not built, the full records are computed then.
         self.board_lazy = bool(board_lazy) and world == 1 and hasattr(self.compute, "lanes")
 
     # ---- pixel-sharded background model (world > 1) -------------------------------------------------------
     def _band_counts(self, gobans, n_total, rates):
         """all-to-all of goban bands, this rank's band through the whole batch in frame order -> its counts
         (n_total, band rows, 19)"""
+        import time
         import torch
+        t0 = time.perf_counter()
         bands = band_rows(self.world)
         px = [(20 * a, min(20 * b, 380)) for a, b in bands]
         if gobans is None:
@@ -437,21 +486,34 @@ class FastFilePipeline:
         expect = [len(shard_indices(n_total, src, self.world)) * (hi - lo) * 380 * 3 for src in range(self.world)]
         parts = self.group.all_to_all_bands([gobans[:, a:b].contiguous() for a, b in px], expect)
         full = torch.empty((n_total, hi - lo, 380, 3), dtype=torch.uint8, device=parts[0].device)
-        for src, part in enumerate(parts):
-            idx = shard_indices(n_total, src, self.world)
-            full[torch.as_tensor(idx, device=full.device)] = part.reshape(len(idx), hi - lo, 380, 3)
+        for src, part in enumerate(parts):                        # frame f of the batch came from rank f mod world
+            full[src::self.world] = part.reshape(-1, hi - lo, 380, 3)
+        if full.is_cuda:
+            torch.cuda.current_stream(full.device).synchronize()
+        t1 = time.perf_counter()
         counts = self._band_model()(full, rates)
         counts = counts.cpu().numpy() if hasattr(counts, "cpu") else np.asarray(counts)
+        t2 = time.perf_counter()
+        self.host_seconds["band_exchange"] += t1 - t0
+        self.host_seconds["band_model"] += t2 - t1
         return counts.astype(np.int32).reshape(n_total, bands[self.rank][1] - bands[self.rank][0], gsize)
 
     def _band_model(self):
+        """this rank's band of the background model on ITS OWN context: a lane's context belongs to that lane's thread,
+        which is inside the next batch while this one is being exchanged"""
         if self.band_model is None:
+            if self.ctx_bg is None:
+                dev = getattr(self.ctx, "device", None)
+                if dev is None:
+                    raise RuntimeError("the pixel-sharded background model needs a context of its own (ctx_bg=...)")
+                self.ctx_bg = capi.Context(dev)
             a, b = self.band
-            handle = self.ctx.mog2_create(min(20 * b, 380) - 20 * a, 380)
+            bg = self.ctx_bg
+            handle = bg.mog2_create(min(20 * b, 380) - 20 * a, 380)
             last = b == gsize
 
             def run(band_gobans, rates):
-                return self.ctx.mog2_band_run(handle, band_gobans, rates, last_band=last)
+                return bg.mog2_band_run(handle, band_gobans, rates, last_band=last)
             self.band_model = run
         return self.band_model
 
@@ -469,7 +531,7 @@ class FastFilePipeline:
             return blank, why
 
     def submit(self, my_frames, n_total):
-        """start the GPU part of a batch (my_frames: frames rank, rank + world, ... of it) -> ticket for finish()"""
+        """start a batch (my_frames: frames rank, rank + world, ... of it) -> ticket for finish()"""
         mtx = self.mtx
         rates = learning_rates(self.stone_frames, n_total, self.bg_init_frames) if mtx is not None else np.zeros(n_total)
         if mtx is not None:
@@ -477,71 +539,114 @@ class FastFilePipeline:
         mine = shard_indices(n_total, self.rank, self.world)
         rates_for_core = rates if self.world == 1 else rates[mine]
         seq = self.compute.ticket() if hasattr(self.compute, "ticket") else None
-        return self._runner.submit(self._guarded, my_frames, mtx, rates_for_core, len(mine), seq), mtx, rates, n_total, my_frames
+        t = _Ticket(self._runner.submit(self._guarded, my_frames, mtx, rates_for_core, len(mine), seq), mtx, rates, n_total, my_frames)
+        t.exchange = self._comm.submit(self._exchange, t)
+        return t
 
-    def finish(self, ticket):
-        """records, collectives, fold (rank 0), transform broadcast -> the fold's per-frame request lists on rank 0,
-        None elsewhere"""
+    def _exchange(self, t):
+        """stage 2 (this rank's exchange thread) -> (records of the whole batch, counts or None, transform after this
+        batch, failure seen by any rank)"""
         import time
-        fut, mtx, rates, n_total, my_frames = ticket
-        (board, rl, rc, fg, gobans), failure = fut.result()
+        hs = self.host_seconds
+        (board, rl, rc, fg, gobans), failure = t.core.result()
         if failure is not None:
             self.errors.append(failure)
+        n_total = t.n_total
         t0 = time.perf_counter()
         rec = pack_records(board, rl, rc, failed=failure is not None)
         t1 = time.perf_counter()
+        hs["pack"] += t1 - t0
         if self.world == 1:
-            full, counts = rec, fg
+            full, counts, failed = rec, fg, failure is not None
         else:
+            # row 0 of every rank's contribution is a header: a rank whose shard is empty can still say that it failed
             per = (n_total + self.world - 1) // self.world
-            got = self.group.all_gather_rows(rec, per)
+            mine = np.zeros(len(rec) + 1, REC)
+            mine[0]["flags"] = FLAG_FAILED if failure is not None else 0
+            mine[0]["n_lines"] = len(rec)
+            mine[1:] = rec
+            got = self.group.all_gather_rows(mine, per + 1)
             full = np.zeros(n_total, REC)
             for r in range(self.world):
-                idx = shard_indices(n_total, r, self.world)
-                full[idx] = got[r, :len(idx)]
+                k = len(shard_indices(n_total, r, self.world))
+                full[r::self.world] = got[r, 1:1 + k]
+            failed = bool((got[:, 0]["flags"] & FLAG_FAILED).any())
+            t2 = time.perf_counter()
+            hs["gather"] += t2 - t1
             counts = None
-            if mtx is not None:
-                mine_counts = self._band_counts(gobans, n_total, rates)                   # (n_total, rows, 19)
-                widest = max(b - a for a, b in band_rows(self.world))
-                slab = np.zeros((1, n_total, widest, gsize), np.int32)
-                slab[0, :, :mine_counts.shape[1]] = mine_counts
-                allc = self.group.all_gather_rows(slab, 1)[:, 0]                         # (world, n_total, widest, 19)
-                counts = np.concatenate([allc[r, :, :b - a] for r, (a, b) in enumerate(band_rows(self.world))], 1)
-        t2 = time.perf_counter()
-        if (full["flags"] & FLAG_FAILED).any():
-            raise RuntimeError("a rank failed in the GPU core of this batch: %s" % (self.errors[-1:] or "see its log"))
-        emitted, new = None, None
-        if self.rank == 0:
-            emitted = self.fold(full, counts, mtx is not None, frames=my_frames if self.board_lazy else None)
-            new = self.board.mtx
+        if failed:                                             # every rank sees the same flags here, before the band
+            return full, None, self.board.mtx, True            # exchange whose sizes a failed rank could not honour
+        # ordered board fold (rank 0): it needs the records only, so the transform is known -- and on its way to the
+        # other ranks -- before the background model's exchange starts
         t3 = time.perf_counter()
+        new = None
+        if self.rank == 0:
+            self._fold_board(full, t.frames if self.board_lazy else None)
+            new = self.board.mtx
+        t4 = time.perf_counter()
+        hs["fold_board"] += t4 - t3
         if self.world > 1:
             wire = np.zeros(10)
             if self.rank == 0 and new is not None:
                 wire[0], wire[1:] = 1.0, np.asarray(new, np.float64).reshape(9)
             wire = self.group.broadcast_array(wire, 0)
-            self.mtx = wire[1:].reshape(3, 3).copy() if wire[0] else None
-        else:
-            self.mtx = new
-        t4 = time.perf_counter()
+            new = wire[1:].reshape(3, 3).copy() if wire[0] else None
+            t5 = time.perf_counter()
+            hs["bcast"] += t5 - t4
+            if t.have_mtx:
+                mine_counts = self._band_counts(gobans, n_total, t.rates)                # (n_total, rows, 19)
+                t6 = time.perf_counter()
+                widest = max(b - a for a, b in band_rows(self.world))
+                slab = np.zeros((1, n_total, widest, gsize), np.int32)
+                slab[0, :, :mine_counts.shape[1]] = mine_counts
+                allc = self.group.all_gather_rows(slab, 1)[:, 0]                         # (world, n_total, widest, 19)
+                counts = np.concatenate([allc[r, :, :b - a] for r, (a, b) in enumerate(band_rows(self.world))], 1)
+                hs["counts_gather"] += time.perf_counter() - t6
+        return full, counts, new, False
+
+    def finish(self, ticket):
+        """wait for the batch's exchange, publish the transform, stones fold (rank 0) -> the fold's per-frame request
+        lists on rank 0, None elsewhere"""
+        import time
+        full, counts, new, failed = ticket.exchange.result()
+        if failed:
+            raise RuntimeError("a rank failed in the GPU core of this batch: %s" % (self.errors[-1:] or "see its log"))
+        self.mtx = new
+        t0 = time.perf_counter()
+        emitted = None
+        if self.rank == 0:
+            emitted = self.stones.run(full["region_label"], full["region_conf"], counts) if ticket.have_mtx else [()] * len(full)
         hs = self.host_seconds
-        hs["pack"] += t1 - t0
-        hs["collectives"] += (t2 - t1) + (t4 - t3)
-        hs["fold"] += t3 - t2
-        self.frames_done += n_total
+        hs["fold_stones"] += time.perf_counter() - t0
+        hs["fold"] = hs["fold_board"] + hs["fold_stones"]
+        hs["collectives"] = hs["gather"] + hs["bcast"] + hs["band_exchange"] + hs["counts_gather"]
+        self.frames_done += ticket.n_total
         return emitted
 
     def process_batch(self, my_frames, n_total):
         return self.finish(self.submit(my_frames, n_total))
 
+    def _fold_board(self, full, frames=None):
+        """ordered replay of the board finder on the gathered records of one batch (rank 0); with `frames` (hold-off-aware
+        mode) the board records are computed on demand, the wanted frames split over the lanes' board contexts, each
+        driven from its own lane thread (a context is single-threaded)"""
+        if frames is None:
+            return self.board.run(full)
+        lanes, pools = self.compute.lanes, self.compute.pools
+
+        def fetch(idx):
+            idx = list(idx)
+            k = len(lanes) if len(idx) >= 4 * len(lanes) else 1
+            cuts = [round(i * len(idx) / k) for i in range(k + 1)]
+            futs = [pools[i][0].submit(lanes[i][0].board_detect, _take(frames, idx[cuts[i]:cuts[i + 1]]), -1, LMAX, True)
+                    for i in range(k)]
+            got = [f.result() for f in futs]
+            return np.concatenate([g[0] for g in got]), np.concatenate([g[1] for g in got])
+        return self.board.run_lazy(len(full), fetch)
+
     def fold(self, full, counts, have_mtx=True, frames=None):
-        """ordered replay of both finders on the gathered records of one batch (rank 0); with `frames` (hold-off-aware
-        mode) the board records are computed on demand instead of read from `full`"""
-        if frames is not None:
-            ctx_board = self.compute.lanes[0][0]
-            self.board.run_lazy(len(full), lambda idx: ctx_board.board_detect(_take(frames, idx), -1, LMAX, True))
-        else:
-            self.board.run(full)
+        """both ordered folds of one batch, one after the other (what finish() does across its stages)"""
+        self._fold_board(full, frames)
         if not have_mtx:
             return [()] * len(full)
         return self.stones.run(full["region_label"], full["region_conf"], counts)

@@ -1,0 +1,147 @@
+"""The N > 1 path with the REAL kernels: two processes on the `gloo` backend, both on cuda:0, the
+real GpuCore (two lanes of board + stones contexts, the band of the background model on its own context), two batches
+in flight through submit() / finish().  What rank 0 ends up with -- requests, transform after every batch, game
+record, policy state -- must equal a one-process run over the same film with the same batch schedule.
+
+Reference side: the two finder threads this replaces (core/vmanager.py:408-424), the stones finder reading the board
+finder's transform (stone/stonesfinder.py:136-138) and the background model in frame order (:171-176)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+H, W = 480, 640
+FILM = 120
+BATCH = 24                       # 5 batches; the camera is bumped at frame 60 (inside batch 2): the transform changes twice
+BUMP = 60
+BG = 6
+
+
+def _film(select):
+    """two takes of one game: frames [0, BUMP) from one camera position, [BUMP, FILM) from another (other seed: other
+    corners).  After the bump the stones path warps with a stale transform until the board fold catches up -- garbage
+    in, but the SAME garbage at every world size."""
+    import torch
+    from camkifu_amd import synth
+    a = synth.film(FILM, H, W, seed=11, quiet=8, move_every=30, hand_frames=12, select=[g for g in select if g < BUMP])[0]
+    b = synth.film(FILM, H, W, seed=12, quiet=8, move_every=30, hand_frames=12, select=[g for g in select if g >= BUMP])[0]
+    return torch.cat([a, b]).cuda()
+
+
+def _drive(rank, world, depth=2):
+    import torch
+    import torch.distributed as dist  # noqa: F401
+    from camkifu_amd import capi, pipeline
+    from camkifu_amd.controller import ControllerHeadless
+    from camkifu_amd.stone.nn_manager import NNManager
+    torch.cuda.set_device(0)
+    lanes = [(capi.Context(0), capi.Context(0)) for _ in range(2)]
+    weights = NNManager.init_net()
+    for _, c in lanes:
+        c.cnn_set_weights(weights)
+    ctrl = ControllerHeadless()
+    pipe = pipeline.FastFilePipeline(H, W, ctrl, rank=rank, world=world, device=torch.device("cpu") if world > 1 else None,
+                                     lanes=lanes, ctx_bg=capi.Context(0), bg_init_frames=BG)
+    pipe.board.refresh_frames = 5            # keep looking: the bump must be noticed within a batch or two
+    mine, batches = [], []
+    for b0 in range(0, FILM, BATCH):
+        idx = b0 + pipeline.shard_indices(BATCH, rank, world)
+        batches.append((len(mine), len(mine) + len(idx)))
+        mine.extend(int(g) for g in idx)
+    frames = _film(mine)
+    tickets, emitted, mtxs = [], [], []
+    for k, (lo, hi) in enumerate(batches):
+        tickets.append(pipe.submit(frames[lo:hi], BATCH))
+        if len(tickets) == depth:                               # two batches in flight
+            emitted.append(pipe.finish(tickets.pop(0)))
+            mtxs.append(None if pipe.mtx is None else pipe.mtx.tolist())
+    while tickets:
+        emitted.append(pipe.finish(tickets.pop(0)))
+        mtxs.append(None if pipe.mtx is None else pipe.mtx.tolist())
+    st = pipe.stones.policy.state()
+    return dict(emitted=emitted, mtxs=mtxs, sgf=ctrl.kifu.to_sgf(), targets=st["targets"].tolist(),
+                looked=pipe.board.looked, host=dict(pipe.host_seconds))
+
+
+def _run(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank, _drive(rank, world)))
+    except BaseException as why:                                 # the parent must not wait for a rank that died
+        import traceback
+        q.put((rank, "FAILED: %s\n%s" % (why, traceback.format_exc())))
+        raise
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def _spawn(world):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_run, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=420) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, out in res:
+        assert not isinstance(out, str), out
+    return [out for _, out in res]
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_real_kernels_equal_one_rank():
+    one = _spawn(1)[0]
+    changes = [k for k in range(1, len(one["mtxs"])) if one["mtxs"][k] != one["mtxs"][k - 1]]
+    assert one["mtxs"][0] is not None and len(changes) >= 1, one["mtxs"]          # found, then moved by the bump
+    assert any(req for batch in one["emitted"] for req in batch)                  # the policy did record stones
+    two = _spawn(2)
+    r0, r1 = two
+    assert r0["emitted"] == one["emitted"]
+    assert r0["sgf"] == one["sgf"] and r0["targets"] == one["targets"] and r0["looked"] == one["looked"]
+    assert r0["mtxs"] == one["mtxs"] and r1["mtxs"] == one["mtxs"]                # every rank warps with the same transform
+    assert all(e is None for e in r1["emitted"])                                  # only rank 0 folds
+    assert r0["host"]["band_model"] > 0 and r1["host"]["band_model"] > 0          # the band model did run on both
+
+
+@pytest.mark.gpu
+def test_a_second_thread_on_a_context_is_refused():
+    """the one-thread-per-context contract is enforced by the library: while a thread is inside a call, another
+    thread's call on the same ck_ctx returns CK_ERR_STATE (and says why) instead of racing on the stream"""
+    import threading
+    import torch
+    from camkifu_amd import capi
+    ctx = capi.Context(0)
+    frames = torch.zeros((64, 1080, 1920, 3), dtype=torch.uint8, device="cuda:0")
+    small = np.zeros((16, 16, 3), np.uint8)
+    refused, stop = [], threading.Event()
+
+    def hammer(img):
+        while not stop.is_set():
+            try:
+                ctx.median15(img)
+            except capi.CkError as why:
+                refused.append(str(why))
+                stop.set()
+    threads = [threading.Thread(target=hammer, args=(img,)) for img in (frames, small)]
+    for t in threads:
+        t.start()
+    stop.wait(60)
+    stop.set()
+    for t in threads:
+        t.join()
+    assert refused and "in use by another thread" in refused[0], refused
+    assert np.array_equal(np.asarray(ctx.median15(small)), small)                 # and the context is fine afterwards
+    ctx.close()

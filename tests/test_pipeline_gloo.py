@@ -169,7 +169,7 @@ def test_multi_rank_fold_equals_single_process(world):
 
 
 # ---------------------------------------------------------------- host cost against the world size
-def _timed_rank(rank, world, port, q, per_rank, steps):
+def _timed_rank(rank, world, port, q, per_rank, steps, no_bands=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -195,6 +195,8 @@ def _timed_rank(rank, world, port, q, per_rank, steps):
         pipe = pipeline.FastFilePipeline(H, W, ControllerHeadless(), rank=rank, world=world, compute=compute)
         a, b = pipe.band
         pipe.band_model = lambda band, rates: np.zeros((len(band), b - a, 19), np.int32)
+        if no_bands:           # the host's own work is what is timed: 2 048 goban images through gloo on loopback are not
+            pipe._band_counts = lambda gobans, n, rates: np.zeros((n, b - a, 19), np.int32)
         for _ in range(2):
             pipe.process_batch(None, n_total)                # board found, one stones batch
         per_step, walls = [], []
@@ -239,6 +241,95 @@ def test_rank0_host_cost_per_frame_does_not_grow_with_world(capsys):
     per_rec = {w: (got[w][1]["pack"] + got[w][1]["fold"]) / got[w][3] for w in got}
     assert per_rec[8] <= 2.0 * per_rec[1] + 0.01, per_rec            # ms per record: flat (generous slack for a busy box)
     assert got[8][1]["fold"] < 25.0                                    # 256 records folded in a few ms
+
+
+def test_rank0_host_threads_stay_under_the_gpu_step_at_world_8(capsys):
+    """256 frames per rank at world 8 = 2 048 records per step.  Rank 0's two host stages run on
+    their own threads (exchange thread: pack + board fold between the collectives; caller's thread: stones fold) and
+    overlap the GPU core of the following batches, so what matters is that the BUSIEST of them stays well under the
+    14 ms a GPU step takes.  gloo's loopback collectives are not RCCL's and are left out of the sum; the goban bands
+    (887 MB per step) are not moved in this rehearsal."""
+    world, per_rank, steps = 8, 256, 4
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_timed_rank, args=(r, world, port, q, per_rank, steps, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=400) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    _, ph, wall, n_total = res[0]
+    exchange_thread = ph["pack"] + ph["fold_board"]
+    with capsys.disabled():
+        print("\n  world 8, %d records/step: exchange thread %.2f ms (pack %.2f + board fold %.2f), stones fold %.2f ms; "
+              "gloo collectives %.1f ms (loopback, not RCCL)" % (n_total, exchange_thread, ph["pack"], ph["fold_board"],
+                                                                ph["fold_stones"], ph["collectives"]), end="")
+    assert n_total == 2048
+    assert max(exchange_thread, ph["fold_stones"]) < 14.0, ph
+
+
+def _failing_rank(rank, world, port, q, bad_rank, n_total):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from camkifu_amd import capi
+        mine = pipeline.shard_indices(n_total, rank, world)
+        lines = np.zeros((len(mine), pipeline.LMAX, 2), np.float32)
+        lines[:, :4] = np.array([[100, 0.05], [540, 0.08], [60, 1.55], [420, 1.62]], np.float32)
+        res = np.zeros(len(mine), capi.BOARD_DTYPE)
+        res["n_lines"] = 4
+        calls = [0]
+
+        def compute(frames, mtx, rates):
+            calls[0] += 1
+            if rank == bad_rank and calls[0] == 3:
+                raise capi.CkError("libck_hip error 2: injected")
+            gob = None if mtx is None else np.zeros((len(mine), 380, 380, 3), np.uint8)
+            return (res, lines), np.zeros((len(mine), 10, 10), np.uint8), np.full((len(mine), 10, 10), 0.9), None, gob
+        pipe = pipeline.FastFilePipeline(H, W, ControllerHeadless(), rank=rank, world=world, compute=compute)
+        a, b = pipe.band
+        pipe.band_model = lambda band, rates: np.zeros((len(band), b - a, 19), np.int32)
+        outcome = []
+        for k in range(4):
+            try:
+                pipe.process_batch(None, n_total)
+                outcome.append("ok")
+            except RuntimeError as why:
+                outcome.append("raised: " + str(why)[:40])
+        q.put((rank, outcome, pipe.mtx is not None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bad_rank, n_total", [(1, 9), (2, 2)])
+def test_a_failing_rank_makes_every_rank_raise_instead_of_hanging(bad_rank, n_total):
+    """a GPU-core failure on one rank is carried as a flag through the record gather and EVERY rank raises
+    after it, before the band exchange whose sizes the failed rank could not honour -- also when the failing rank's
+    shard is empty (2 frames dealt to 3 ranks: rank 2 holds none, its header row still says so).  The batches before
+    and after go through."""
+    world = 3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_rank, args=(r, world, port, q, bad_rank, n_total)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, outcome, has_mtx in res:
+        assert outcome[0] == outcome[1] == outcome[3] == "ok", (rank, outcome)
+        assert outcome[2].startswith("raised: a rank failed"), (rank, outcome)
+        assert has_mtx
 
 
 def test_lazy_board_fold_equals_the_eager_one():
