@@ -173,7 +173,10 @@ __global__ __launch_bounds__(256) void canny_nms_kernel(const uint8_t* __restric
 //     the pixel tile, then runs the two fixed-point tangent tests.
 // Tile: 64 x (15 PK - 2) output pixels per 256-thread workgroup (17 column quads x 15 row segments of PK gradient rows).
 #ifndef NMS_PK
-#define NMS_PK 4
+#define NMS_PK 2
+#endif
+#ifndef NMS_STOP
+#define NMS_STOP 0         // profiling aid (tools/pmc_serial.sh): leave the kernel after phase n -- results are then WRONG
 #endif
 constexpr int PK = NMS_PK;                   // gradient rows per thread
 constexpr int PGR = 15 * PK;                 // gradient rows (1-px halo)
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
         }
     }
     __syncthreads();
+    if (NMS_STOP == 1) return;
 
     if (tid < 17 * 15) {
         const int cj = tid % 17, seg = tid / 17;
@@ -331,6 +335,7 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
         }
     }
     __syncthreads();
+    if (NMS_STOP == 2) return;
 
     // NMS: one thread = 4 consecutive pixels of one row (one dword of the map)
     const int TG22 = 13573;   // (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
@@ -398,6 +403,7 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
         }
         km[it] = keepmask;
     }
+    if (NMS_STOP == 3) return;
 #if NMS_LOCAL_UF
     // Tile-local part of the hysteresis union-find, in LDS: every candidate is linked with its W / N (or NW, NE)
     // neighbours inside this tile, so the global pass (canny_link_kernel) only has to visit the candidates on the
@@ -409,14 +415,23 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
         if (q >= PTH * 16) continue;
         // local index = r * 64 + col = 4 q + k; a pixel whose west neighbour inside the quad is kept starts out
         // pointing at the head of that little run (one union less)
-        int4 v;
-        v.x = (km[it] & 1) ? 4 * q : -1;
-        v.y = (km[it] & 2) ? ((km[it] & 1) ? v.x : 4 * q + 1) : -1;
-        v.z = (km[it] & 4) ? ((km[it] & 2) ? v.y : 4 * q + 2) : -1;
-        v.w = (km[it] & 8) ? ((km[it] & 4) ? v.z : 4 * q + 3) : -1;
+        int4 v = make_int4(-1, -1, -1, -1);
+        if (__builtin_amdgcn_ballot_w64(km[it] != 0) != 0) {      // most waves hold no kept pixel at all
+            v.x = (km[it] & 1) ? 4 * q : -1;
+            v.y = (km[it] & 2) ? ((km[it] & 1) ? v.x : 4 * q + 1) : -1;
+            v.z = (km[it] & 4) ? ((km[it] & 2) ? v.y : 4 * q + 2) : -1;
+            v.w = (km[it] & 8) ? ((km[it] & 4) ? v.z : 4 * q + 3) : -1;
+        }
         *reinterpret_cast<int4*>(lab + 4 * q) = v;
     }
-    __syncthreads();                                   // parents in place; the pixel tile is dead from here on (cbuf)
+    {
+        int mine = 0;
+#pragma unroll
+        for (int it = 0; it < NQ; it++) mine |= km[it];
+        // parents in place; the pixel tile is dead from here on (cbuf).  A tile without a single kept pixel (the flat
+        // parts of a median-filtered frame) has nothing to link and nothing to list: done.
+        if (!__syncthreads_or(mine)) return;
+    }
     auto lfind = [&](int a) {
         int p = __hip_atomic_load(lab + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         while (p != a) { a = p; p = __hip_atomic_load(lab + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -452,8 +467,14 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
         }
     }
     __syncthreads();
+    if (NMS_STOP == 4) return;
 #else
-    __syncthreads();                                   // the pixel tile is dead from here on (cbuf)
+    {
+        int mine = 0;
+#pragma unroll
+        for (int it = 0; it < NQ; it++) mine |= km[it];
+        if (!__syncthreads_or(mine)) return;           // the pixel tile is dead from here on (cbuf)
+    }
 #endif
 #pragma unroll
     for (int it = 0; it < NQ; it++) {

@@ -277,6 +277,26 @@ def cnn_predict_regions(weights, goban, want_logits=False):
     return (y, lg) if want_logits else y
 
 
+def baseline_frames(weights, frames, M, threads):
+    """bench.py's cpu_baseline leg: the hot path of n frames with OpenMP ACROSS frames, one frame per
+    thread.  weights None: board path + warp only, the goban images are returned for the caller's classifier
+    -> (per-frame ora_board_lines status / line count, labels (n, 19, 19) or gobans (n, 380, 380, 3), threads that took part)"""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, h, w, _ = frames.shape
+    M = np.ascontiguousarray(M, np.float64).reshape(9)
+    nl = np.zeros(n, np.int32)
+    if weights is None:
+        out = np.zeros((n, 380, 380, 3), np.uint8)
+        used = lib().ora_baseline_frames(_vp(frames), n, h, w, _vp(M), None, int(threads), _vp(nl), None, _vp(out))
+    else:
+        s, keep = _wstruct(weights)
+        out = np.zeros((n, 19, 19), np.uint8)
+        used = lib().ora_baseline_frames(_vp(frames), n, h, w, _vp(M), C.byref(s), int(threads), _vp(nl), _vp(out), None)
+    if used < 0:
+        raise MemoryError("ora_baseline_frames")
+    return nl, out, used
+
+
 def decode_all(y):
     y = np.ascontiguousarray(y, np.float32).reshape(100, 81)
     labels = np.zeros((19, 19), np.uint8)
