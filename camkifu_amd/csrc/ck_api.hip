@@ -200,7 +200,7 @@ void ck_ctx_destroy(ck_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = { &ctx->in_stage, &ctx->in_stage2, &ctx->planes, &ctx->edges, &ctx->map, &ctx->labels,
-                       &ctx->labels2, &ctx->ghost, &ctx->misc, &ctx->bflag, &ctx->comp, &ctx->lists, &ctx->pts, &ctx->accum, &ctx->peaks,
+                       &ctx->labels2, &ctx->runs, &ctx->ghost, &ctx->misc, &ctx->bflag, &ctx->comp, &ctx->lists, &ctx->pts, &ctx->accum, &ctx->peaks,
                        &ctx->goban, &ctx->act0, &ctx->act1, &ctx->act2, &ctx->ybuf, &ctx->lblbuf, &ctx->confbuf,
                        &ctx->rlblbuf, &ctx->rconfbuf, &ctx->fgcbuf,
                        &ctx->out_stage, &ctx->mats,

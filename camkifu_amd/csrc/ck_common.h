@@ -72,6 +72,7 @@ struct ck_ctx {
     DevBuf map;          // n*h*w NMS map
     DevBuf labels;       // n*h*w int32 union-find parents
     DevBuf labels2;
+    DevBuf runs;         // run-table labelling: bit map, rank prefix, row bases, run parents
     DevBuf ghost;        // n*h*w
     DevBuf misc;         // small per-frame counters
     DevBuf bflag;        // per frame: did Canny put an edge pixel on the image frame? (K2 -> K3 label reuse)

@@ -427,6 +427,308 @@ __global__ __launch_bounds__(256) void border_list_kernel(const uint8_t* __restr
     }
 }
 
+// ==========================================================================================================
+// RUN-TABLE form of steps A..E (the board path; k_contour_survey keeps the dense form above).
+// The dense form writes an int32 parent for EVERY pixel (8.3 MB per 1080p frame) only so that a background pixel
+// can name the horizontal zero-run it lies in.  An edge map is a few percent dense, so here the runs are named
+// through the edge list instead:
+//   * bits  [h][w64]  the cleared-frame edge map, one bit per pixel (259 KB per 1080p frame);
+//   * rank  [h][w64]  edge pixels of the row in the words before this one (exclusive prefix, u16);
+//   * rowbase[h]      where the row's segment of the edge list starts (rows are appended with one atomic each, so
+//                     the segments are in no particular order -- nothing needs raster order of the LIST);
+//   * the run that starts at x = 0 of row y is node y; the run right of the edge pixel at list position i is node
+//     h + i.  A background pixel (y, x) lies in the run of the last edge pixel of its row before x:
+//     r = rank[y][x / 64] + popcount(bits below x) -> node r ? h + rowbase[y] + r - 1 : y.  Three small independent
+//     loads instead of a dependent one into a 8 MB image;
+//   * rp[h + n_edges] union-find parents of the run nodes (4-connectivity).  The edge components (8-connectivity)
+//     stay in the dense label image, which only ever holds them at edge pixels: Canny's labels when no edge touched
+//     the image frame, rebuilt here otherwise.
+// prep then moves 2 MB in + 2.4 MB out per 1080p frame instead of 2 + 10.3.
+struct RunTab {
+    unsigned long long* bits;
+    uint16_t* rank;
+    int32_t* rowbase;
+    int32_t* rp;
+    int w64;
+    size_t rp_stride;            // ints per frame in rp
+};
+
+__device__ __forceinline__ bool rt_edge(const unsigned long long* __restrict__ bf, int w64, int y, int x)
+{
+    return (bf[(size_t)y * w64 + (x >> 6)] >> (x & 63)) & 1ull;
+}
+// node of the background pixel (y, x)
+__device__ __forceinline__ int rt_run(const unsigned long long* __restrict__ bf, const uint16_t* __restrict__ rk,
+                                      const int32_t* __restrict__ rb, int h, int w64, int y, int x)
+{
+    const size_t wi = (size_t)y * w64 + (x >> 6);
+    const int r = (int)rk[wi] + __builtin_popcountll(bf[wi] & ((1ull << (x & 63)) - 1ull));
+    return r ? h + rb[y] + r - 1 : y;
+}
+
+// OR of a 64-bit value over the 16 lanes of a DPP row (every lane of the row gets the result)
+__device__ __forceinline__ unsigned long long row16_or(unsigned long long v)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#define CK_DPP_OR(CTRL)                                                                   \
+    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, true);       \
+    hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, true);
+    CK_DPP_OR(0xB1)      // quad_perm [1, 0, 3, 2]
+    CK_DPP_OR(0x4E)      // quad_perm [2, 3, 0, 1]
+    CK_DPP_OR(0x141)     // row_half_mirror
+    CK_DPP_OR(0x140)     // row_mirror
+#undef CK_DPP_OR
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// A'. one wave per image row: cleared-frame edge bytes (later kernels read them), bit words + rank prefix, the row's
+// segment of the edge list, the run nodes' parents.  Rows of up to 256 * NS pixels, all loads of a row in flight at once.
+template <int NS>
+__global__ __launch_bounds__(256) void prep_runs_kernel(const uint8_t* __restrict__ edges, int h, int w,
+                                                        uint8_t* __restrict__ ez, int32_t* __restrict__ L,
+                                                        FrameTab* __restrict__ tab, int32_t* __restrict__ elist, RunTab rt,
+                                                        const int* __restrict__ canny_border_flag)
+{
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int f = blockIdx.y;
+    if (y >= h) return;                                  // whole wave leaves together
+    // L holds Canny's hysteresis labels at the edge pixels: kept unless an edge touched the image frame (cleared
+    // below, which may split a component)
+    const bool keep_edge_parents = canny_border_flag != nullptr && canny_border_flag[f] == 0;
+    const size_t off = ((size_t)f * h + y) * w;
+    const bool row_inner = y > 0 && y < h - 1;
+    int32_t* E = elist + (size_t)f * h * w;
+    int32_t* rp = rt.rp + (size_t)f * rt.rp_stride;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t v[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int x = 256 * s + 4 * lane;
+        v[s] = 0;
+        if (x < w && row_inner) v[s] = *reinterpret_cast<const uint32_t*>(edges + off + x);
+    }
+    int nib[NS], before[NS];          // before: edge pixels of this row in earlier lanes / steps
+    int total = 0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int x = 256 * s + 4 * lane;
+        int nb = ((v[s] & 0xFFu) ? 1 : 0) | ((v[s] & 0xFF00u) ? 2 : 0) | ((v[s] & 0xFF0000u) ? 4 : 0) | ((v[s] & 0xFF000000u) ? 8 : 0);
+        if (x == 0) nb &= ~1;                            // cleared frame: first and last column
+        if (x + 3 == w - 1) nb &= ~8;
+        nib[s] = nb;
+        before[s] = total;
+        if (__builtin_amdgcn_ballot_w64(nb != 0)) {      // wave-uniform
+            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(nb & 1), b1 = __builtin_amdgcn_ballot_w64(nb & 2);
+            const unsigned long long b2 = __builtin_amdgcn_ballot_w64(nb & 4), b3 = __builtin_amdgcn_ballot_w64(nb & 8);
+            before[s] += __builtin_popcountll(b0 & lt) + __builtin_popcountll(b1 & lt) +
+                         __builtin_popcountll(b2 & lt) + __builtin_popcountll(b3 & lt);
+            total += __builtin_popcountll(b0) + __builtin_popcountll(b1) + __builtin_popcountll(b2) + __builtin_popcountll(b3);
+        }
+    }
+    int base = 0;
+    if (total) {
+        if (lane == 0) base = atomicAdd(&tab[f].n_edges, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+    }
+    if (lane == 0) {
+        rt.rowbase[(size_t)f * h + y] = base;
+        rp[y] = y;                                       // the run that starts at x = 0
+    }
+    unsigned long long* bw = rt.bits + ((size_t)f * h + y) * rt.w64;
+    uint16_t* rw = rt.rank + ((size_t)f * h + y) * rt.w64;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int x = 256 * s + 4 * lane;
+        const int nb = nib[s];
+        const unsigned long long word = row16_or((unsigned long long)nb << (4 * (lane & 15)));
+        if (x < w) {
+            *reinterpret_cast<uint32_t*>(ez + off + x) =
+                (nb & 1 ? 1u : 0u) | (nb & 2 ? 0x100u : 0u) | (nb & 4 ? 0x10000u : 0u) | (nb & 8 ? 0x1000000u : 0u);
+            if ((lane & 15) == 0) {
+                bw[4 * s + (lane >> 4)] = word;
+                rw[4 * s + (lane >> 4)] = (uint16_t)before[s];
+            }
+            if (nb) {
+                int slot = base + before[s];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (nb & (1 << k)) {
+                        const int p = y * w + x + k;
+                        E[slot] = p;
+                        rp[h + slot] = h + slot;
+                        if (!keep_edge_parents) L[(size_t)f * h * w + p] = p;
+                        slot++;
+                    }
+            }
+        }
+    }
+}
+
+// B'. unions: the background stretches that open right of an edge pixel (this row and the row below), the runs at
+// x = 0 of consecutive rows, and -- only when Canny's labels could not be kept -- the edge pixels themselves
+__global__ __launch_bounds__(256) void link_runs_kernel(int h, int w, int32_t* __restrict__ labels, const FrameTab* __restrict__ tab,
+                                                        const int32_t* __restrict__ elist, RunTab rt,
+                                                        const int* __restrict__ canny_border_flag)
+{
+    int f, bx;
+    list_frame_block(LIST_BLOCKS, f, bx);
+    const bool edges_linked = canny_border_flag != nullptr && canny_border_flag[f] == 0;   // parents kept from Canny
+    const int ne = tab[f].n_edges, w64 = rt.w64;
+    int32_t* L = labels + (size_t)f * h * w;
+    const int32_t* E = elist + (size_t)f * h * w;
+    const unsigned long long* bf = rt.bits + (size_t)f * h * w64;
+    const uint16_t* rk = rt.rank + (size_t)f * h * w64;
+    const int32_t* rb = rt.rowbase + (size_t)f * h;
+    int32_t* rp = rt.rp + (size_t)f * rt.rp_stride;
+    for (int i = bx * 256 + threadIdx.x; i < ne + h - 1; i += LIST_BLOCKS * 256) {
+        if (i < ne) {
+            const int p = E[i];                        // 1 <= x <= w-2, 1 <= y <= h-2
+            const int y = p / w, x = p - y * w;
+            const bool e_n = rt_edge(bf, w64, y - 1, x), e_ne = rt_edge(bf, w64, y - 1, x + 1);
+            const bool e_e = rt_edge(bf, w64, y, x + 1), e_s = rt_edge(bf, w64, y + 1, x), e_se = rt_edge(bf, w64, y + 1, x + 1);
+            if (!edges_linked) {
+                if (rt_edge(bf, w64, y, x - 1)) uf_union(L, p, p - 1);
+                if (e_n) uf_union(L, p, p - w);
+                else {
+                    if (rt_edge(bf, w64, y - 1, x - 1)) uf_union(L, p, p - w - 1);
+                    if (e_ne) uf_union(L, p, p - w + 1);
+                }
+            }
+            // the stretch opening right of p: (y, x + 1) and the pixel above it both background
+            if (!e_e && !e_ne) uf_union(rp, h + i, rt_run(bf, rk, rb, h, w64, y - 1, x + 1));
+            // the one opening right of p in the row below (if the pixel below p is an edge pixel too -- a vertical
+            // stroke -- that pixel's own stretch is this very one: leave it to it)
+            if (!e_se && !e_e && !e_s) uf_union(rp, rt_run(bf, rk, rb, h, w64, y + 1, x + 1), h + i);
+        } else {
+            const int yy = i - ne + 1;                 // x = 0 of rows 1 .. h-1: always background
+            uf_union(rp, yy, yy - 1);
+        }
+    }
+}
+
+// C' + D'. every run node at its root (one lookup from here on), every edge pixel at its root where Canny did not
+// leave it there
+__global__ __launch_bounds__(256) void flatten_runs_kernel(int h, int w, int32_t* __restrict__ labels, const FrameTab* __restrict__ tab,
+                                                           const int32_t* __restrict__ elist, RunTab rt,
+                                                           const int* __restrict__ canny_border_flag)
+{
+    int f, bx;
+    list_frame_block(LIST_BLOCKS, f, bx);
+    const bool edges_flat = canny_border_flag != nullptr && canny_border_flag[f] == 0;
+    const int ne = tab[f].n_edges;
+    int32_t* L = labels + (size_t)f * h * w;
+    const int32_t* E = elist + (size_t)f * h * w;
+    int32_t* rp = rt.rp + (size_t)f * rt.rp_stride;
+    for (int i = bx * 256 + threadIdx.x; i < ne + h; i += LIST_BLOCKS * 256) {
+        rp[i] = uf_find(rp, i);                          // (a plain store of an ancestor: safe next to concurrent finds)
+        if (!edges_flat && i < ne) { const int p = E[i]; L[p] = uf_find(L, p); }
+    }
+}
+
+// D' + E'. top-level roots, then the outer-border list + bounding boxes (two kernels: the border pass needs every
+// root's slot).  A background neighbour is in S0 iff its run's root is the root of node 0 (row 0 is all background).
+__global__ __launch_bounds__(256) void roots_runs_kernel(int h, int w, const int32_t* __restrict__ labels,
+                                                         int32_t* __restrict__ compid, FrameTab* __restrict__ tab, int maxc,
+                                                         int32_t* __restrict__ roots, int32_t* __restrict__ aabb,
+                                                         const int32_t* __restrict__ elist, RunTab rt)
+{
+    int f, bx;
+    list_frame_block(LIST_BLOCKS, f, bx);
+    const int ne = tab[f].n_edges;
+    const size_t off = (size_t)f * h * w;
+    const int32_t* L = labels + off;
+    const int32_t* E = elist + off;
+    const int32_t* rb = rt.rowbase + (size_t)f * h;
+    const int32_t* rp = rt.rp + (size_t)f * rt.rp_stride;
+    const int root0 = rp[0];
+    for (int i = bx * 256 + threadIdx.x; i < ne; i += LIST_BLOCKS * 256) {
+        const int p = E[i];
+        if (L[p] != p) continue;
+        const int y = p / w;
+        const int west = (i == rb[y]) ? y : h + i - 1;  // the west neighbour of a component's first pixel is background
+        if (rp[west] != root0) continue;
+        const int slot = atomicAdd(&tab[f].n_roots, 1);
+        if (slot >= maxc) { tab[f].overflow = 1; compid[off + p] = -1; continue; }
+        compid[off + p] = slot;
+        roots[(size_t)f * maxc + slot] = p;
+        int32_t* bb = aabb + ((size_t)f * maxc + slot) * 4;
+        bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void border_runs_kernel(int h, int w, const int32_t* __restrict__ labels,
+                                                          const int32_t* __restrict__ compid, int maxc, FrameTab* __restrict__ tab,
+                                                          int32_t* __restrict__ aabb, const int32_t* __restrict__ elist,
+                                                          int32_t* __restrict__ blist, RunTab rt)
+{
+    int f, bx;
+    list_frame_block(LIST_BLOCKS, f, bx);
+    const int ne = tab[f].n_edges, w64 = rt.w64;
+    const size_t off = (size_t)f * h * w;
+    const int32_t* L = labels + off;
+    const int32_t* E = elist + off;
+    int32_t* B = blist + off;
+    const unsigned long long* bf = rt.bits + (size_t)f * h * w64;
+    const uint16_t* rk = rt.rank + (size_t)f * h * w64;
+    const int32_t* rb = rt.rowbase + (size_t)f * h;
+    const int32_t* rp = rt.rp + (size_t)f * rt.rp_stride;
+    const int root0 = rp[0];
+    const int trips = (ne + LIST_BLOCKS * 256 - 1) / (LIST_BLOCKS * 256);      // uniform trip count
+    for (int t = 0; t < trips; t++) {
+        const int i = t * LIST_BLOCKS * 256 + bx * 256 + threadIdx.x;
+        bool b = false;
+        int p = 0, cslot = -1;
+        if (i < ne) {
+            p = E[i];
+            const int y = p / w, x = p - y * w;
+            // the four neighbours: edge bit, then the node of a background one (independent loads), then its root
+            const size_t wi = (size_t)y * w64 + (x >> 6);
+            const unsigned long long here = bf[wi];
+            const bool e_w = (x & 63) ? (here >> ((x & 63) - 1)) & 1ull : rt_edge(bf, w64, y, x - 1);
+            const bool e_e = ((x & 63) != 63) ? (here >> ((x & 63) + 1)) & 1ull : rt_edge(bf, w64, y, x + 1);
+            const bool e_n = rt_edge(bf, w64, y - 1, x), e_s = rt_edge(bf, w64, y + 1, x);
+            const int n_w = (i == rb[y]) ? y : h + i - 1;                     // the run that ends at p - 1 (if p - 1 is background)
+            const int n_e = h + i;
+            const int n_n = e_n ? 0 : rt_run(bf, rk, rb, h, w64, y - 1, x);
+            const int n_s = e_s ? 0 : rt_run(bf, rk, rb, h, w64, y + 1, x);
+            const int t_w = rp[e_w ? 0 : n_w], t_e = rp[e_e ? 0 : n_e], t_n = rp[n_n], t_s = rp[n_s];
+            b = (!e_w && t_w == root0) || (!e_e && t_e == root0) || (!e_n && t_n == root0) || (!e_s && t_s == root0);
+            if (b) {
+                cslot = compid[off + L[p]];
+                if ((unsigned)cslot >= (unsigned)maxc) b = false;
+            }
+        }
+        // bounding boxes: reduce per component inside the wave, one lane updates the box and only where it grows
+        {
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(b);
+            const int y = p / w, x = p - y * w;
+            const int lane = threadIdx.x & 63;
+            while (todo) {
+                const int lead = __builtin_ctzll(todo);
+                const int s_lead = __builtin_amdgcn_readlane(cslot, lead);
+                const bool mine = b && cslot == s_lead;
+                todo &= ~__builtin_amdgcn_ballot_w64(mine);
+                int mnx = mine ? x : 0x7fffffff, mxx = mine ? x : -1, mny = mine ? y : 0x7fffffff, mxy = mine ? y : -1;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    mnx = min(mnx, __shfl_xor(mnx, d)); mxx = max(mxx, __shfl_xor(mxx, d));
+                    mny = min(mny, __shfl_xor(mny, d)); mxy = max(mxy, __shfl_xor(mxy, d));
+                }
+                if (lane == lead) {
+                    int32_t* bb = aabb + ((size_t)f * maxc + s_lead) * 4;
+                    if (mnx < uf_load(bb, 0)) atomicMin(bb + 0, mnx);
+                    if (mxx > uf_load(bb, 1)) atomicMax(bb + 1, mxx);
+                    if (mny < uf_load(bb, 2)) atomicMin(bb + 2, mny);
+                    if (mxy > uf_load(bb, 3)) atomicMax(bb + 3, mxy);
+                }
+            }
+        }
+        const int slot = wave_append(&tab[f].n_border, b);
+        if (b) B[slot] = p;
+    }
+}
+
 // pack the first `k` entries of every frame's root / bounding-box table into dense arrays so the
 // host needs one contiguous copy instead of a strided one
 __global__ void pack_tables_kernel(const int32_t* __restrict__ roots, const int32_t* __restrict__ aabb, int maxc, int k, int n,
@@ -825,24 +1127,44 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         const bool dwords = (w & 3) == 0 && ((uintptr_t)d_edges & 3) == 0;
         // reuse of Canny's component roots (ck_board_detect only) needs the row kernel that preserves them
         const int* kflag = (dwords && w <= 4096) ? d_canny_border_flag : nullptr;
-        if (dwords && w <= 1024)
-            hipLaunchKernelGGL(prep_rows4u_kernel<4>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist, kflag);
-        else if (dwords && w <= 2048)
-            hipLaunchKernelGGL(prep_rows4u_kernel<8>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist, kflag);
-        else if (dwords && w <= 4096)
-            hipLaunchKernelGGL(prep_rows4u_kernel<16>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist, kflag);
-        else if (dwords)
-            hipLaunchKernelGGL(prep_rows4_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
-        else
-            hipLaunchKernelGGL(prep_rows_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
-        hipLaunchKernelGGL(link_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
-                           (const FrameTab*)d_tab, (const int32_t*)elist, kflag);
-        hipLaunchKernelGGL(flatten_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
-                           (const FrameTab*)d_tab, (const int32_t*)elist, kflag);
-        hipLaunchKernelGGL(roots_list_kernel, lgrid, lblock, 0, ctx->stream, h, w, (const int32_t*)L, compid, d_tab, maxc,
-                           d_roots, d_aabb, (const int32_t*)elist);
-        hipLaunchKernelGGL(border_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, (const int32_t*)L,
-                           (const int32_t*)compid, maxc, d_tab, d_aabb, (const int32_t*)elist, blist);
+        if (dwords && w <= 4096) {
+            // run-table form: no dense parent image
+            RunTab rt;
+            rt.w64 = (w + 63) / 64;
+            rt.rp_stride = fpx + (size_t)h;
+            const size_t bits_b = (size_t)n * h * rt.w64 * 8, rank_b = (size_t)n * h * rt.w64 * 2, rb_b = (size_t)n * h * 4;
+            const size_t rank_o = bits_b, rb_o = (rank_o + rank_b + 15) & ~(size_t)15, rp_o = (rb_o + rb_b + 15) & ~(size_t)15;
+            CK_TRY(ck_ensure(ctx, ctx->runs, rp_o + (size_t)n * rt.rp_stride * 4));
+            rt.bits = (unsigned long long*)ctx->runs.p;
+            rt.rank = (uint16_t*)((char*)ctx->runs.p + rank_o);
+            rt.rowbase = (int32_t*)((char*)ctx->runs.p + rb_o);
+            rt.rp = (int32_t*)((char*)ctx->runs.p + rp_o);
+            if (w <= 1024)
+                hipLaunchKernelGGL(prep_runs_kernel<4>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist, rt, kflag);
+            else if (w <= 2048)
+                hipLaunchKernelGGL(prep_runs_kernel<8>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist, rt, kflag);
+            else
+                hipLaunchKernelGGL(prep_runs_kernel<16>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist, rt, kflag);
+            hipLaunchKernelGGL(link_runs_kernel, lgrid, lblock, 0, ctx->stream, h, w, L, (const FrameTab*)d_tab, (const int32_t*)elist, rt, kflag);
+            hipLaunchKernelGGL(flatten_runs_kernel, lgrid, lblock, 0, ctx->stream, h, w, L, (const FrameTab*)d_tab, (const int32_t*)elist, rt, kflag);
+            hipLaunchKernelGGL(roots_runs_kernel, lgrid, lblock, 0, ctx->stream, h, w, (const int32_t*)L, compid, d_tab, maxc,
+                               d_roots, d_aabb, (const int32_t*)elist, rt);
+            hipLaunchKernelGGL(border_runs_kernel, lgrid, lblock, 0, ctx->stream, h, w, (const int32_t*)L, (const int32_t*)compid, maxc,
+                               d_tab, d_aabb, (const int32_t*)elist, blist, rt);
+        } else {
+            if (dwords)
+                hipLaunchKernelGGL(prep_rows4_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
+            else
+                hipLaunchKernelGGL(prep_rows_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
+            hipLaunchKernelGGL(link_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
+                               (const FrameTab*)d_tab, (const int32_t*)elist, kflag);
+            hipLaunchKernelGGL(flatten_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
+                               (const FrameTab*)d_tab, (const int32_t*)elist, kflag);
+            hipLaunchKernelGGL(roots_list_kernel, lgrid, lblock, 0, ctx->stream, h, w, (const int32_t*)L, compid, d_tab, maxc,
+                               d_roots, d_aabb, (const int32_t*)elist);
+            hipLaunchKernelGGL(border_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, (const int32_t*)L,
+                               (const int32_t*)compid, maxc, d_tab, d_aabb, (const int32_t*)elist, blist);
+        }
         CK_HIP(ctx, hipGetLastError());
     }
 
