@@ -97,6 +97,24 @@ constexpr float H2_WSCALE = 256.f;      // split-precision mode: weights are sto
 #define H2C2S_TB 24      // pooling tiles (4x4 output pixels) per conv2 workgroup: 24 = 3 tile rows x 3 workgroups per patch (14.9 us
                          // per frame); 32 = 4 x 2 (fewer weight loads per MFMA, but one workgroup per CU: 16.4 us); 16 = 2 x 4: 16.6 us
 #endif
+#ifndef H2_DBG_SKIP
+#define H2_DBG_SKIP 0     // profiling aid (results are then WRONG): 1 = leave out the k-loops, 2 = leave out the fused conv1 tiles
+#endif
+#ifndef H2_DBG_TIME
+#define H2_DBG_TIME 0     // profiling aid: per-workgroup phase times of the fused conv1 + conv2 kernel (100 MHz wall clock),
+#endif                    // summed into g_h2_prof and printed by the host after the launch
+#if H2_DBG_TIME
+__device__ unsigned long long g_h2_prof[8];
+#define H2_STAMP(K) do { if (FUSE1 && threadIdx.x == 0) { const unsigned long long now__ = wall_clock64(); atomicAdd(&g_h2_prof[K], now__ - t_prev__); t_prev__ = now__; } } while (0)
+#else
+#define H2_STAMP(K) do { } while (0)
+#endif
+#ifndef H2_PRIO
+#define H2_PRIO 1         // wave priority 3 outside the k-loop (staging, fused conv1, epilogue), 0 inside: see conv_h2_body
+#endif
+#ifndef H2C2S_WM
+#define H2C2S_WM 8       // waves per conv2 workgroup along the pixel tiles: R = H2C2S_TB / H2C2S_WM tiles per wave
+#endif
 #ifndef CK_H2_OPMAJOR
 #define CK_H2_OPMAJOR 0     // developer knob: product-major order of the split-precision MFMAs inside a k-step (same sums bit for bit;
                             // measured: 14.8 vs 14.9 us per frame when held to 128 VGPRs, 16.6 at 130 -- the chain order is not the limit)
@@ -588,19 +606,32 @@ __global__ __launch_bounds__(64 * WAVES_M * (COUTS / 16)) void conv_mfma16_bf16_
 // the bf16 kernel; one k-step = 32 channels of one kernel tap.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
+// swizzled conv2 tile: chunk c of the pixel at column x of tile row y sits in slot c ^ h2_swz(x, y)
+__device__ __forceinline__ int h2_swz(int x, int y) { return ((x & 6) ^ (x & 1) ^ (y << 2)) & 7; }
+
 __device__ __forceinline__ void split_h2(float x, _Float16& hi, _Float16& lo)
 {
     hi = (_Float16)x;
     lo = (_Float16)(x - (float)hi);
 }
 
+// Padding of the non-swizzled split-precision tiles, chosen against the REAL ds_read_b128 lane groups
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32: MI355X_MICROARCH.md, LDS) with a model of every fragment read of
+// the layer (tools/lds_conflict_model.py): conv3 (plain tiles of 16 raster pixels, 32 channels) is conflict-free with
+// 48 halves of pixel padding and rows = 32 halves mod 64, conv4 (pooling tiles, 96 channels) with no pixel padding and
+// rows = 16 mod 64; the round-2 values (8 / 48 and 8 / 32) cost 7.7 and 8.0 LDS cycles per read instead of 4.
+template <int CINP, bool POOL>
+constexpr int h2_pspad() { return POOL ? (CINP == 96 ? 0 : 8) : (CINP == 32 ? 48 : 8); }
+template <int CINP, bool POOL, int OW>
+constexpr int h2_rsrem() { return POOL ? (CINP == 96 ? 16 : 32) : (CINP == 32 ? 32 : (8 * OW) % 64); }
+
 // halves of LDS one block's input tile takes (same formulas as in the body)
 template <int H, int W, int CIN, int KH, int KW, int TB, bool POOL, bool SWZ>
 constexpr int h2_tile_halves()
 {
     constexpr int OW = W - KW + 1, M = (H - KH + 1) * OW, CINP = cdiv(CIN, 32) * 32;
-    constexpr int PS = SWZ ? 2 * CINP : 2 * CINP + 8;
-    constexpr int RS = SWZ ? W * PS + 16 : lds_stride_b(W * PS, POOL ? 32 : (8 * OW) % 64, 64);
+    constexpr int PS = SWZ ? 2 * CINP : 2 * CINP + h2_pspad<CINP, POOL>();
+    constexpr int RS = SWZ ? W * PS : lds_stride_b(W * PS, h2_rsrem<CINP, POOL, OW>(), 64);
     constexpr int ROWS_RAW = POOL ? 4 * (TB / (OW / 4)) + KH - 1 : (TB * 16 + OW - 2) / OW + 1 + KH - 1;
     (void)M;
     return (ROWS_RAW < H ? ROWS_RAW : H) * RS;
@@ -624,13 +655,19 @@ __device__ __forceinline__ void conv_h2_body(
     constexpr int OH = H - KH + 1, OW = W - KW + 1, M = OH * OW;
     constexpr int NT = cdiv(COUT, 16), WAVES_N = NT / RN;
     constexpr int CINP = cdiv(CIN, 32) * 32;
-    // SWZ: no padding -- a pixel is exactly its 8 chunks of 16 bytes (hi 0..3, lo 4..7) and chunk c of pixel x sits in
-    // slot c ^ ((x >> 1) & 7); rows are 32 bytes apart modulo 256.  A fragment read (16 pixels x one chunk: 16 adjacent
-    // pixels of a row, or the 4x4 block of a pooling tile) then covers all 16 slots of the 64 banks, and a 16-row tile of
-    // conv2 takes 73 KB instead of 83: two workgroups with 3 pixel tiles per wave fit a CU.
+    // SWZ: no padding -- a pixel is exactly its 8 chunks of 16 bytes (hi 0..3, lo 4..7), rows are whole multiples of
+    // 256 bytes, and chunk c of the pixel at column x of tile row y sits in slot c ^ h2_swz(x, y) =
+    // c ^ (2 (x >> 1) ^ (x & 1) ^ 4 (y & 1)).  ds_read_b128 is served in four groups of 16 lanes that are NOT contiguous
+    // ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32: MI355X_MICROARCH.md, LDS): a group holds the two diagonal 2x2
+    // windows of the pooling tile with k-quarter kq and the two off-diagonal ones with kq ^ 1.  Found by exhaustive
+    // search over linear swizzles against a model of every fragment read of the layer (tools/lds_conflict_model.py):
+    // every group lands on 16 distinct 16-byte slots of the 64 banks, for every tap -- and the 8-byte stores of the
+    // fused conv1 (16 consecutive pixels of a row per lane group) spread over the 32 store banks two deep, as before.
+    // (The round-2 swizzle, (x >> 1) & 7 with rows 32 bytes apart, is conflict-free for CONTIGUOUS groups of 16
+    // lanes; with the real groups the model gives 9.6 LDS cycles per read instead of 4.)
     static_assert(!SWZ || (CINP == 32 && POOL), "swizzled layout: 32 channels, pooling tiles");
-    constexpr int PS = SWZ ? 2 * CINP : 2 * CINP + 8;              // halves per pixel
-    constexpr int RS = SWZ ? W * PS + 16 : lds_stride_b(W * PS, POOL ? 32 : (8 * OW) % 64, 64);     // halves per row
+    constexpr int PS = SWZ ? 2 * CINP : 2 * CINP + h2_pspad<CINP, POOL>();              // halves per pixel
+    constexpr int RS = SWZ ? W * PS : lds_stride_b(W * PS, h2_rsrem<CINP, POOL, OW>(), 64);     // halves per row
     constexpr int KS = KH * KW * (CINP / 32);
     constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
     constexpr int R = cdiv(TB, WAVES_M);
@@ -645,6 +682,16 @@ __device__ __forceinline__ void conv_h2_body(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WAVES_N, wm = wave / WAVES_N;
     const int l15 = lane & 15, kq = lane >> 4;
+#if H2_DBG_TIME
+    unsigned long long t_prev__ = wall_clock64();
+#endif
+    // Two workgroups share a CU, and while one is in its k-loop (MFMA after MFMA) the other is usually staging its
+    // tile or running the fused conv1: short phases of loads, LDS traffic and vector arithmetic that need few issue
+    // slots but, at equal priority, wait behind the other workgroup's matrix instructions for every one of them
+    // (measured per workgroup: 7.8 us of staging + conv1 next to 8.4 us of k-loop, for 6 % of the flops).  They run
+    // at wave priority 3, the k-loop at 0: the issue arbiter serves the short phase first, the matrix pipe stays fed
+    // by the other workgroup.
+    if constexpr (H2_PRIO != 0) __builtin_amdgcn_s_setprio(3);
     const int tile_blk = blk_y * TB;
     const int oy_min = POOL ? 4 * (tile_blk / (OW / 4)) : (tile_blk * 16) / OW;
     int row_cnt = H - oy_min;
@@ -683,11 +730,12 @@ __device__ __forceinline__ void conv_h2_body(
 #pragma unroll
         for (int n = 0; n < 2; n++) bv1[n] = *reinterpret_cast<const float4*>(bias1 + n * 16 + 4 * kq);
         __syncthreads();
+        H2_STAMP(0);                                          // pixels staged, conv1 weights loaded
         const int ntile1 = row_cnt * W / 16;                 // 36 or 27 tiles of 16 conv1 pixels
         constexpr int NW = NTHREADS / 64, R1 = cdiv(ROWS * W / 16, NW);
         float big = 0.f;
 #pragma unroll
-        for (int r = 0; r < R1; r++) {
+        for (int r = 0; r < (H2_DBG_SKIP == 2 ? 0 : R1); r++) {
             const int tile = wave + NW * r;
             if (tile < ntile1) {
                 const int m = tile * 16 + l15, my = m / W, mx = m % W;
@@ -713,7 +761,7 @@ __device__ __forceinline__ void conv_h2_body(
                     }
                 }
                 // lane (pixel l15, kq) holds channels 16 n + 4 kq .. + 3: half a chunk of the pixel
-                const int sw = (mx >> 1) & 7;
+                const int sw = h2_swz(mx, my);
                 _Float16* px = &lds[my * RS + mx * PS + 4 * (kq & 1)];
 #pragma unroll
                 for (int n = 0; n < 2; n++) {
@@ -736,6 +784,7 @@ __device__ __forceinline__ void conv_h2_body(
             }
         }
         if (overflow && !(big <= 65000.f)) *overflow = 1;
+        H2_STAMP(4);                                          // wave 0's conv1 tiles
     } else if constexpr (!IN_LDS) {
         const float2* g = reinterpret_cast<const float2*>(in + ((size_t)patch * H + oy_min) * W * CIN);
         float big = 0.f;
@@ -751,7 +800,7 @@ __device__ __forceinline__ void conv_h2_body(
             split_h2(v.y, h1, l1);
             typedef _Float16 h2v __attribute__((ext_vector_type(2)));
             if constexpr (SWZ) {
-                const int x = pxl % W, sw = (x >> 1) & 7;
+                const int x = pxl % W, sw = h2_swz(x, pxl / W);
                 _Float16* d = &lds[(pxl / W) * RS + x * PS + (2 * c & 7)];
                 *reinterpret_cast<h2v*>(d + (((c >> 2) ^ sw) << 3)) = h2v{h0, h1};
                 *reinterpret_cast<h2v*>(d + (((c >> 2) ^ sw ^ 4) << 3)) = h2v{l0, l1};
@@ -771,6 +820,7 @@ __device__ __forceinline__ void conv_h2_body(
             }
     }
     if constexpr (!IN_LDS) __syncthreads();
+    H2_STAMP(1);                                              // conv1 tiles done (all waves)
 
     const int tile0 = tile_blk + wm * R;
     int abase[R], axr[R];
@@ -789,15 +839,20 @@ __device__ __forceinline__ void conv_h2_body(
             oy = m / OW; ox = m % OW;
         }
         abase[r] = SWZ ? (oy - oy_min) * RS + ox * PS : (oy - oy_min) * RS + ox * PS + 8 * kq;
-        axr[r] = ox;
+        axr[r] = SWZ ? (ox | ((oy - oy_min) & 1) << 18) : ox;      // swizzled layout: column, and 4 x the parity of the tile row
     }
+    // The accumulators start at bias x weight scale (a power of two: exact), so the epilogue has no global load to wait
+    // for -- the bias fetch hides behind the staging instead of sitting between the last MFMA and the stores.
     f32x4 acc[R][RN];
 #pragma unroll
-    for (int r = 0; r < R; r++)
+    for (int n = 0; n < RN; n++) {
+        const int co0 = (wn * RN + n) * 16 + l15;
+        const float b0 = (co0 < COUT ? bias[co0] : 0.f) * H2_WSCALE;
 #pragma unroll
-        for (int n = 0; n < RN; n++)
+        for (int r = 0; r < R; r++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) acc[r][n][e] = 0.f;
+            for (int e = 0; e < 4; e++) acc[r][n][e] = b0;
+    }
 
     int nv = TB - wm * R;
     nv = nv > R ? R : nv;
@@ -814,8 +869,10 @@ __device__ __forceinline__ void conv_h2_body(
         constexpr int NS = PF + 1;
         uint4 bq[NS][RN][2];
         if constexpr (SWZ) {
-            // column tap outermost: the swizzle depends on x = ox + j only, so the two fragment addresses of a pixel
-            // tile are computed once per tap column and the KH rows are immediate offsets.  The weight fragments stay in
+            // column tap outermost: the swizzle of a pixel depends on its column x = ox + j and on the parity of its row.
+            // The two fragment addresses of a pixel tile are computed once per tap column; a row of the other parity
+            // flips bit 2 of the slot, which is exactly what tells the hi plane from the lo plane -- so for odd taps i the
+            // two addresses simply change roles, and the KH rows are immediate offsets.  The weight fragments stay in
             // (i, j) order in memory; seq = j * KH + i is the order they are used in.
             auto step_of = [](int seq) { return (seq % KH) * KW + seq / KH; };
 #pragma unroll
@@ -826,12 +883,15 @@ __device__ __forceinline__ void conv_h2_body(
                     for (int pl = 0; pl < 2; pl++) bq[u][n][pl] = wq[((size_t)n * KS + step_of(u)) * 128 + pl * 64];
 #pragma unroll
             for (int j = 0; j < KW; j++) {
-                int ahj[NV > 0 ? NV : 1], alj[NV > 0 ? NV : 1];
+                // hi-plane address for even taps i; the lo plane -- and the hi plane for odd i -- is 32 halves away (slot ^ 4:
+                // pixels and rows are multiples of 64 halves, so the slot bits of an address can be flipped with an xor)
+                int a0j[NV > 0 ? NV : 1], a1j[NV > 0 ? NV : 1];
 #pragma unroll
                 for (int r = 0; r < NV; r++) {
-                    const int ch = kq ^ (((axr[r] + j) >> 1) & 7);
-                    ahj[r] = abase[r] + j * PS + (ch << 3);
-                    alj[r] = abase[r] + j * PS + ((ch ^ 4) << 3);
+                    const int x = (axr[r] & 0xFFFF) + j;
+                    const int ch = kq ^ h2_swz(x, 0) ^ (axr[r] >> 16);
+                    a0j[r] = abase[r] + j * PS + (ch << 3);
+                    a1j[r] = a0j[r] ^ 32;
                 }
 #pragma unroll
                 for (int i = 0; i < KH; i++) {
@@ -857,8 +917,8 @@ __device__ __forceinline__ void conv_h2_body(
                     h8 ahv[NV > 0 ? NV : 1], alv[NV > 0 ? NV : 1];
 #pragma unroll
                     for (int r = 0; r < NV; r++) {
-                        ahv[r] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&lds[ahj[r] + i * RS]));
-                        alv[r] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&lds[alj[r] + i * RS]));
+                        ahv[r] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&lds[((i & 1) ? a1j[r] : a0j[r]) + i * RS]));
+                        alv[r] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&lds[((i & 1) ? a0j[r] : a1j[r]) + i * RS]));
                     }
 #pragma unroll
                     for (int r = 0; r < NV; r++)
@@ -875,8 +935,8 @@ __device__ __forceinline__ void conv_h2_body(
 #else
 #pragma unroll
                     for (int r = 0; r < NV; r++) {
-                        const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&lds[ahj[r] + i * RS]));
-                        const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&lds[alj[r] + i * RS]));
+                        const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&lds[((i & 1) ? a1j[r] : a0j[r]) + i * RS]));
+                        const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const uint4*>(&lds[((i & 1) ? a0j[r] : a1j[r]) + i * RS]));
 #pragma unroll
                         for (int n = 0; n < RN; n++) {
                             acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[n], acc[r][n], 0, 0, 0);
@@ -936,19 +996,21 @@ __device__ __forceinline__ void conv_h2_body(
         }
     };
     const bool idle = tile0 >= RT;             // the last block of a patch may hold fewer tiles than waves x R
-    if (!idle) {
+    if constexpr (H2_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+    if (!idle && H2_DBG_SKIP != 1) {
         if (nv == R) k_loop(std::integral_constant<int, R>{});
         else if constexpr (R * WAVES_M > TB) k_loop(std::integral_constant<int, R - 1>{});
     }
 
     float nxt_big = 0.f;
+    if constexpr (H2_PRIO != 0) __builtin_amdgcn_s_setprio(3);
     if constexpr (NXT_W > 0) __syncthreads();          // every wave is done with the input tile the output overlays
+    H2_STAMP(2);                                       // wave 0's k-loop
     if (idle) return;
 
 #pragma unroll
     for (int n = 0; n < RN; n++) {
         const int co = (wn * RN + n) * 16 + l15;
-        const float bv = co < COUT ? bias[co] : 0.f;
         if constexpr (POOL) {
             float* o = out + (size_t)patch * (M / 4) * COUT;
 #pragma unroll
@@ -957,7 +1019,7 @@ __device__ __forceinline__ void conv_h2_body(
                 float mx = acc[r][n][0] > acc[r][n][1] ? acc[r][n][0] : acc[r][n][1];
                 const float m2 = acc[r][n][2] > acc[r][n][3] ? acc[r][n][2] : acc[r][n][3];
                 mx = mx > m2 ? mx : m2;
-                mx = mx * wscale_inv + bv;            // the weight scale is a power of two: exact
+                mx = mx * wscale_inv;                 // the weight scale is a power of two: exact (the bias is in the sum already)
                 mx = mx > 0.f ? mx : 0.f;
                 const int py = 2 * (t / (OW / 4)) + (kq >> 1), px = 2 * (t % (OW / 4)) + (kq & 1);
                 if (r < nv && t < RT && co < COUT) o[(size_t)(py * (OW / 2) + px) * COUT + co] = mx;
@@ -969,7 +1031,7 @@ __device__ __forceinline__ void conv_h2_body(
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int m = (tile0 + r) * 16 + 4 * kq + e;
-                    float v = acc[r][n][e] * wscale_inv + bv;
+                    float v = acc[r][n][e] * wscale_inv;
                     v = (v > 0.f && co < COUT) ? v : 0.f;
                     nxt_big = fmaxf(nxt_big, v);
                     _Float16 hh, ll;
@@ -988,7 +1050,7 @@ __device__ __forceinline__ void conv_h2_body(
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int m = (tile0 + r) * 16 + 4 * kq + e;
-                    float v = acc[r][n][e] * wscale_inv + bv;
+                    float v = acc[r][n][e] * wscale_inv;
                     v = v > 0.f ? v : 0.f;
                     if (r < nv && m < M && co < COUT) o[(size_t)m * COUT + co] = v;
                 }
@@ -998,11 +1060,16 @@ __device__ __forceinline__ void conv_h2_body(
     if constexpr (NXT_W > 0) {
         if (overflow && !(nxt_big <= 65000.f)) *overflow = 1;
     }
+    H2_STAMP(3);                                       // epilogue
+#if H2_DBG_TIME
+    if (FUSE1 && threadIdx.x == 0) atomicAdd(&g_h2_prof[7], 1ull);
+#endif
 }
 
 template <int H, int W, int CIN, int KH, int KW, int COUT, int TB, int YB, int WAVES_M, int RN, bool POOL, int PF, bool SB, bool SWZ = false,
           bool FUSE1 = false>
-__global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfma16_h2_kernel(
+// (two workgroups of 8 waves must fit a CU: 4 waves per SIMD = 128 VGPRs -- the second launch bound is HIP's minimum waves per SIMD; said explicitly, because one register more halves the occupancy)
+__global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN), (64 * WAVES_M * (cdiv(COUT, 16) / RN) >= 512 ? 4 : 1)) void conv_mfma16_h2_kernel(
     const float* __restrict__ in, const uint16_t* __restrict__ wt, const float* __restrict__ bias,
     float* __restrict__ out, float wscale_inv, int* __restrict__ overflow,
     const uint8_t* __restrict__ goban1 = nullptr, const uint16_t* __restrict__ wf1 = nullptr, const float* __restrict__ bias1 = nullptr)
@@ -1021,7 +1088,7 @@ __global__ __launch_bounds__(256, 2) void conv34_h2_kernel(
     int* __restrict__ overflow)
 {
     constexpr int T3 = h2_tile_halves<16, 16, 32, 3, 3, 13, false, false>(), T4 = h2_tile_halves<14, 14, 90, 3, 3, 9, true, false>();
-    constexpr int PS4 = 2 * 96 + 8, RS4 = lds_stride_b(14 * PS4, 32, 64);
+    constexpr int PS4 = 2 * 96 + h2_pspad<96, true>(), RS4 = lds_stride_b(14 * PS4, h2_rsrem<96, true, 12>(), 64);
     __shared__ __attribute__((aligned(16))) _Float16 lds[T3 > T4 ? T3 : T4];
     conv_h2_body<16, 16, 32, 3, 3, 90, 13, 1, 2, 3, false, H2C3_PF, H2C3_SB, false, false, false, 14, PS4, RS4, 96>(
         lds, blockIdx.x, 0, in, wt3, bias3, nullptr, wscale_inv, overflow);
@@ -1693,9 +1760,20 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             // 8x8 pooling tiles of 4x4 pixels: workgroups of whole tile rows, pooled output 16x16x32
             if (h2) {
 #if H2C2_SWZ
-                hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, H2C2S_TB, 64 / H2C2S_TB + (64 % H2C2S_TB != 0), 8, 2, true, H2C2S_PF, H2C2S_SB, true, H2_FUSE1 != 0>), dim3(np, 64 / H2C2S_TB + (64 % H2C2S_TB != 0)), dim3(512), (size_t)lds_pad_conv2(), ctx->stream,
+                hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, H2C2S_TB, 64 / H2C2S_TB + (64 % H2C2S_TB != 0), H2C2S_WM, 2, true, H2C2S_PF, H2C2S_SB, true, H2_FUSE1 != 0>), dim3(np, 64 / H2C2S_TB + (64 % H2C2S_TB != 0)), dim3(64 * H2C2S_WM), (size_t)lds_pad_conv2(), ctx->stream,
                                    (const float*)a1, (const uint16_t*)W.c2w_h2.p, (const float*)W.c2b.p, p2, 1.f / H2_WSCALE, d_nonfinite,
                                    gob, (const uint16_t*)W.c1w_h2.p, (const float*)W.c1b.p);
+#if H2_DBG_TIME
+                {
+                    unsigned long long hp[8];
+                    (void)hipStreamSynchronize(ctx->stream);
+                    (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_h2_prof), sizeof hp);
+                    if (hp[7]) fprintf(stderr, "[conv2 phases, us per workgroup over %llu workgroups] stage %.2f  conv1 tiles (wave 0) %.2f  wait for the others %.2f  k-loop %.2f  epilogue %.2f\n", hp[7],
+                                       hp[0] * 0.01 / hp[7], hp[4] * 0.01 / hp[7], hp[1] * 0.01 / hp[7], hp[2] * 0.01 / hp[7], hp[3] * 0.01 / hp[7]);
+                    memset(hp, 0, sizeof hp);
+                    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_h2_prof), hp, sizeof hp);
+                }
+#endif
 #else
                 hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, H2C2_TB, 64 / H2C2_TB, H2C2_WM, 2, true, H2C2_PF, true>), dim3(np, 64 / H2C2_TB), dim3(64 * H2C2_WM), 0, ctx->stream,
                                    (const float*)a1, (const uint16_t*)W.c2w_h2.p, (const float*)W.c2b.p, p2, 1.f / H2_WSCALE, d_nonfinite);
