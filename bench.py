@@ -331,10 +331,14 @@ def main():
             extras["holdoff_aware"] = dict(value=round(n_total * k / dlz, 2), unit="frames/s", steps=k, same_game_record=bool(same),
                                            host_ms_per_step={kk: round(1e3 * v / k, 3) for kk, v in lazy.host_seconds.items()},
                                            board_records_computed_pct=round(100.0 * lazy.board.fetched / max(1, lazy.board.seen), 1),
-                                           note="NOT the headline, and slower as built: K1-K6 run only for the frames the board fold looks "
-                                                "at (windows predicted from the hold-off, one launch per batch), but that launch sits on the "
-                                                "fold's thread, one context, ~70 us per frame with its host round trips, while the eager path "
-                                                "spreads full batches over two lanes; stones path on every frame")
+                                           board_fetch_calls_per_batch=round(lazy.board.calls * n_total / max(1, lazy.board.seen), 2),
+                                           extra_grouping_rounds_of_recent_detections=list(lazy.board.recent),
+                                           note="NOT the headline (that one runs K1-K6 on every frame): K1-K6 only for the frames the board "
+                                                "fold looks at, all windows of a batch predicted from the frame-count phase of the library's 4-frame "
+                                                "grouping and fetched in one call over both lanes' board contexts, behind the stones core of the next "
+                                                "batch.  On this film detections need 0 to 4 extra grouping rounds (hands over the board), so the "
+                                                "windows carry slack and about half of the records are still computed: it ends level with the eager "
+                                                "path, whose board work hides behind two lanes anyway; stones path on every frame")
         # (2) PCIe-inclusive: the batch starts as I420 in PINNED host memory (what a video-file reader holds), is
         # uploaded and converted lane by lane (ck_i420_to_bgr), answers come back to the host; two batches in flight
         if world == 1:

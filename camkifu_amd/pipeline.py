@@ -149,8 +149,9 @@ class BoardFold:
         self.frame = np.zeros((h, w, 0), np.uint8)          # what _detect needs of a frame once the image chain ran: its shape
         self.refresh_frames = 10 * cvconf.file_fps if refresh_frames is None else refresh_frames
         self.hold = 0
-        self.seen = self.looked = self.fetched = 0           # records offered / records _detect was called with / computed lazily
-        self.episode = 8                                     # frames the last detection took (run_lazy's prediction)
+        self.seen = self.looked = self.fetched = self.calls = 0   # records offered / looked at / computed lazily / fetch calls
+        self.episode = 8                                     # frames the last detection took
+        self.recent = [1]                                    # extra grouping rounds the last few detections needed (run_lazy's prediction)
 
     @property
     def mtx(self):
@@ -194,25 +195,29 @@ class BoardFold:
         """The same fold over a batch of n frames whose board records do not exist yet: `fetch(indices)` computes the
         records of those frames (-> BOARD_DTYPE array, lines (len(indices), cap, 2)) and is only asked for frames this
         fold is going to look at.  During the hold-off the reference does not run K1..K6 at all (bf_auto.py:43-49);
-        this is that, batch-wise.  The frames looked at are predictable -- from the frame the hold-off expires on until
-        the next hit, which on a steady camera comes after as many frames as last time -- so the windows of a whole batch
-        are requested in ONE call (small launches are latency-bound); a hit that comes later than predicted costs an
-        extra call of `chunk` frames, one that comes earlier leaves a few computed records unused.  Same calls to `step`
-        in the same order as `run` over the full records, hence the same corners."""
-        span = max(chunk, self.episode + 2)
-        want, k, hold = [], 0, self.hold
-        while k < n:                                         # the prediction: hold-off, then `span` frames, a hit, ...
-            if hold > 0:
-                skip = min(hold, n - k)
-                k, hold = k + skip, hold - skip
-                continue
-            want.extend(range(k, min(n, k + span)))
-            k, hold = k + max(1, self.episode), self.refresh_frames
+        this is that, batch-wise.  The frames looked at are predictable (below), so the windows of a whole batch are
+        requested in ONE call; a hit that comes later than predicted costs an extra call of 2 x `chunk` frames, one that
+        comes earlier leaves a few computed records unused.  Same calls to `step` in the same order as `run` over the
+        full records, hence the same corners."""
+        # A fetch is a GPU round trip of a few milliseconds whatever its size, and where window j + 1 starts depends on
+        # where window j's hit fell -- a chain of round trips unless the hits are predicted.  They can be: the library
+        # looks for corners only on frames whose running count is a multiple of 4 (bf_auto.py:85-94), so a window that
+        # opens on count c closes on the next multiple of 4 (1 to 4 frames), or 4 x `tries` frames later when the
+        # grouping needed more rounds lately.  All windows of the batch are asked for in ONE call.
+        c0 = self.finder.total_f_processed
+        slack = 4 * max(self.recent[-2:])                    # frames a hit may come late by, judging from the last two
+        want, a, late = [], self.hold, 0
+        while a < n:
+            first = (-(c0 + a)) % 4 + 1                      # the window closes here if the first grouping round hits
+            late += slack                                    # ... and every window before this one may have run late too
+            want.extend(f for f in range(a, min(n, a + first + late)) if not want or f > want[-1])
+            a += first + self.refresh_frames
         cache = {}
 
         def load(indices):
             res, lines = fetch(indices)
             self.fetched += len(indices)
+            self.calls += 1
             for j, f in enumerate(indices):
                 cache[f] = (int(res["status"][j]), int(res["n_lines"][j]), lines[j])
         if want:
@@ -227,12 +232,16 @@ class BoardFold:
                 k += skip
                 continue
             if k not in cache:
-                load([f for f in range(k, min(n, k + chunk)) if f not in cache])
+                load([f for f in range(k, min(n, k + 2 * chunk)) if f not in cache])
             status, n_lines, lines = cache[k]
+            if run == 0:
+                opened = self.finder.total_f_processed       # the count this window opens on
             self.step(dict(status=status, n_lines=n_lines, lines=lines))
             k, run = k + 1, run + 1
             if self.hold > 0:
-                self.episode, run = run, 0                   # frames it took from the end of the hold-off to this hit
+                self.episode = run                           # frames it took from the end of the hold-off to this hit
+                self.recent = (self.recent + [max(0, (run - ((-opened) % 4 + 1)) // 4)])[-4:]
+                run = 0
         return self.mtx
 
 
