@@ -261,6 +261,27 @@ class StonesFinder(VidProcessor):
             self._posgrid.learn(np.abs(cached))
         return cached
 
+    # ---- consistency checks on a candidate result (stonesfinder.py:597-783; vectorised in stone/checks.py) ---------
+    def check_against(self, stones, reference=None, rs=0, re=gsize, cs=0, ce=gsize, **kwargs):
+        from . import checks
+        return checks.check_against(stones, reference, rs, re, cs, ce)
+
+    def check_lines(self, stones, img=None, rs=0, re=gsize, cs=0, ce=gsize, **kwargs):
+        from . import checks
+        return checks.check_lines(stones, self.get_intersections(img), rs, re, cs, ce)
+
+    def check_thickness(self, stones, rs=0, re=gsize, cs=0, ce=gsize, **kwargs):
+        from . import checks
+        return checks.check_thickness(stones, rs, re, cs, ce)
+
+    def check_flow(self, stones, rs=0, re=gsize, cs=0, ce=gsize, **kwargs):
+        from . import checks
+        return checks.check_flow(stones, self.sink.board_codes().reshape(gsize, gsize) == 0, rs, re, cs, ce)
+
+    def first_line_lonelies(self, stones, reference=None, rs=0, re=gsize, cs=0, ce=gsize, **kwargs):
+        from . import checks
+        return checks.first_line_lonelies(stones, reference, rs, re, cs, ce)
+
     # ---- user corrections ------------------------------------------------------------------------
     def corrected(self, err_move, exp_move):
         pending = self.corrections
