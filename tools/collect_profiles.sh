@@ -6,7 +6,7 @@
 set -e
 export TMPDIR=/tmp
 O=gpurun_out
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 bench.py --no-cpu-baseline --no-extras > $O/bench_prof.json 2> $O/prof_bench.err
 echo "bench stats done"
@@ -17,7 +17,7 @@ echo "stonefind stats done"
 # the per-launch traces are large and not needed once the stats exist (gpurun merges back at most 64 MiB)
 find $O/prof_bench $O/prof_serial $O/prof_stonefind -name "*kernel_trace.csv" -delete 2>/dev/null || true
 find $O/prof_bench $O/prof_serial $O/prof_stonefind -name "*.db" -delete 2>/dev/null || true
-PMCARGS="--steps 1 --warmup 0 --frames 64 --lanes 1 --no-cpu-baseline --no-extras"
+PMCARGS="--timed-only --steps 2 --warmup 1 --frames 256 --lanes 2"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py $PMCARGS > /dev/null 2> $O/pmc_fetch.err
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py $PMCARGS > /dev/null 2> $O/pmc_write.err
@@ -25,6 +25,9 @@ echo "write done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc_valu -- python3 bench.py $PMCARGS > /dev/null 2> $O/pmc_valu.err
 echo "valu done"
 find $O/pmc_fetch $O/pmc_write $O/pmc_valu -name "*.db" -delete 2>/dev/null || true
+# summarise here: at the bench's own scale the raw counter tables are too large to travel back (gpurun merges 64 MiB)
+python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write 128 $O/pmc_traffic.json $O/pmc_valu > /dev/null
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_valu
 du -sh $O | tail -1
 python bench.py > $O/bench_full.json 2> $O/bench_full.err
 echo "bench done"

@@ -17,6 +17,8 @@ import sys
 
 # (kernel-name substring, stage, frames per dispatch cap, loads are 16 B per lane)
 STAGE = [("median_mfma_kernel<15>", "median", None, False), ("canny_nms", "canny_nms", None, False),
+         ("prep_runs", "ccl_prep_runs", None, False), ("link_runs", "ccl_link_runs", None, False),
+         ("border_runs", "ccl_border_runs", None, False),
          ("prep_rows", "ccl_prep_rows", None, False), ("border_list", "ccl_border_list", None, False),
          ("hough_vote", "hough_vote", None, False), ("warp_kernel", "warp", None, False),
          ("mog2_run_kernel", "mog2", None, False),
@@ -24,8 +26,12 @@ STAGE = [("median_mfma_kernel<15>", "median", None, False), ("canny_nms", "canny
          ("fc1_h2_kernel", "cnn_fc1", None, True)]
 
 
+# SURVEY.md 8(d) per 1080p frame: median 2 x 3WH, NMS 3WH + WH, warp 433 200 + the source quad (<= 3WH), background model 433 200 + 1 444
+ALGORITHMIC = {"median": 12441600, "canny_nms": 8294400, "warp": 433200 + 6220800, "mog2": 433200 + 1444}
+
+
 def load(d, counter):
-    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
@@ -42,8 +48,9 @@ def main():
     valu = load(sys.argv[5], "SQ_INSTS_VALU") if len(sys.argv) > 5 else {}
     mfma = load(sys.argv[5], "SQ_INSTS_MFMA") if len(sys.argv) > 5 else {}
     frames = int(sys.argv[3])
-    out = {"_source": "rocprofv3 --pmc, one pass per counter group, `bench.py --steps 1 --warmup 0 --frames %d --lanes 1 "
-                      "--no-cpu-baseline --no-extras` (tools/collect_profiles.sh); KiB counters; per frame" % frames,
+    out = {"_source": "rocprofv3 --pmc, one pass per counter group, the bench's own shape: `bench.py --timed-only --frames 256 --lanes 2 "
+                      "--warmup 1 --steps 2` = %d frames per launch, two lanes cycling 1.59 GB of frames (inputs come from HBM, not "
+                      "from the Infinity Cache), tools/collect_profiles.sh; KiB counters; per frame" % frames,
            "_correction": "hbm_bytes_raw = (FETCH_SIZE + WRITE_SIZE) * 1024; hbm_bytes_corrected doubles FETCH_SIZE only for "
                           "kernels with wide_loads = true (16 B per lane), MI355X_MICROARCH.md"}
     for key, stage, chunk, wide in STAGE:
@@ -55,6 +62,9 @@ def main():
         out[stage] = dict(fetch_kib_per_frame=round(fk, 1), write_kib_per_frame=round(wk, 1), wide_loads=wide,
                           hbm_bytes_raw=int((fk + wk) * 1024), hbm_bytes_corrected=int(((2 if wide else 1) * fk + wk) * 1024),
                           dispatches=fetch[stage][0])
+        if stage in ALGORITHMIC:
+            out[stage]["algorithmic_bytes"] = ALGORITHMIC[stage]
+            out[stage]["counter_over_algorithmic"] = round(out[stage]["hbm_bytes_corrected"] / ALGORITHMIC[stage], 3)
         if stage in valu:
             m = int(mfma[stage][1] / mfma[stage][0] / per) if stage in mfma else 0      # SQ_INSTS_VALU includes the MFMAs
             out[stage]["valu_wave_insts_per_frame"] = int(valu[stage][1] / valu[stage][0] / per) - m

@@ -3,10 +3,10 @@
 # (named per round): rocprofv3 kernel stats of the bench command and of the serial pass, the PMC traffic summary, the bench line.
 set -e
 cd "$(dirname "$0")/.."
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 rm -rf gpurun_out/prof_bench gpurun_out/prof_serial gpurun_out/prof_stonefind gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_valu
 /usr/local/graft/bin/gpurun --timeout 1100 -- 'timeout -k 10 1000 bash tools/collect_profiles.sh' > /tmp/collect.log 2>&1 || { tail -20 /tmp/collect.log; exit 1; }
-python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write 64 profiles/${R}_pmc_traffic.json gpurun_out/pmc_valu > /dev/null
+cp gpurun_out/pmc_traffic.json profiles/${R}_pmc_traffic.json
 python - "$R" <<'PY'
 import csv, glob, json, sys
 R = sys.argv[1]
