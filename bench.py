@@ -422,6 +422,10 @@ def main():
     if rank == 0:
         handle = ctx.mog2_create(380, 380)
         rates = np.full(F, 0.005)
+        # one untimed pass at this pass's own shape (a whole batch in one call): scratch buffers grow to it outside the brackets
+        ctx_b.board_detect(frames, cap=pipeline.LMAX, raw=True)
+        ctx.stones_run(frames, M, mog2=handle, learning_rates=rates)
+        torch.cuda.synchronize()
         for c in (ctx, ctx_b):
             c.timing_enable(True)
             c.timing_reset()
