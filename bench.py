@@ -189,6 +189,10 @@ def main():
     ap.add_argument("--streams", action="store_true",
                     help="BASELINE config 5: every GPU processes its OWN video stream (its own game, camera and background "
                          "model; seed + rank) -- no record gather, no band exchange; the default is ONE video dealt to the ranks")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="rehearsal on ONE GPU: a process group of one rank on --dist-backend and the pipeline's whole exchange stage "
+                         "(record gather, transform broadcast, band all-to-all, band model on its own context, counts gather) "
+                         "issued for real")
     ap.add_argument("--timed-only", action="store_true",
                     help="profiling runs (rocprofv3 --pmc): set-up, warm-up and the timed region only -- every dispatch of the run "
                          "then has the bench's own shape (frames / lanes per launch); prints a short line")
@@ -216,6 +220,13 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.dist_backend)
+    elif args.force_exchange:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=0, world_size=1)
 
     from camkifu_amd import capi, pipeline, synth
     from camkifu_amd.controller import ControllerHeadless
@@ -243,7 +254,7 @@ def main():
 
     def new_pipe():
         return pipeline.FastFilePipeline(H, W, ControllerHeadless(), rank=pr, world=pw, device=cdev,
-                                         lanes=lanes, ctx_bg=ctx_bg)
+                                         lanes=lanes, ctx_bg=ctx_bg, force_exchange=args.force_exchange)
     pipe = new_pipe()
 
     def sync():
@@ -558,7 +569,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out_line["cpu_baseline"] = cpu_baseline(frames, M, weights, n_warm=8, n_frames=args.cpu_frames, reps=5)
         print(json.dumps(out_line))
-    if world > 1:
+    if world > 1 or args.force_exchange:
         dist.barrier()
         dist.destroy_process_group()
 

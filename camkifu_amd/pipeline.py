@@ -449,15 +449,19 @@ class FastFilePipeline:
     `gobans` (n x 380 x 380 x 3) is only handed back when world > 1, for the pixel-sharded background model."""
 
     def __init__(self, h, w, controller, ctx=None, rank=0, world=1, device=None, compute=None, ctx_board=None,
-                 bg_init_frames=50, band_model=None, lanes=None, ctx_bg=None, board_lazy=False):
+                 bg_init_frames=50, band_model=None, lanes=None, ctx_bg=None, board_lazy=False, force_exchange=False):
         from concurrent.futures import ThreadPoolExecutor
         self.h, self.w = h, w
         self.rank, self.world = rank, world
         self.group = _Group(rank, world, device)
         self.ctx = ctx if ctx is not None else (lanes[0][1] if lanes else None)      # frame source helper (process_y4m)
         self.ctx_bg = ctx_bg
+        # force_exchange: run the whole exchange stage (record gather, broadcast, band all-to-all, counts gather) even with
+        # one rank -- a process group of one must exist -- so that the collective code path can be exercised on a box with
+        # a single GPU (tests/test_gpu_multirank.py does, over RCCL)
+        self.exchange = world > 1 or bool(force_exchange)
         if compute is None:
-            compute = GpuCore(lanes or [(ctx_board, ctx)], bg_ctx=ctx_bg, local_model=(world == 1))
+            compute = GpuCore(lanes or [(ctx_board, ctx)], bg_ctx=ctx_bg, local_model=not self.exchange)
         self.compute = compute
         self._runner = ThreadPoolExecutor(2)                  # two batches may be inside the GPU core at once
         self._comm = ThreadPoolExecutor(1)                    # stage 2: every collective of this rank, in batch order
@@ -474,7 +478,7 @@ class FastFilePipeline:
         # hold-off-aware mode (one rank): the GPU core leaves the board path out and the board fold computes, through the
         # lanes' board contexts (on their own threads), only the records it looks at.  With frames dealt across ranks
         # the fold would have to ask other ranks for theirs: not built, the full records are computed then.
-        self.board_lazy = bool(board_lazy) and world == 1 and hasattr(self.compute, "lanes")
+        self.board_lazy = bool(board_lazy) and not self.exchange and hasattr(self.compute, "lanes")
 
     # ---- pixel-sharded background model (world > 1) -------------------------------------------------------
     def _band_counts(self, gobans, n_total, rates):
@@ -546,7 +550,7 @@ class FastFilePipeline:
         if mtx is not None:
             self.stone_frames += n_total
         mine = shard_indices(n_total, self.rank, self.world)
-        rates_for_core = rates if self.world == 1 else rates[mine]
+        rates_for_core = rates if not self.exchange else rates[mine]
         seq = self.compute.ticket() if hasattr(self.compute, "ticket") else None
         t = _Ticket(self._runner.submit(self._guarded, my_frames, mtx, rates_for_core, len(mine), seq), mtx, rates, n_total, my_frames)
         t.exchange = self._comm.submit(self._exchange, t)
@@ -565,7 +569,7 @@ class FastFilePipeline:
         rec = pack_records(board, rl, rc, failed=failure is not None)
         t1 = time.perf_counter()
         hs["pack"] += t1 - t0
-        if self.world == 1:
+        if not self.exchange:
             full, counts, failed = rec, fg, failure is not None
         else:
             # row 0 of every rank's contribution is a header: a rank whose shard is empty can still say that it failed
@@ -594,7 +598,7 @@ class FastFilePipeline:
             new = self.board.mtx
         t4 = time.perf_counter()
         hs["fold_board"] += t4 - t3
-        if self.world > 1:
+        if self.exchange:
             wire = np.zeros(10)
             if self.rank == 0 and new is not None:
                 wire[0], wire[1:] = 1.0, np.asarray(new, np.float64).reshape(9)

@@ -29,7 +29,7 @@ def _film(select):
     return torch.cat([a, b]).cuda()
 
 
-def _drive(rank, world, depth=2):
+def _drive(rank, world, depth=2, force_nccl=False):
     import torch
     import torch.distributed as dist  # noqa: F401
     from camkifu_amd import capi, pipeline
@@ -41,8 +41,12 @@ def _drive(rank, world, depth=2):
     for _, c in lanes:
         c.cnn_set_weights(weights)
     ctrl = ControllerHeadless()
-    pipe = pipeline.FastFilePipeline(H, W, ctrl, rank=rank, world=world, device=torch.device("cpu") if world > 1 else None,
-                                     lanes=lanes, ctx_bg=capi.Context(0), bg_init_frames=BG)
+    if force_nccl:           # one rank, but every collective of the exchange stage issued for real, on device buffers over RCCL
+        pipe = pipeline.FastFilePipeline(H, W, ctrl, rank=0, world=1, device=torch.device("cuda", 0), lanes=lanes,
+                                         ctx_bg=capi.Context(0), bg_init_frames=BG, force_exchange=True)
+    else:
+        pipe = pipeline.FastFilePipeline(H, W, ctrl, rank=rank, world=world, device=torch.device("cpu") if world > 1 else None,
+                                         lanes=lanes, ctx_bg=capi.Context(0), bg_init_frames=BG)
     pipe.board.refresh_frames = 5            # keep looking: the bump must be noticed within a batch or two
     mine, batches = [], []
     for b0 in range(0, FILM, BATCH):
@@ -64,24 +68,28 @@ def _drive(rank, world, depth=2):
                 looked=pipe.board.looked, host=dict(pipe.host_seconds))
 
 
-def _run(rank, world, port, q):
+def _run(rank, world, port, q, force_nccl=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    if world > 1:
+    if force_nccl:
+        import torch
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    elif world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank, _drive(rank, world)))
+        q.put((rank, _drive(rank, world, force_nccl=force_nccl)))
     except BaseException as why:                                 # the parent must not wait for a rank that died
         import traceback
         q.put((rank, "FAILED: %s\n%s" % (why, traceback.format_exc())))
         raise
     finally:
-        if world > 1:
+        if world > 1 or force_nccl:
             dist.destroy_process_group()
 
 
-def _spawn(world):
+def _spawn(world, force_nccl=False):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -89,7 +97,7 @@ def _spawn(world):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_run, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, q, force_nccl)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=420) for _ in range(world)), key=lambda t: t[0])
@@ -114,6 +122,19 @@ def test_two_ranks_with_real_kernels_equal_one_rank():
     assert r0["mtxs"] == one["mtxs"] and r1["mtxs"] == one["mtxs"]                # every rank warps with the same transform
     assert all(e is None for e in r1["emitted"])                                  # only rank 0 folds
     assert r0["host"]["band_model"] > 0 and r1["host"]["band_model"] > 0          # the band model did run on both
+
+
+@pytest.mark.gpu
+def test_the_exchange_stage_over_rccl_with_one_rank():
+    """What a one-GPU box can check of the RCCL path: a process group of ONE rank on the `nccl` backend and the pipeline
+    told to run its whole exchange stage anyway -- all-gather of the records, transform broadcast, all-to-all of goban
+    bands on device buffers, band model on its own context, counts gather, all issued from the exchange thread.  Same
+    requests, transforms and game record as the plain one-rank run (which has no exchange stage at all)."""
+    plain = _spawn(1)[0]
+    rccl = _spawn(1, force_nccl=True)[0]
+    assert rccl["emitted"] == plain["emitted"] and rccl["mtxs"] == plain["mtxs"]
+    assert rccl["sgf"] == plain["sgf"] and rccl["targets"] == plain["targets"]
+    assert rccl["host"]["band_exchange"] > 0 and rccl["host"]["band_model"] > 0 and plain["host"]["band_exchange"] == 0
 
 
 @pytest.mark.gpu
