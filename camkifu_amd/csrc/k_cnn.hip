@@ -112,6 +112,12 @@ __device__ unsigned long long g_h2_prof[8];
 #ifndef H2_PRIO
 #define H2_PRIO 1         // wave priority 3 outside the k-loop (staging, fused conv1, epilogue), 0 inside: see conv_h2_body
 #endif
+#ifndef H2C34_RN
+#define H2C34_RN 3        // channel tiles per wave in the fused conv3 + conv4 kernel: 3 -> 4 waves per workgroup, 2 -> 6 waves
+#endif
+#ifndef H2C34_MINW
+#define H2C34_MINW 2      // minimum waves per SIMD asked of the compiler for that kernel
+#endif
 #ifndef H2C2S_WM
 #define H2C2S_WM 8       // waves per conv2 workgroup along the pixel tiles: R = H2C2S_TB / H2C2S_WM tiles per wave
 #endif
@@ -1082,7 +1088,7 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN), (64 * WAVES_M
 // conv3 (3x3x32 -> 90, relu) and conv4 (3x3x90 -> 90, relu, 2x2 max-pool) of one patch in one workgroup: conv3's
 // 14x14x90 output is written as hi/lo halves into conv4's LDS tile (which overlays conv3's own input tile once its
 // k-loop is done) instead of going to HBM and back.  Same arithmetic in the same order as the two kernels apart.
-__global__ __launch_bounds__(256, 2) void conv34_h2_kernel(
+__global__ __launch_bounds__(64 * 2 * (6 / H2C34_RN), H2C34_MINW) void conv34_h2_kernel(
     const float* __restrict__ in, const uint16_t* __restrict__ wt3, const float* __restrict__ bias3,
     const uint16_t* __restrict__ wt4, const float* __restrict__ bias4, float* __restrict__ out, float wscale_inv,
     int* __restrict__ overflow)
@@ -1090,10 +1096,10 @@ __global__ __launch_bounds__(256, 2) void conv34_h2_kernel(
     constexpr int T3 = h2_tile_halves<16, 16, 32, 3, 3, 13, false, false>(), T4 = h2_tile_halves<14, 14, 90, 3, 3, 9, true, false>();
     constexpr int PS4 = 2 * 96 + h2_pspad<96, true>(), RS4 = lds_stride_b(14 * PS4, h2_rsrem<96, true, 12>(), 64);
     __shared__ __attribute__((aligned(16))) _Float16 lds[T3 > T4 ? T3 : T4];
-    conv_h2_body<16, 16, 32, 3, 3, 90, 13, 1, 2, 3, false, H2C3_PF, H2C3_SB, false, false, false, 14, PS4, RS4, 96>(
+    conv_h2_body<16, 16, 32, 3, 3, 90, 13, 1, 2, H2C34_RN, false, H2C3_PF, H2C3_SB, false, false, false, 14, PS4, RS4, 96>(
         lds, blockIdx.x, 0, in, wt3, bias3, nullptr, wscale_inv, overflow);
     __syncthreads();
-    conv_h2_body<14, 14, 90, 3, 3, 90, 9, 1, 2, 3, true, H2C34_PF, true, false, false, true>(
+    conv_h2_body<14, 14, 90, 3, 3, 90, 9, 1, 2, H2C34_RN, true, H2C34_PF, true, false, false, true>(
         lds, blockIdx.x, 0, nullptr, wt4, bias4, out, wscale_inv, overflow);
 }
 
@@ -1788,7 +1794,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         if (h2 && H2_FUSE34) {
             TimeScope ts(ctx, "cnn_conv4");
             // conv3 + conv4 of a patch in one workgroup; pooled 6x6x90 written directly
-            hipLaunchKernelGGL(conv34_h2_kernel, dim3(np), dim3(256), (size_t)lds_pad_conv34(), ctx->stream, (const float*)p2, (const uint16_t*)W.c3w_h2.p,
+            hipLaunchKernelGGL(conv34_h2_kernel, dim3(np), dim3(64 * 2 * (6 / H2C34_RN)), (size_t)lds_pad_conv34(), ctx->stream, (const float*)p2, (const uint16_t*)W.c3w_h2.p,
                                (const float*)W.c3b.p, (const uint16_t*)W.c4w_h2.p, (const float*)W.c4b.p, p4, 1.f / H2_WSCALE, d_nonfinite);
         } else {
             {
