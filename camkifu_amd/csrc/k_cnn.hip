@@ -118,6 +118,9 @@ __device__ unsigned long long g_h2_prof[8];
 #ifndef H2C34_MINW
 #define H2C34_MINW 2      // minimum waves per SIMD asked of the compiler for that kernel
 #endif
+#ifndef H2_C1_U
+#define H2_C1_U 1         // tiles of the fused conv1 a wave keeps in flight at once (2 and 3 measured the same: the phase is short of issue slots, not of independent work)
+#endif
 #ifndef H2C2S_WM
 #define H2C2S_WM 8       // waves per conv2 workgroup along the pixel tiles: R = H2C2S_TB / H2C2S_WM tiles per wave
 #endif
@@ -740,39 +743,52 @@ __device__ __forceinline__ void conv_h2_body(
         const int ntile1 = row_cnt * W / 16;                 // 36 or 27 tiles of 16 conv1 pixels
         constexpr int NW = NTHREADS / 64, R1 = cdiv(ROWS * W / 16, NW);
         float big = 0.f;
+        // U tiles of a wave in flight at once, their operations interleaved in program order (the compiler keeps it):
+        // one tile is a chain of dependent steps -- five LDS dwords per k-step, funnel shifts, 12 MFMAs in two chains,
+        // bias / relu / split, stores -- that takes ~1 us next to the other workgroup's k-loop, and a wave has 4 or 5.
+        auto conv1_tiles = [&](auto u_tag, int t_first) {
+            constexpr int U = decltype(u_tag)::value;
+            int a0[U], my[U], mx[U];
+            uint32_t ash[U];
+            f32x4 c1[U][2];
 #pragma unroll
-        for (int r = 0; r < (H2_DBG_SKIP == 2 ? 0 : R1); r++) {
-            const int tile = wave + NW * r;
-            if (tile < ntile1) {
-                const int m = tile * 16 + l15, my = m / W, mx = m % W;
-                const int a0 = (my + (kq >> 1)) * IRS + mx * 3 + 8 * (kq & 1);
-                const uint32_t ash = (uint32_t)(a0 & 1) << 4;
-                f32x4 c1[2];
+            for (int u = 0; u < U; u++) {
+                const int m = (t_first + NW * u) * 16 + l15;
+                my[u] = m / W; mx[u] = m % W;
+                a0[u] = (my[u] + (kq >> 1)) * IRS + mx[u] * 3 + 8 * (kq & 1);
+                ash[u] = (uint32_t)(a0[u] & 1) << 4;
 #pragma unroll
                 for (int n = 0; n < 2; n++)
 #pragma unroll
-                    for (int e = 0; e < 4; e++) c1[n][e] = 0.f;
+                    for (int e = 0; e < 4; e++) c1[u][n][e] = 0.f;
+            }
 #pragma unroll
-                for (int sx = 0; sx < 3; sx++) {
+            for (int sx = 0; sx < 3; sx++) {
+                h8 a[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
                     // 8 halves from an odd or even half offset: five aligned dwords, funnel-shifted by 0 or 16 bits
-                    const uint32_t* aq = reinterpret_cast<const uint32_t*>(&in1[(a0 & ~1) + 2 * sx * IRS]);
+                    const uint32_t* aq = reinterpret_cast<const uint32_t*>(&in1[(a0[u] & ~1) + 2 * sx * IRS]);
                     const uint32_t d0 = aq[0], d1 = aq[1], d2 = aq[2], d3 = aq[3], d4 = aq[4];
-                    const uint4 au = make_uint4(__builtin_amdgcn_alignbit(d1, d0, ash), __builtin_amdgcn_alignbit(d2, d1, ash),
-                                                __builtin_amdgcn_alignbit(d3, d2, ash), __builtin_amdgcn_alignbit(d4, d3, ash));
-                    const h8 a = __builtin_bit_cast(h8, au);
-#pragma unroll
-                    for (int n = 0; n < 2; n++) {
-                        c1[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[sx][n][1], a, c1[n], 0, 0, 0);
-                        c1[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[sx][n][0], a, c1[n], 0, 0, 0);
-                    }
+                    const uint4 au = make_uint4(__builtin_amdgcn_alignbit(d1, d0, ash[u]), __builtin_amdgcn_alignbit(d2, d1, ash[u]),
+                                                __builtin_amdgcn_alignbit(d3, d2, ash[u]), __builtin_amdgcn_alignbit(d4, d3, ash[u]));
+                    a[u] = __builtin_bit_cast(h8, au);
                 }
-                // lane (pixel l15, kq) holds channels 16 n + 4 kq .. + 3: half a chunk of the pixel
-                const int sw = h2_swz(mx, my);
-                _Float16* px = &lds[my * RS + mx * PS + 4 * (kq & 1)];
 #pragma unroll
                 for (int n = 0; n < 2; n++) {
-                    float v[4] = {c1[n][0] * wscale_inv + bv1[n].x, c1[n][1] * wscale_inv + bv1[n].y,
-                                  c1[n][2] * wscale_inv + bv1[n].z, c1[n][3] * wscale_inv + bv1[n].w};
+#pragma unroll
+                    for (int u = 0; u < U; u++) c1[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[sx][n][1], a[u], c1[u][n], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < U; u++) c1[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[sx][n][0], a[u], c1[u][n], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    // lane (pixel l15, kq) holds channels 16 n + 4 kq .. + 3: half a chunk of the pixel
+                    float v[4] = {c1[u][n][0] * wscale_inv + bv1[n].x, c1[u][n][1] * wscale_inv + bv1[n].y,
+                                  c1[u][n][2] * wscale_inv + bv1[n].z, c1[u][n][3] * wscale_inv + bv1[n].w};
                     typedef _Float16 h4v __attribute__((ext_vector_type(4)));
                     h4v hi, lo;
 #pragma unroll
@@ -783,10 +799,18 @@ __device__ __forceinline__ void conv_h2_body(
                         split_h2(v[e], hh, ll);
                         hi[e] = hh; lo[e] = ll;
                     }
-                    const int c = 2 * n + (kq >> 1);
+                    const int sw = h2_swz(mx[u], my[u]), c = 2 * n + (kq >> 1);
+                    _Float16* px = &lds[my[u] * RS + mx[u] * PS + 4 * (kq & 1)];
                     *reinterpret_cast<h4v*>(px + ((c ^ sw) << 3)) = hi;
                     *reinterpret_cast<h4v*>(px + ((c ^ sw ^ 4) << 3)) = lo;
                 }
+        };
+        {
+            constexpr int U = H2_C1_U;
+            int r = 0;
+            if (H2_DBG_SKIP != 2) {
+                for (; r + U <= R1 && wave + NW * (r + U - 1) < ntile1; r += U) conv1_tiles(std::integral_constant<int, U>{}, wave + NW * r);
+                for (; r < R1 && wave + NW * r < ntile1; r++) conv1_tiles(std::integral_constant<int, 1>{}, wave + NW * r);
             }
         }
         if (overflow && !(big <= 65000.f)) *overflow = 1;
