@@ -167,6 +167,35 @@ def test_board_lines_random_edge_maps(ck, ora, density):
         _cmp_board(out[k], ghost[k], ora.board_lines(maps[k], hough_thresh=20))
 
 
+@pytest.mark.parametrize("h, w", [(37, 68), (61, 132), (90, 1000), (48, 1028), (33, 2052), (21, 4096)])
+def test_board_lines_run_table_widths(ck, ora, h, w):
+    """the run-table labelling (bit words of 64 pixels, rank prefix, 256-pixel steps per lane group) on widths that end
+    inside a word / inside a step / exactly on one, with strokes that touch the image frame (cleared: components may
+    split there), single pixels next to word boundaries and dense noise -- ghost image and line list bit for bit"""
+    rng = np.random.default_rng(h * 10007 + w)
+    maps = []
+    maps.append((rng.random((h, w)) < 0.35).astype(np.uint8) * 255)           # dense noise: many tiny runs per row
+    e = np.zeros((h, w), np.uint8)
+    e[h // 3, :] = 255                                                         # a stroke from frame to frame
+    e[:, w // 2] = 255
+    e[2:-2, 2] = e[2:-2, w - 3] = 255
+    e[2, 2:-2] = e[h - 3, 2:-2] = 255                                          # a box one pixel inside the cleared frame
+    maps.append(e)
+    e = np.zeros((h, w), np.uint8)
+    for x in (63, 64, 65, 127, 128, 255, 256, 257, w - 2, 1):                  # lone pixels around word / step boundaries
+        if 0 < x < w - 1:
+            e[1 + (x % (h - 2)), x] = 255
+    e[h // 2, 60:70] = 255
+    e[h // 2 + 2, max(1, w - 70):w - 1] = 255
+    maps.append(e)
+    for e in maps:
+        thr = max(12, min(h, w) // 3)
+        out, ghost = ck.board_lines(e, hough_thresh=thr, cap=4096, want_ghost=True)
+        ref = ora.board_lines(e, hough_thresh=thr)
+        assert ref["status"] <= 4096
+        _cmp_board(out[0], ghost, ref)
+
+
 def test_board_lines_edge_cases(ck, ora):
     z = np.zeros((20, 30), np.uint8)
     out = ck.board_lines(z)
