@@ -114,6 +114,20 @@ def test_canny_random(ck, ora, shape):
     assert e.any()
 
 
+@pytest.mark.parametrize("low, high", [(0, 0), (0, 255), (200, 100), (1, 2039), (2039, 2040), (2040, 2040), (5000, 6000)])
+def test_canny_threshold_extremes(ck, ora, low, high):
+    """the packed NMS kernel keeps ONE key per pixel (magnitude * 4 + channel tag) and tests `key > 4 low + 3`: thresholds
+    at the ends of the magnitude range (0 .. 2040 = 8 x 255), swapped, and beyond it; hard 0 / 255 texture so that the
+    largest magnitudes do occur, plus ties between channels (identical planes: the first channel must win)"""
+    rng = np.random.default_rng(low * 7 + high)
+    img = (rng.random((70, 133, 3)) < 0.5).astype(np.uint8) * 255
+    img[:, 60:] = img[:, 60:, :1]                                   # right part: three identical channels
+    img[20:40, 10:50] = rng.integers(0, 256, (20, 40, 3), dtype=np.uint8)
+    e, m = ck.canny(img, low, high, want_map=True)
+    e2, m2, _, _, _ = ora.canny(img, low, high, want_map=True)
+    assert np.array_equal(m, m2) and np.array_equal(e, e2)
+
+
 def test_board_edges_chain(ck, ora, synth):
     frames = np.stack([synth.scene(480, 640, seed=s)["frame"].numpy() for s in (1, 2, 3)])
     e = ck.board_edges(frames)
