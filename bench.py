@@ -352,6 +352,7 @@ def main():
             same = lazy.process_batch(frames, n_total) == requests
             k = max(4, args.steps // 2)
             dlz = timed(lazy, k, 2, frames)
+            lazy.close()
             extras["holdoff_aware"] = dict(value=round(n_total * k / dlz, 2), unit="frames/s", steps=k, same_game_record=bool(same),
                                            host_ms_per_step={kk: round(1e3 * v / k, 3) for kk, v in lazy.host_seconds.items()},
                                            board_records_computed_pct=round(100.0 * lazy.board.fetched / max(1, lazy.board.seen), 1),

@@ -329,6 +329,13 @@ class GpuCore:
         import threading
         self._turn, self._issued, self._served = threading.Condition(), 0, 0
 
+    def close(self):
+        """stop the lanes' threads (idempotent; contexts stay the caller's)"""
+        pools = {id(p): p for pair in self.pools for p in pair}
+        pools[id(self.bg_pool)] = self.bg_pool
+        for p in pools.values():
+            p.shutdown(wait=False)
+
     def ticket(self):
         """call in batch order (FastFilePipeline.submit does): the background model sees the batches in that order even
         when two of them are inside __call__ at once"""
@@ -460,6 +467,7 @@ class FastFilePipeline:
         # one rank -- a process group of one must exist -- so that the collective code path can be exercised on a box with
         # a single GPU (tests/test_gpu_multirank.py does, over RCCL)
         self.exchange = world > 1 or bool(force_exchange)
+        self._owns_compute = compute is None
         if compute is None:
             compute = GpuCore(lanes or [(ctx_board, ctx)], bg_ctx=ctx_bg, local_model=not self.exchange)
         self.compute = compute
@@ -638,6 +646,19 @@ class FastFilePipeline:
 
     def process_batch(self, my_frames, n_total):
         return self.finish(self.submit(my_frames, n_total))
+
+    def close(self):
+        """stop this pipeline's stage threads (and the GPU core's, when it was built here); idempotent"""
+        self._runner.shutdown(wait=False)
+        self._comm.shutdown(wait=False)
+        if self._owns_compute and hasattr(self.compute, "close"):
+            self.compute.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def _fold_board(self, full, frames=None):
         """ordered replay of the board finder on the gathered records of one batch (rank 0); with `frames` (hold-off-aware
