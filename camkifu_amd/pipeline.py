@@ -600,17 +600,27 @@ class FastFilePipeline:
         # ordered board fold (rank 0): it needs the records only, so the transform is known -- and on its way to the
         # other ranks -- before the background model's exchange starts
         t3 = time.perf_counter()
-        new = None
+        new, fold_error = None, None
         if self.rank == 0:
-            self._fold_board(full, t.frames if self.board_lazy else None)
-            new = self.board.mtx
+            try:
+                self._fold_board(full, t.frames if self.board_lazy else None)
+                new = self.board.mtx
+            except Exception as why:                           # e.g. the IndexError the reference raises on a 3-vertex hull
+                if not self.exchange:
+                    raise
+                fold_error = why                               # the other ranks are about to wait in the broadcast: tell them
         t4 = time.perf_counter()
         hs["fold_board"] += t4 - t3
         if self.exchange:
             wire = np.zeros(10)
-            if self.rank == 0 and new is not None:
+            if self.rank == 0 and fold_error is not None:
+                wire[0] = -1.0
+            elif self.rank == 0 and new is not None:
                 wire[0], wire[1:] = 1.0, np.asarray(new, np.float64).reshape(9)
             wire = self.group.broadcast_array(wire, 0)
+            if wire[0] < 0:                                    # every rank leaves the batch here, before the band exchange
+                self.errors.append(fold_error if fold_error is not None else RuntimeError("the board fold failed on rank 0"))
+                return full, None, self.mtx, True
             new = wire[1:].reshape(3, 3).copy() if wire[0] else None
             t5 = time.perf_counter()
             hs["bcast"] += t5 - t4
@@ -631,7 +641,7 @@ class FastFilePipeline:
         import time
         full, counts, new, failed = ticket.exchange.result()
         if failed:
-            raise RuntimeError("a rank failed in the GPU core of this batch: %s" % (self.errors[-1:] or "see its log"))
+            raise RuntimeError("a rank failed in this batch (GPU core, or the board fold on rank 0): %s" % (self.errors[-1:] or "see its log"))
         self.mtx = new
         t0 = time.perf_counter()
         emitted = None

@@ -273,7 +273,7 @@ def test_rank0_host_threads_stay_under_the_gpu_step_at_world_8(capsys):
     assert max(exchange_thread, ph["fold_stones"]) < 14.0, ph
 
 
-def _failing_rank(rank, world, port, q, bad_rank, n_total):
+def _failing_rank(rank, world, port, q, bad_rank, n_total, fold_fails=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -294,6 +294,15 @@ def _failing_rank(rank, world, port, q, bad_rank, n_total):
         pipe = pipeline.FastFilePipeline(H, W, ControllerHeadless(), rank=rank, world=world, compute=compute)
         a, b = pipe.band
         pipe.band_model = lambda band, rates: np.zeros((len(band), b - a, 19), np.int32)
+        if fold_fails and rank == 0:                        # the reference's own failure mode: an exception out of _detect
+            fold, batches = pipe._fold_board, [0]
+
+            def failing(full, frames=None):
+                batches[0] += 1
+                if batches[0] == 3:
+                    raise IndexError("corner hull has fewer than 4 vertices")
+                return fold(full, frames)
+            pipe._fold_board = failing
         outcome = []
         for k in range(4):
             try:
@@ -330,6 +339,29 @@ def test_a_failing_rank_makes_every_rank_raise_instead_of_hanging(bad_rank, n_to
         assert outcome[0] == outcome[1] == outcome[3] == "ok", (rank, outcome)
         assert outcome[2].startswith("raised: a rank failed"), (rank, outcome)
         assert has_mtx
+
+
+def test_a_board_fold_exception_on_rank_0_reaches_every_rank():
+    """rank 0 folds the board records between the record gather and the transform broadcast, while the other ranks
+    already wait in that broadcast: an exception there (the reference raises IndexError on a 3-vertex corner hull,
+    bf_auto.py:206) travels in the broadcast and every rank raises from finish() -- nobody is left in a collective"""
+    world = 3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_rank, args=(r, world, port, q, -1, 9, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, outcome, has_mtx in res:
+        assert outcome[0] == outcome[1] == outcome[3] == "ok", (rank, outcome)
+        assert outcome[2].startswith("raised: a rank failed"), (rank, outcome)
 
 
 def test_lazy_board_fold_equals_the_eager_one():
