@@ -11,8 +11,10 @@ library's ordered policy (corners -> transform, stones -> moves); the transform 
 Workload (BASELINE.json configs[2]): 1080p, 256-frame batches on one MI355X; with N GPUs ONE video is dealt to
 the ranks frame by frame (rank r holds frames r, r+N, ...), 256 frames per rank and step (weak scaling).
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run, one rank
-per GPU.  Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`, one rank per GPU; for N > 1 either launched by
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or, from the plain command,
+by this file itself (self_launch: N child processes started before anything touches the GPU).  Rank 0 prints ONE
+JSON line.
 """
 import argparse
 import json
@@ -170,6 +172,79 @@ def cv2_crosscheck(ctx, frames, M):
     return out
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` from the plain command: start the N ranks here (one process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment -- what torch.distributed.run would set), relay rank 0's JSON line and
+    exit non-zero if any rank did.  This parent never touches the GPU (no torch.cuda / HIP call before or after the
+    spawn); a rank that dies takes the others down with it instead of leaving them in a collective."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    share = max(1, host_threads() // n)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this pool
+        env.setdefault("OMP_NUM_THREADS", str(share))
+        # rank 0's stdout is the bench line; what the other ranks print goes to stderr so that stdout stays ONE line
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    import threading
+    relayed = []
+
+    def relay():
+        for line in procs[0].stdout:                             # stdout carries the bench line and nothing else:
+            dest = sys.stdout if line.lstrip().startswith("{") else sys.stderr    # library chatter (gloo's) goes to stderr
+            relayed.append(line)
+            dest.write(line)
+            dest.flush()
+    pump = threading.Thread(target=relay, daemon=True)
+    pump.start()
+    failed, deadline = None, None
+    while True:
+        codes = [p.poll() for p in procs]
+        if failed is None:
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed, deadline = bad[0], time.time() + 20.0   # the others may be stuck in a collective with the dead rank
+        if all(c is not None for c in codes):
+            break
+        if deadline is not None and time.time() > deadline:
+            for p in procs:                                      # exactly the processes started above
+                if p.poll() is None:
+                    p.kill()
+            deadline = time.time() + 60.0
+        time.sleep(0.05)
+    pump.join(timeout=10.0)
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %d exited with code %d\n" % failed)
+        return failed[1] if failed[1] > 0 else 1
+    return 0
+
+
+def launch_check(kind):
+    """--launch-check: what a rank does when only the launcher is under test (no GPU needed): join a gloo group, add up
+    the ranks, rank 0 prints one JSON line; `fail:R` makes rank R exit with code 3 before the group forms"""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if kind.startswith("fail:") and rank == int(kind[5:]):
+        raise SystemExit(3)
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
+    t = torch.tensor([rank + 1.0])
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "local_rank": int(os.environ["LOCAL_RANK"]), "sum": float(t.item())}))
+    else:
+        print("rank %d of %d is up" % (rank, world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,7 +274,14 @@ def main():
     ap.add_argument("--lanes", type=int, default=2,
                     help="pairs of (board, stones) contexts per GPU; the batch is split between them so more "
                          "kernels are in flight and drain / host gaps of one lane are filled by the others")
+    ap.add_argument("--launch-check", default=None, metavar="ok|fail:R",
+                    help="test the N-rank launcher alone (gloo, no GPU): every rank joins a group and rank 0 prints one line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # the plain command: be the launcher (before any GPU call)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if args.launch_check:
+        return launch_check(args.launch_check)
 
     import numpy as np
     import torch
@@ -209,7 +291,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -324,7 +406,7 @@ def main():
         if rank == 0:
             print(json.dumps({"timed_only": True, "value": round((world if args.streams else 1) * n_total * args.steps / dt, 2),
                               "ms_per_step": round(1e3 * dt / args.steps, 3), "frames_per_launch": F // len(lanes)}))
-        if world > 1:
+        if world > 1 or args.force_exchange:
             dist.barrier()
             dist.destroy_process_group()
         return

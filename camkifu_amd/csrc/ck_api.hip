@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <vector>
 #include <thread>
+#include <chrono>
 
 #include "ck_common.h"
 #include "ck_stonegeom.h"
@@ -197,6 +198,19 @@ int ck_ctx_create(int device, ck_ctx** out)
 void ck_ctx_destroy(ck_ctx* ctx)
 {
     if (!ctx) return;
+    // A thread still inside an entry point owns the stream and the scratch buffers: freeing them under it would be a
+    // use-after-free.  Wait for it to leave (a call is milliseconds); a context that stays busy is leaked, and said so.
+    unsigned long long nobody = 0;
+    const unsigned long long me = ck_thread_token();
+    for (int spin = 0; !ctx->owner.compare_exchange_strong(nobody, me, std::memory_order_acq_rel); spin++) {
+        if (nobody == me) break;                     // destroyed from inside one of its own calls: nothing to wait for
+        if (spin >= 5000) {
+            fprintf(stderr, "ck_ctx_destroy: context %p is still in use by another thread after 5 s; not freed\n", (void*)ctx);
+            return;
+        }
+        nobody = 0;
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = { &ctx->in_stage, &ctx->in_stage2, &ctx->planes, &ctx->edges, &ctx->map, &ctx->labels,

@@ -132,6 +132,14 @@ struct CtxCall {
             return;
         }
         ctx->depth = 1;
+        // the HIP device is per-thread state: whichever host thread drives this context now (a lane's worker, the
+        // exchange thread of rank r > 0 ...) works on the context's device from here on
+        if (hipSetDevice(ctx->device) != hipSuccess) {
+            ctx->depth = 0;
+            ctx->owner.store(0, std::memory_order_release);
+            code = CK_ERR_HIP;
+            ctx = nullptr;
+        }
     }
     ~CtxCall()
     {

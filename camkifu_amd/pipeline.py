@@ -128,6 +128,30 @@ class _Group:
         return list(torch.split(recv, [int(r) for r in recv_sizes]))
 
 
+def _on_device(device):
+    """initializer of every worker thread of the pipeline: torch's current device is per-thread state and starts at
+    device 0 in a new thread -- on rank r > 0 a worker would otherwise allocate, copy and synchronise on GPU 0"""
+    if device is None:
+        return None
+
+    def init():
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.set_device(device)
+    return init
+
+
+def _pool(workers, device):
+    from concurrent.futures import ThreadPoolExecutor
+    init = _on_device(device)
+    return ThreadPoolExecutor(workers, initializer=init) if init else ThreadPoolExecutor(workers)
+
+
+def _device_of(ctx):
+    """the GPU index of a real context, None for the stand-ins the CPU tests use"""
+    return ctx.device if isinstance(ctx, capi.Context) else None
+
+
 def _take(frames, indices):
     """the frames with those indices, contiguous (a slice when they are consecutive)"""
     if len(indices) and indices[-1] - indices[0] + 1 == len(indices):
@@ -297,11 +321,12 @@ class GpuCore:
     world > 1 the goban tensor is handed back for the pixel-sharded exchange instead."""
 
     def __init__(self, lanes, bg_ctx=None, local_model=True):
-        from concurrent.futures import ThreadPoolExecutor
         # A context belongs to ONE thread (the library refuses a second one: CK_ERR_STATE).  A lane given without a board
         # context, or a core given without a model context, gets one of its own when the stones context is a real
         # capi.Context; with stand-in contexts (tests) the orphan work shares the stones context AND its thread.
         self.lanes, self.pools = [], []
+        self.device = dev = next((_device_of(c) for pair in lanes for c in pair if _device_of(c) is not None), None)
+        ThreadPoolExecutor = lambda k: _pool(k, dev)         # noqa: E731  every worker thread starts on this GPU
         for b, s in lanes:
             ps = ThreadPoolExecutor(1)
             if b is None and isinstance(s, capi.Context):
@@ -329,12 +354,13 @@ class GpuCore:
         import threading
         self._turn, self._issued, self._served = threading.Condition(), 0, 0
 
-    def close(self):
-        """stop the lanes' threads (idempotent; contexts stay the caller's)"""
+    def close(self, wait=True):
+        """stop the lanes' threads (idempotent; contexts stay the caller's).  By default this returns only when every
+        queued call has left its context: the caller may close the contexts right after."""
         pools = {id(p): p for pair in self.pools for p in pair}
         pools[id(self.bg_pool)] = self.bg_pool
         for p in pools.values():
-            p.shutdown(wait=False)
+            p.shutdown(wait=wait)
 
     def ticket(self):
         """call in batch order (FastFilePipeline.submit does): the background model sees the batches in that order even
@@ -425,6 +451,10 @@ class GpuCore:
         return self.bg_ctx.mog2_band_run(self._handle, gobans, rates, last_band=True)
 
 
+class _BandExchangeBroken(RuntimeError):
+    """this rank could not take part in the band all-to-all at all (not even with blank bands)"""
+
+
 class _Ticket:
     """one batch on its way through the stages: GPU core -> exchange (records, transform, bands, counts) -> stones fold"""
     __slots__ = ("core", "exchange", "mtx", "rates", "n_total", "frames", "have_mtx")
@@ -457,7 +487,6 @@ class FastFilePipeline:
 
     def __init__(self, h, w, controller, ctx=None, rank=0, world=1, device=None, compute=None, ctx_board=None,
                  bg_init_frames=50, band_model=None, lanes=None, ctx_bg=None, board_lazy=False, force_exchange=False):
-        from concurrent.futures import ThreadPoolExecutor
         self.h, self.w = h, w
         self.rank, self.world = rank, world
         self.group = _Group(rank, world, device)
@@ -471,8 +500,17 @@ class FastFilePipeline:
         if compute is None:
             compute = GpuCore(lanes or [(ctx_board, ctx)], bg_ctx=ctx_bg, local_model=not self.exchange)
         self.compute = compute
-        self._runner = ThreadPoolExecutor(2)                  # two batches may be inside the GPU core at once
-        self._comm = ThreadPoolExecutor(1)                    # stage 2: every collective of this rank, in batch order
+        gpu = getattr(compute, "device", None)
+        if gpu is None:
+            gpu = next((_device_of(c) for c in (ctx, ctx_board, ctx_bg) if _device_of(c) is not None), None)
+        self.gpu = gpu
+        self._runner = _pool(2, gpu)                          # two batches may be inside the GPU core at once
+        self._comm = _pool(1, gpu)                            # stage 2: every collective of this rank, in batch order
+        # The exchange thread's torch work (band slicing, the scatter into `full`, waiting for the collectives) goes on a
+        # stream of ITS OWN: the lanes' threads synchronise torch's DEFAULT stream before they hand a tensor to the library
+        # (capi._in), so anything this thread queued there -- i.e. a wait for an all-to-all that completes when the SLOWEST
+        # rank has joined -- would gate every board / warp / classifier call of the next batch.
+        self._xstream = None
         self.board = BoardFold(h, w)
         self.stones = StonesFold(controller, bg_init_frames)
         self.bg_init_frames, self.stone_frames = bg_init_frames, 0      # frames the stones path has been given (every rank counts)
@@ -505,7 +543,23 @@ class FastFilePipeline:
             gobans = gobans.to(self.group.device)                 # gloo rehearsal: collectives on host buffers
         lo, hi = px[self.rank]
         expect = [len(shard_indices(n_total, src, self.world)) * (hi - lo) * 380 * 3 for src in range(self.world)]
-        parts = self.group.all_to_all_bands([gobans[:, a:b].contiguous() for a, b in px], expect)
+        n_mine = len(shard_indices(n_total, self.rank, self.world))
+        late = None
+        try:
+            if len(gobans) != n_mine:
+                raise RuntimeError("the GPU core handed back %d goban images for a shard of %d frames" % (len(gobans), n_mine))
+            if gobans.is_cuda and torch.cuda.current_stream(gobans.device) != torch.cuda.default_stream(gobans.device):
+                gobans.record_stream(torch.cuda.current_stream(gobans.device))
+            send = [gobans[:, a:b].contiguous() for a, b in px]
+        except Exception as why:                                  # the peers are about to wait in the all-to-all: join it
+            late = why                                            # with blank bands of the right sizes, fail afterwards
+            try:
+                send = [torch.zeros((n_mine, b - a, 380, 3), dtype=torch.uint8, device=self.group.device or "cpu") for a, b in px]
+            except Exception as worse:
+                raise _BandExchangeBroken("%s (and no memory for blank bands: %s)" % (why, worse))
+        parts = self.group.all_to_all_bands(send, expect)
+        if late is not None:
+            raise late
         full = torch.empty((n_total, hi - lo, 380, 3), dtype=torch.uint8, device=parts[0].device)
         for src, part in enumerate(parts):                        # frame f of the batch came from rank f mod world
             full[src::self.world] = part.reshape(-1, hi - lo, 380, 3)
@@ -565,8 +619,22 @@ class FastFilePipeline:
         return t
 
     def _exchange(self, t):
-        """stage 2 (this rank's exchange thread) -> (records of the whole batch, counts or None, transform after this
-        batch, failure seen by any rank)"""
+        """stage 2 on this rank's exchange thread, with that thread's own torch stream current (see __init__)"""
+        if self.gpu is None or not self.exchange:
+            return self._exchange_on_stream(t)
+        import torch
+        if not torch.cuda.is_available():
+            return self._exchange_on_stream(t)
+        if self._xstream is None:
+            self._xstream = torch.cuda.Stream(device=self.gpu)
+        with torch.cuda.stream(self._xstream):
+            try:
+                return self._exchange_on_stream(t)
+            finally:
+                self._xstream.synchronize()                   # nothing of this batch is left queued behind the thread
+
+    def _exchange_on_stream(self, t):
+        """-> (records of the whole batch, counts or None, transform after this batch, failure seen by any rank)"""
         import time
         hs = self.host_seconds
         (board, rl, rc, fg, gobans), failure = t.core.result()
@@ -625,14 +693,29 @@ class FastFilePipeline:
             t5 = time.perf_counter()
             hs["bcast"] += t5 - t4
             if t.have_mtx:
-                mine_counts = self._band_counts(gobans, n_total, t.rates)                # (n_total, rows, 19)
-                t6 = time.perf_counter()
+                # A rank whose band model fails (a library error, out of memory for the band tensor ...) must not leave
+                # the others waiting: it still joins the counts gather, with a header row that says so, and every rank
+                # leaves the batch together.
                 widest = max(b - a for a, b in band_rows(self.world))
-                slab = np.zeros((1, n_total, widest, gsize), np.int32)
-                slab[0, :, :mine_counts.shape[1]] = mine_counts
-                allc = self.group.all_gather_rows(slab, 1)[:, 0]                         # (world, n_total, widest, 19)
-                counts = np.concatenate([allc[r, :, :b - a] for r, (a, b) in enumerate(band_rows(self.world))], 1)
+                slab = np.zeros((1, n_total + 1, widest, gsize), np.int32)               # row 0: header (-1 = failed)
+                band_error = None
+                try:
+                    mine_counts = self._band_counts(gobans, n_total, t.rates)            # (n_total, rows, 19)
+                    slab[0, 1:, :mine_counts.shape[1]] = mine_counts
+                except _BandExchangeBroken:
+                    raise                                     # could not even join the all-to-all: nothing left to keep in step
+                except Exception as why:
+                    band_error = why
+                    slab[0, 0] = -1
+                t6 = time.perf_counter()
+                allc = self.group.all_gather_rows(slab, 1)[:, 0]                         # (world, 1 + n_total, widest, 19)
                 hs["counts_gather"] += time.perf_counter() - t6
+                if (allc[:, 0] < 0).any():
+                    bad = [int(r) for r in np.nonzero((allc[:, 0] < 0).any(axis=(1, 2)))[0]]
+                    self.errors.append(band_error if band_error is not None
+                                       else RuntimeError("the background model's band failed on rank(s) %s" % bad))
+                    return full, None, self.mtx, True
+                counts = np.concatenate([allc[r, 1:, :b - a] for r, (a, b) in enumerate(band_rows(self.world))], 1)
         return full, counts, new, False
 
     def finish(self, ticket):
@@ -641,7 +724,8 @@ class FastFilePipeline:
         import time
         full, counts, new, failed = ticket.exchange.result()
         if failed:
-            raise RuntimeError("a rank failed in this batch (GPU core, or the board fold on rank 0): %s" % (self.errors[-1:] or "see its log"))
+            raise RuntimeError("a rank failed in this batch (GPU core, the board fold on rank 0, or a band of the background "
+                               "model): %s" % (self.errors[-1:] or "see its log"))
         self.mtx = new
         t0 = time.perf_counter()
         emitted = None
@@ -657,12 +741,13 @@ class FastFilePipeline:
     def process_batch(self, my_frames, n_total):
         return self.finish(self.submit(my_frames, n_total))
 
-    def close(self):
-        """stop this pipeline's stage threads (and the GPU core's, when it was built here); idempotent"""
-        self._runner.shutdown(wait=False)
-        self._comm.shutdown(wait=False)
+    def close(self, wait=True):
+        """stop this pipeline's stage threads (and the GPU core's, when it was built here); idempotent.  By default it
+        returns only when the batches in flight have left the contexts, so that the caller may close those next."""
+        self._runner.shutdown(wait=wait)
+        self._comm.shutdown(wait=wait)
         if self._owns_compute and hasattr(self.compute, "close"):
-            self.compute.close()
+            self.compute.close(wait)
 
     def __enter__(self):
         return self

@@ -166,3 +166,70 @@ def test_a_second_thread_on_a_context_is_refused():
     assert refused and "in use by another thread" in refused[0], refused
     assert np.array_equal(np.asarray(ctx.median15(small)), small)                 # and the context is fine afterwards
     ctx.close()
+
+
+def _bench(*extra, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(extra), env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_from_the_plain_command_with_two_ranks():
+    """`python bench.py --gpus 2 ...` with no external launcher starts its two ranks itself (before
+    anything touches the GPU), each with its own RANK / LOCAL_RANK, and prints rank 0's ONE line.  On a one-GPU box the
+    ranks share cuda:0 and talk over gloo (two RCCL ranks cannot share a device); frames are dealt 0, 2, 4 ... / 1, 3, 5 ...
+    and the fold's game record must be the true one."""
+    out = _bench("--gpus", "2", "--dist-backend", "gloo", "--single-device", "--frames", "128", "--steps", "2", "--warmup", "1",
+                 "--no-extras", "--no-cpu-baseline")
+    assert out["n_gpus"] == 2 and out["config"]["frames_per_gpu"] == 128
+    assert out["value"] > 0 and out["board_found_by_fold"] is True
+    assert out["move_sequence_ratio"] == 1.0 and out["stone_grid_match_pct"] == 100.0
+    assert out["host_ms_per_step"]["band_exchange"] > 0          # the pixel-sharded background model did exchange bands
+
+
+@pytest.mark.gpu
+def test_the_exchange_stage_does_not_gate_the_lanes():
+    """The exchange thread's torch work and its waits for the collectives sit on that thread's OWN stream, so the lanes'
+    default-stream synchronisation (capi._in) never waits for an all-to-all: with the whole exchange stage issued over
+    RCCL (one rank) the job runs as fast as without it, within the run-to-run noise of one box.  Best of three each,
+    interleaved."""
+    args = ["--frames", "256", "--steps", "12", "--warmup", "2", "--timed-only"]
+    plain, forced = [], []
+    for _ in range(3):
+        plain.append(_bench(*args)["value"])
+        forced.append(_bench(*args, "--force-exchange")["value"])
+    ratio = max(forced) / max(plain)
+    print("\n  frames/s plain %s, with the exchange stage over RCCL %s: ratio of the best %.4f" % (plain, forced, ratio), end="")
+    assert ratio > 0.97, (plain, forced)
+
+
+@pytest.mark.gpu
+def test_closing_the_pipeline_then_the_contexts_with_a_batch_in_flight():
+    """close() waits for the batches in flight, and ck_ctx_destroy waits for a thread still inside a call --
+    the with-statement pattern (close the pipeline, drop the contexts) cannot free a stream under a lane's thread"""
+    import torch
+    from camkifu_amd import capi, pipeline, synth
+    from camkifu_amd.controller import ControllerHeadless
+    frames = synth.film(32, H, W, seed=5, quiet=8, move_every=30, hand_frames=12)[0].cuda()
+    lanes = [(capi.Context(0), capi.Context(0)) for _ in range(2)]
+    bg = capi.Context(0)
+    with pipeline.FastFilePipeline(H, W, ControllerHeadless(), lanes=lanes, ctx_bg=bg) as pipe:
+        pipe.submit(frames, 32)                       # never finished by the caller
+        pipe.submit(frames, 32)
+    for pair in lanes:
+        for c in pair:
+            c.close()
+    bg.close()
+    torch.cuda.synchronize()
+    c = capi.Context(0)
+    assert np.array_equal(np.asarray(c.median15(np.zeros((16, 16, 3), np.uint8))), np.zeros((16, 16, 3), np.uint8))
+    c.close()

@@ -273,7 +273,7 @@ def test_rank0_host_threads_stay_under_the_gpu_step_at_world_8(capsys):
     assert max(exchange_thread, ph["fold_stones"]) < 14.0, ph
 
 
-def _failing_rank(rank, world, port, q, bad_rank, n_total, fold_fails=False):
+def _failing_rank(rank, world, port, q, bad_rank, n_total, fold_fails=False, band_fails=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -287,13 +287,22 @@ def _failing_rank(rank, world, port, q, bad_rank, n_total, fold_fails=False):
 
         def compute(frames, mtx, rates):
             calls[0] += 1
-            if rank == bad_rank and calls[0] == 3:
+            if rank == bad_rank and calls[0] == 3 and band_fails is None:
                 raise capi.CkError("libck_hip error 2: injected")
             gob = None if mtx is None else np.zeros((len(mine), 380, 380, 3), np.uint8)
+            if rank == bad_rank and calls[0] == 3 and band_fails == "before the all-to-all":
+                gob = gob[:-1]                                # a shard short of one goban image: the send sizes are wrong
             return (res, lines), np.zeros((len(mine), 10, 10), np.uint8), np.full((len(mine), 10, 10), 0.9), None, gob
         pipe = pipeline.FastFilePipeline(H, W, ControllerHeadless(), rank=rank, world=world, compute=compute)
         a, b = pipe.band
-        pipe.band_model = lambda band, rates: np.zeros((len(band), b - a, 19), np.int32)
+        band_calls = [0]
+
+        def band_model(band, rates):
+            band_calls[0] += 1
+            if rank == bad_rank and band_calls[0] == 2 and band_fails == "in the model":      # batch 3 = the 2nd with a transform
+                raise capi.CkError("libck_hip error 2: injected into the band model")
+            return np.zeros((len(band), b - a, 19), np.int32)
+        pipe.band_model = band_model
         if fold_fails and rank == 0:                        # the reference's own failure mode: an exception out of _detect
             fold, batches = pipe._fold_board, [0]
 
@@ -329,6 +338,32 @@ def test_a_failing_rank_makes_every_rank_raise_instead_of_hanging(bad_rank, n_to
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_failing_rank, args=(r, world, port, q, bad_rank, n_total)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, outcome, has_mtx in res:
+        assert outcome[0] == outcome[1] == outcome[3] == "ok", (rank, outcome)
+        assert outcome[2].startswith("raised: a rank failed"), (rank, outcome)
+        assert has_mtx
+
+
+@pytest.mark.parametrize("where", ["in the model", "before the all-to-all"])
+def test_a_band_model_failure_on_one_rank_reaches_every_rank(where):
+    """the pixel-sharded background model runs AFTER the record gather's failure flags, inside the exchange
+    stage: a rank whose band fails (a library error in ck_mog2_band_run, no memory for the band tensor, a shard of the
+    wrong size) still joins the band all-to-all (with blank bands if need be) and the counts gather, whose header row
+    says so: every rank raises from finish(), nobody waits for a collective, the next batch goes through."""
+    world = 3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_rank, args=(r, world, port, q, 1, 9, False, where)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(world))
