@@ -225,6 +225,21 @@ def self_launch(n, argv):
     return 0
 
 
+class stdout_to_stderr:
+    """libraries that greet on the C-level stdout (RCCL prints a version banner when its first communicator comes up)
+    must not add lines to the ONE line this program prints: file descriptor 1 points at stderr meanwhile"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def launch_check(kind):
     """--launch-check: what a rank does when only the launcher is under test (no GPU needed): join a gloo group, add up
     the ranks, rank 0 prints one JSON line; `fail:R` makes rank R exit with code 3 before the group forms"""
@@ -297,18 +312,21 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")      # where collective buffers live
-    if world > 1:
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.dist_backend)
-    elif args.force_exchange:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        else:
-            dist.init_process_group(args.dist_backend, rank=0, world_size=1)
+    with stdout_to_stderr():
+        if world > 1:
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(args.dist_backend)
+        elif args.force_exchange:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            else:
+                dist.init_process_group(args.dist_backend, rank=0, world_size=1)
+        if dist.is_initialized():
+            dist.barrier()                                     # the communicator (and its banner) comes up here, not later
 
     from camkifu_amd import capi, pipeline, synth
     from camkifu_amd.controller import ControllerHeadless
