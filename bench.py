@@ -423,7 +423,8 @@ def main():
         sync()
         if rank == 0:
             print(json.dumps({"timed_only": True, "value": round((world if args.streams else 1) * n_total * args.steps / dt, 2),
-                              "ms_per_step": round(1e3 * dt / args.steps, 3), "frames_per_launch": F // len(lanes)}))
+                              "ms_per_step": round(1e3 * dt / args.steps, 3), "frames_per_launch": F // len(lanes),
+                              "host_ms_per_step": host_ms}))
         if world > 1 or args.force_exchange:
             dist.barrier()
             dist.destroy_process_group()

@@ -27,7 +27,7 @@ EXPORTS = [
     "ck_median15", "ck_median", "ck_canny", "ck_goban_canny", "ck_board_edges", "ck_board_lines", "ck_board_detect",
     "ck_i420_to_bgr", "ck_get_perspective_transform", "ck_warp_perspective",
     "ck_mog2_create", "ck_mog2_apply", "ck_mog2_destroy",
-    "ck_cnn_set_weights", "ck_cnn_set_mode", "ck_cnn_predict", "ck_stones_detect",
+    "ck_cnn_set_weights", "ck_cnn_set_mode", "ck_cnn_predict", "ck_cnn_maps", "ck_stones_detect",
     "ck_cnn_regions", "ck_stones_run", "ck_zone_counts", "ck_mog2_band_run",
     "ck_contour_stones", "ck_contours_external", "ck_find_intersections", "ck_update_grid",
     "ck_ordered_hull", "ck_boardfold_create", "ck_boardfold_destroy", "ck_boardfold_reset", "ck_boardfold_step",
@@ -343,6 +343,18 @@ class Context:
         conf, cp, _ = self._out(goban, (n, 19, 19), np.float64)
         self._chk(lib().ck_cnn_predict(self._h, p, n, sp, yp, lp, cp, osp))
         return (y, labels, conf) if want_y else (labels, conf)
+
+    def cnn_maps(self, goban):
+        """the classifier's pooled filter maps as the context's mode computes them (host float32, channels-last):
+        (pool2 (n, 100, 16, 16, 32), pool4 (n, 100, 6, 6, 90)) -- the outputs of the two MaxPooling2D layers of
+        create_net (stone/nn_manager.py:280-292); n <= 128"""
+        shp = tuple(goban.shape)
+        n = 1 if len(shp) == 3 else shp[0]
+        p, sp, keep = _in(goban)
+        p2 = np.empty((n, 100, 16, 16, 32), np.float32)
+        p4 = np.empty((n, 100, 6, 6, 90), np.float32)
+        self._chk(lib().ck_cnn_maps(self._h, p, n, sp, p2.ctypes.data_as(C.c_void_p), p4.ctypes.data_as(C.c_void_p)))
+        return p2, p4
 
     def stones_detect(self, bgr, M):
         n, h, w = self._shape(bgr, 3)

@@ -580,6 +580,43 @@ int ck_cnn_predict(ck_ctx* ctx, const uint8_t* goban, int n, int in_space,
     CK_API_END(ctx)
 }
 
+int ck_cnn_maps(ck_ctx* ctx, const uint8_t* goban, int n, int in_space, float* pool2, float* pool4)
+{
+    CK_API_BEGIN(ctx)
+    if (!ctx) return CK_ERR_ARG;
+    if (!goban || n <= 0 || n > 128) return ck_fail(ctx, CK_ERR_ARG, "goban NULL or n outside 1 .. 128");
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, goban, (size_t)n * 380 * 380 * 3, in_space, ctx->in_stage, &d_in));
+    CK_TRY(cnn_predict_dev(ctx, (const uint8_t*)d_in, n, nullptr, nullptr, nullptr, CK_HOST));
+    CK_TRY(finish(ctx));
+    if (ctx->cnn_mode == CK_CNN_F16X2 && ctx->cnn_flag_host && *(volatile int*)ctx->cnn_flag_host)
+        return ck_fail(ctx, CK_ERR_STATE, "an activation left the fp16 range: the maps of this batch are the f32 chain's (set CK_CNN_FP32)");
+    // after one chunk the pooled conv2 output is still in act1 and the pooled conv4 output in act2 (k_cnn_predict)
+    const size_t np = (size_t)n * 100;
+    if (ctx->cnn_mode == CK_CNN_BF16) {
+        // bf16 activations, conv4's channels padded to 96: widened on the host
+        std::vector<uint16_t> raw;
+        auto widen = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+        if (pool2) {
+            raw.resize(np * 8192);
+            CK_HIP(ctx, hipMemcpy(raw.data(), ctx->act1.p, raw.size() * 2, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < raw.size(); i++) pool2[i] = widen(raw[i]);
+        }
+        if (pool4) {
+            raw.resize(np * 3456);
+            CK_HIP(ctx, hipMemcpy(raw.data(), ctx->act2.p, raw.size() * 2, hipMemcpyDeviceToHost));
+            for (size_t p = 0; p < np; p++)
+                for (int px = 0; px < 36; px++)
+                    for (int c = 0; c < 90; c++) pool4[(p * 36 + px) * 90 + c] = widen(raw[(p * 36 + px) * 96 + c]);
+        }
+        return CK_OK;
+    }
+    if (pool2) CK_HIP(ctx, hipMemcpy(pool2, ctx->act1.p, np * 8192 * sizeof(float), hipMemcpyDeviceToHost));
+    if (pool4) CK_HIP(ctx, hipMemcpy(pool4, ctx->act2.p, np * 3240 * sizeof(float), hipMemcpyDeviceToHost));
+    return CK_OK;
+    CK_API_END(ctx)
+}
+
 int ck_stones_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
                      const double* M, int m_count, uint8_t* labels, double* conf, int out_space)
 {

@@ -118,13 +118,20 @@ class _Group:
         return t.cpu().numpy()
 
     def all_to_all_bands(self, send_parts, recv_sizes):
-        """send_parts[d]: torch uint8 tensor for rank d; recv_sizes[s]: bytes rank s sends here (both sides can
-        work them out from the batch size) -> list of what every rank sent here"""
+        """send_parts[d]: torch uint8 tensor (any strides) for rank d; recv_sizes[s]: bytes rank s sends here (both sides
+        can work them out from the batch size) -> list of what every rank sent here.  Each part is copied ONCE, straight
+        into its slot of the send buffer."""
         import torch
         import torch.distributed as dist
-        send = torch.cat([p.reshape(-1) for p in send_parts])
+        sizes = [int(p.numel()) for p in send_parts]
+        send = torch.empty(sum(sizes), dtype=torch.uint8, device=send_parts[0].device)
+        at = 0
+        for p, k in zip(send_parts, sizes):
+            if k:
+                send[at:at + k].view(p.shape).copy_(p)
+            at += k
         recv = torch.empty(int(sum(recv_sizes)), dtype=torch.uint8, device=send.device)
-        dist.all_to_all_single(recv, send, [int(r) for r in recv_sizes], [int(p.numel()) for p in send_parts])
+        dist.all_to_all_single(recv, send, [int(r) for r in recv_sizes], sizes)
         return list(torch.split(recv, [int(r) for r in recv_sizes]))
 
 
@@ -550,7 +557,7 @@ class FastFilePipeline:
                 raise RuntimeError("the GPU core handed back %d goban images for a shard of %d frames" % (len(gobans), n_mine))
             if gobans.is_cuda and torch.cuda.current_stream(gobans.device) != torch.cuda.default_stream(gobans.device):
                 gobans.record_stream(torch.cuda.current_stream(gobans.device))
-            send = [gobans[:, a:b].contiguous() for a, b in px]
+            send = [gobans[:, a:b] for a, b in px]                 # strided views: copied once, into the send buffer
         except Exception as why:                                  # the peers are about to wait in the all-to-all: join it
             late = why                                            # with blank bands of the right sizes, fail afterwards
             try:
@@ -560,9 +567,12 @@ class FastFilePipeline:
         parts = self.group.all_to_all_bands(send, expect)
         if late is not None:
             raise late
-        full = torch.empty((n_total, hi - lo, 380, 3), dtype=torch.uint8, device=parts[0].device)
-        for src, part in enumerate(parts):                        # frame f of the batch came from rank f mod world
-            full[src::self.world] = part.reshape(-1, hi - lo, 380, 3)
+        if self.world == 1:
+            full = parts[0].reshape(n_total, hi - lo, 380, 3)     # one sender: already in frame order
+        else:
+            full = torch.empty((n_total, hi - lo, 380, 3), dtype=torch.uint8, device=parts[0].device)
+            for src, part in enumerate(parts):                    # frame f of the batch came from rank f mod world
+                full[src::self.world] = part.reshape(-1, hi - lo, 380, 3)
         if full.is_cuda:
             torch.cuda.current_stream(full.device).synchronize()
         t1 = time.perf_counter()
@@ -620,7 +630,8 @@ class FastFilePipeline:
 
     def _exchange(self, t):
         """stage 2 on this rank's exchange thread, with that thread's own torch stream current (see __init__)"""
-        if self.gpu is None or not self.exchange:
+        import os
+        if self.gpu is None or not self.exchange or os.environ.get("CK_EXCHANGE_DEFAULT_STREAM"):   # (developer A/B knob)
             return self._exchange_on_stream(t)
         import torch
         if not torch.cuda.is_available():

@@ -138,6 +138,13 @@ int ck_cnn_set_mode(ck_ctx* ctx, int mode);      /* CK_CNN_F16X2 (default): f32 
  * conf (n*361 doubles, max(y)/sum(y)) may be NULL. */
 int ck_cnn_predict(ck_ctx* ctx, const uint8_t* goban, int n, int in_space,
                    float* y, uint8_t* labels, double* conf, int out_space);
+/* The classifier's intermediate filter maps, for inspection and parity tests ("intermediate float filter maps within
+ * 1e-4"): what the network of create_net (nn_manager.py:280-295) holds after its two MaxPooling2D layers, as computed by
+ * the kernels of the context's mode, channels-last float32 in HOST memory:
+ *   pool2 (n*100*16*16*32): relu(conv2(relu(conv1(x)))) max-pooled 2x2   (nn_manager.py:281-286)
+ *   pool4 (n*100*6*6*90):   ... relu(conv4(relu(conv3(.)))) max-pooled 2x2 (nn_manager.py:287-292), the Flatten input
+ * Region order i*10+j as everywhere; either may be NULL; n <= 128 (one chunk of the classifier's frame loop). */
+int ck_cnn_maps(ck_ctx* ctx, const uint8_t* goban, int n, int in_space, float* pool2, float* pool4);
 
 /* ---- K8 + K10..K12: frame + M -> 19x19 labels   stonesfinder.py:140 + nn_cache.py:33-41 */
 int ck_stones_detect(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,

@@ -124,6 +124,11 @@ void ora_cnn_predict_regions(const ora_cnn_weights* W, const uint8_t* goban,
 /* patches: n x 40 x 40 x 3 u8 -> y n x 81 */
 void ora_cnn_forward(const ora_cnn_weights* W, const uint8_t* patches, int n,
                      float* y_out, float* logits_out);
+/* the same, plus (optionally) the outputs of the two MaxPooling2D layers: pool2 n x 16 x 16 x 32, pool4 n x 6 x 6 x 90 */
+void ora_cnn_forward_maps(const ora_cnn_weights* W, const uint8_t* patches, int n,
+                          float* y_out, float* logits_out, float* pool2_out, float* pool4_out);
+/* the 100 region patches of a goban image (K10), region order i*10+j: 100 x 40 x 40 x 3 */
+void ora_cnn_region_patches(const uint8_t* goban, uint8_t* patches);
 /* NNCache.predict_all_stones: labels 19x19 u8 {0=E,1=B,2=W}, conf 19x19 double */
 void ora_decode_all(const float* y /*100x81*/, uint8_t* labels, double* conf);
 

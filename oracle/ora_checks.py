@@ -1,106 +1,81 @@
-"""ORACLE (test infrastructure only): plain-loop restatement of the reference's consistency checks, statement for
-statement (/root/reference/src/camkifu/stone/stonesfinder.py:597-783, core/imgutil.py:360-379).  cv2.distanceTransform
-(DIST_C, 3x3 mask) is restated as the two-pass chamfer it is; nothing from the reference is imported."""
-import numpy as np
+"""ORACLE (test infrastructure only): the consistency checks of a stones finder, stated from what each one MEANS and
+answered by brute force over point sets -- a second, independent reading of
+/root/reference/src/camkifu/stone/stonesfinder.py:597-783, not a walk through its control flow, and sharing no
+formulation with the product's whole-array code (camkifu_amd/stone/checks.py).
+
+    check_against        of the points where the goban already holds a stone, which fraction does the candidate agree on?
+    check_lines          of the zones in which a grid line was seen, which fraction does the candidate leave empty?
+    check_thickness      is some stone more than two king's moves away from every point of another symbol?
+    check_flow           do the newly added stones of the two colours balance to within one?
+    first_line_lonelies  first-line stones with no stone of either array within two king's moves
+
+Distances are chessboard distances between points, looked up pairwise (no distance transform, no neighbourhood
+generator).  Nothing from the reference is imported."""
+from fractions import Fraction
 
 gsize, E, B, W = 19, 'E', 'B', 'W'
 
 
-def check_against(stones, reference, rs=0, re=gsize, cs=0, ce=gsize):          # :597-632
-    refs = matches = 0
-    for r in range(rs, re):
-        for c in range(cs, ce):
-            if reference[r, c] in (B, W):
-                refs += 1
-                if stones[r, c] == reference[r, c]:
-                    matches += 1
-    if 4 < refs:
-        return 1 if 0.81 < matches / refs else -1
-    return 0
+def _points(rs, re, cs, ce):
+    return [(r, c) for r in range(rs, re) for c in range(cs, ce)]
 
 
-def check_lines(stones, grid, rs=0, re=gsize, cs=0, ce=gsize):                  # :634-673 (grid = get_intersections(img))
-    lines = matches = 0
-    for r in range(rs, re):
-        for c in range(cs, ce):
-            if int(grid[r, c][0]) + int(grid[r, c][1]) < 0:
-                lines += 1
-                if stones[r, c] == E:
-                    matches += 1
-    if 4 < lines:
-        return 1 if 0.9 < matches / lines else -1
-    return 0
+def _king(p, q):
+    """moves a chess king needs from p to q"""
+    return max(abs(p[0] - q[0]), abs(p[1] - q[1]))
 
 
-def distance_c3(mask):
-    """cv2.distanceTransform(mask, cv2.DIST_C, 3): two-pass 3x3 chamfer with all weights 1 over an image padded by a
-    border of 'infinite' distance -- exact chessboard distance to the nearest zero pixel of the image"""
-    h, w = mask.shape
-    big = 10 ** 6
-    d = np.full((h + 2, w + 2), big, np.int64)
-    for y in range(h):
-        for x in range(w):
-            if mask[y, x] == 0:
-                d[y + 1, x + 1] = 0
-    for y in range(1, h + 1):
-        for x in range(1, w + 1):
-            if d[y, x]:
-                d[y, x] = min(d[y, x], d[y - 1, x - 1] + 1, d[y - 1, x] + 1, d[y - 1, x + 1] + 1, d[y, x - 1] + 1)
-    for y in range(h, 0, -1):
-        for x in range(w, 0, -1):
-            if d[y, x]:
-                d[y, x] = min(d[y, x], d[y + 1, x + 1] + 1, d[y + 1, x] + 1, d[y + 1, x - 1] + 1, d[y, x + 1] + 1)
-    return d[1:-1, 1:-1]
+def _verdict(good, total, needed, bar):
+    """-1 / 0 / 1: undetermined unless MORE than `needed` cases, passed when the share of good ones EXCEEDS `bar`
+    (exact rational comparison against the decimal the reference writes: 0.81, 0.9)"""
+    if total <= needed:
+        return 0
+    return 1 if Fraction(good, total) > Fraction(bar) else -1
 
 
-def check_thickness(stones, rs=0, re=gsize, cs=0, ce=gsize):                     # :675-700
+def check_against(stones, reference, rs=0, re=gsize, cs=0, ce=gsize):
+    occupied = {p for p in _points(rs, re, cs, ce) if reference[p] != E}
+    agreed = {p for p in occupied if stones[p] == reference[p]}
+    return _verdict(len(agreed), len(occupied), 4, "0.81")
+
+
+def check_lines(stones, grid, rs=0, re=gsize, cs=0, ce=gsize):
+    """grid = get_intersections(img): the two coordinates of a zone are negated where a line was found"""
+    with_line = {p for p in _points(rs, re, cs, ce) if int(grid[p][0]) + int(grid[p][1]) < 0}
+    left_empty = {p for p in with_line if stones[p] == E}
+    return _verdict(len(left_empty), len(with_line), 4, "0.9")
+
+
+def depth_inside_colour(stones, color, rs, re, cs, ce):
+    """for every point of the region holding `color`: king's moves to the nearest point OF THE REGION that holds
+    something else (None when the region holds nothing else: the array's edge is not 'something else')"""
+    pts = _points(rs, re, cs, ce)
+    others = [q for q in pts if stones[q] != color]
+    return {p: (min(_king(p, q) for q in others) if others else None) for p in pts if stones[p] == color}
+
+
+def check_thickness(stones, rs=0, re=gsize, cs=0, ce=gsize):
     for color in (B, W):
-        avatar = np.array([[1 if stones[r, c] == color else 0 for c in range(cs, ce)] for r in range(rs, re)], np.uint8)
-        if avatar.size and 2 < distance_c3(avatar.reshape((re - rs, ce - cs))).max():
+        depths = depth_inside_colour(stones, color, rs, re, cs, ce).values()
+        if any(d is None or d > 2 for d in depths):
             return -1
     return 0
 
 
-def check_flow(stones, is_empty, rs=0, re=gsize, cs=0, ce=gsize):               # :702-736 (is_empty(r, c) -> bool)
-    moves = []
-    for r in range(rs, re):
-        for c in range(cs, ce):
-            if is_empty(r, c) and stones[r, c] != E:
-                moves.append(stones[r, c])
-    diff = 0
-    for mv in moves:
-        diff += 1 if mv == B else -1
-    return 0 if abs(diff) <= 1 else -1
+def check_flow(stones, is_empty, rs=0, re=gsize, cs=0, ce=gsize):
+    """is_empty(r, c) -> bool: the goban's view.  Only stones put on empty points are new."""
+    new = [stones[p] for p in _points(rs, re, cs, ce) if stones[p] != E and is_empty(*p)]
+    return 0 if abs(new.count(B) - new.count(W)) <= 1 else -1
 
 
-def around(x, y, margin, xmin=None, xmax=None, ymin=None, ymax=None):            # imgutil.py:360-379
-    for i in range(-margin, margin + 1):
-        if (xmin is None or xmin <= x + i) and (xmax is None or x + i < xmax):
-            for j in range(-margin, margin + 1):
-                if i == j == 0:
-                    continue
-                if (ymin is None or ymin <= y + j) and (ymax is None or y + j < ymax):
-                    yield x + i, y + j
-
-
-def first_line_lonelies(stones, reference, rs=0, re=gsize, cs=0, ce=gsize):    # :738-783
-    pos = set()
-    for r in (rs, re):
-        if r in (0, gsize - 1):
-            for c in range(cs, ce):
-                pos.add((r, c))
-    for c in (cs, ce):
-        if c in (0, gsize - 1):
-            for r in range(rs, re):
-                pos.add((r, c))
-    lonelies = []
-    for (r, c) in pos:
-        if stones[r, c] in (B, W):
-            alone = True
-            for x, y in around(r, c, 2, xmin=0, xmax=gsize, ymin=0, ymax=gsize):
-                if reference[x, y] in (B, W) or stones[x, y] in (B, W):
-                    alone = False
-                    break
-            if alone:
-                lonelies.append((r, c))
-    return lonelies
+def first_line_lonelies(stones, reference, rs=0, re=gsize, cs=0, ce=gsize):
+    """The sides of the region that lie on the goban's first line -- where the reference tests the row INDICES rs and
+    re, and the column indices cs and ce, against 0 and 18 (re / ce being the exclusive ends: the far side only counts
+    for a region that stops at index 18).  On those sides, every stone of the candidate that has no stone, in the
+    candidate or on the goban, within two king's moves."""
+    board = _points(0, gsize, 0, gsize)
+    anything = [q for q in board if stones[q] != E or reference[q] != E]
+    side = {(r, c) for r in (rs, re) if r in (0, gsize - 1) for c in range(cs, ce)}
+    side |= {(r, c) for c in (cs, ce) if c in (0, gsize - 1) for r in range(rs, re)}
+    return [p for p in sorted(side)
+            if stones[p] != E and not any(q != p and _king(p, q) <= 2 for q in anything)]

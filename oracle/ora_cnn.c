@@ -68,6 +68,14 @@ static void dense(const float* in, int nin, const float* w, const float* b, int 
 void ora_cnn_forward(const ora_cnn_weights* Wt, const uint8_t* patches, int n,
                      float* y_out, float* logits_out)
 {
+    ora_cnn_forward_maps(Wt, patches, n, y_out, logits_out, 0, 0);
+}
+
+/* the same forward pass; optionally also the outputs of the two MaxPooling2D layers (nn_manager.py:286, 292):
+ * pool2_out n x 16 x 16 x 32, pool4_out n x 6 x 6 x 90, channels-last */
+void ora_cnn_forward_maps(const ora_cnn_weights* Wt, const uint8_t* patches, int n,
+                          float* y_out, float* logits_out, float* pool2_out, float* pool4_out)
+{
     /* patches are independent: OpenMP over patches (the CPU baseline uses every core) */
 #pragma omp parallel
     {
@@ -89,6 +97,8 @@ void ora_cnn_forward(const ora_cnn_weights* Wt, const uint8_t* patches, int n,
         conv_relu(p2, 16, 16, 32, Wt->c3w, Wt->c3b, 3, 3, 90, a3);
         conv_relu(a3, 14, 14, 90, Wt->c4w, Wt->c4b, 3, 3, 90, a4);
         maxpool2(a4, 12, 12, 90, p4);
+        if (pool2_out) memcpy(pool2_out + (size_t)p * 8192, p2, sizeof(float) * 8192);
+        if (pool4_out) memcpy(pool4_out + (size_t)p * 3240, p4, sizeof(float) * 3240);
         dense(p4, 3240, Wt->d1w, Wt->d1b, 160, h1);
         for (int i = 0; i < 160; i++) h1[i] = h1[i] > 0.f ? h1[i] : 0.f;
         dense(h1, 160, Wt->d2w, Wt->d2b, 81, lg);
@@ -107,10 +117,8 @@ void ora_cnn_forward(const ora_cnn_weights* Wt, const uint8_t* patches, int n,
  * region index i -> first pixel row 20*rs where rs = 2i, except i=9 -> rs=17 (340). */
 static int region_origin(int i) { int rs = 2 * i; if (19 - rs < 2) rs = 17; return 20 * rs; }
 
-void ora_cnn_predict_regions(const ora_cnn_weights* Wt, const uint8_t* goban,
-                             float* y_out, float* logits_out)
+void ora_cnn_region_patches(const uint8_t* goban, uint8_t* patches)
 {
-    uint8_t* patches = (uint8_t*)malloc(100 * 4800);
     for (int i = 0; i < 10; i++)
         for (int j = 0; j < 10; j++) {
             int x0 = region_origin(i), y0 = region_origin(j);   /* x = row, y = col in the reference's naming */
@@ -118,6 +126,13 @@ void ora_cnn_predict_regions(const ora_cnn_weights* Wt, const uint8_t* goban,
             for (int r = 0; r < 40; r++)
                 memcpy(dst + (size_t)r * 120, goban + ((size_t)(x0 + r) * 380 + y0) * 3, 120);
         }
+}
+
+void ora_cnn_predict_regions(const ora_cnn_weights* Wt, const uint8_t* goban,
+                             float* y_out, float* logits_out)
+{
+    uint8_t* patches = (uint8_t*)malloc(100 * 4800);
+    ora_cnn_region_patches(goban, patches);
     ora_cnn_forward(Wt, patches, 100, y_out, logits_out);
     free(patches);
 }

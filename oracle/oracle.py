@@ -267,6 +267,21 @@ def cnn_forward(weights, patches, want_logits=False):
     return (y, lg) if want_logits else y
 
 
+def cnn_region_maps(weights, goban):
+    """the 100 regions of a goban image through the network -> (y (100, 81), pool2 (100, 16, 16, 32), pool4 (100, 6, 6, 90)):
+    the softmax and the outputs of the two MaxPooling2D layers (nn_manager.py:286, 292)"""
+    goban = np.ascontiguousarray(goban, np.uint8)
+    assert goban.shape == (380, 380, 3)
+    s, keep = _wstruct(weights)
+    patches = np.zeros((100, 40, 40, 3), np.uint8)
+    lib().ora_cnn_region_patches(_vp(goban), _vp(patches))
+    y = np.zeros((100, 81), np.float32)
+    p2 = np.zeros((100, 16, 16, 32), np.float32)
+    p4 = np.zeros((100, 6, 6, 90), np.float32)
+    lib().ora_cnn_forward_maps(C.byref(s), _vp(patches), 100, _vp(y), None, _vp(p2), _vp(p4))
+    return y, p2, p4
+
+
 def cnn_predict_regions(weights, goban, want_logits=False):
     goban = np.ascontiguousarray(goban, np.uint8)
     assert goban.shape == (380, 380, 3)

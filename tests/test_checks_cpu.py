@@ -1,6 +1,8 @@
 """StonesFinder.check_against / check_lines / check_thickness / check_flow / first_line_lonelies
-(reference stone/stonesfinder.py:597-783): the vectorised forms in camkifu_amd/stone/checks.py against the plain-loop
-restatement oracle/ora_checks.py on random gobans and sub-regions, plus hand-checked cases at the decision boundaries."""
+(reference stone/stonesfinder.py:597-783): the whole-array forms in camkifu_amd/stone/checks.py against
+oracle/ora_checks.py -- each check stated from its meaning and answered by brute force over point sets (pairwise
+king's-move distances, exact rational thresholds), a reading independent of the reference's control flow -- on random
+gobans and sub-regions, plus hand-checked cases at the decision boundaries."""
 import numpy as np
 import pytest
 
@@ -49,16 +51,27 @@ def test_checks_equal_the_restatement_on_random_gobans(seed):
             assert sorted(checks.first_line_lonelies(st, ref, *region)) == sorted(ora.first_line_lonelies(st, ref, *region))
 
 
-def test_distance_restatement_is_the_chessboard_distance():
+def test_the_oracle_depth_is_the_chessboard_distance_transform():
+    """the oracle's pairwise king's-move depth against scipy's chamfer distance transform (chessboard metric) of the
+    colour mask -- an implementation neither the oracle nor the product shares; scipy treats the array edge as the
+    library does (never a zero)"""
+    from scipy import ndimage
     rng = np.random.default_rng(5)
     for _ in range(20):
-        m = (rng.random((9, 11)) < 0.8).astype(np.uint8)
-        if m.all():
-            m[4, 4] = 0
-        zy, zx = np.nonzero(m == 0)
-        yy, xx = np.mgrid[0:9, 0:11]
-        brute = np.min(np.maximum(np.abs(yy[..., None] - zy), np.abs(xx[..., None] - zx)), axis=-1)
-        assert np.array_equal(ora.distance_c3(m), brute)
+        g = np.full((19, 19), E, dtype=object)
+        g[rng.random((19, 19)) < 0.8] = B
+        if (g == B).all():
+            g[4, 4] = E
+        rs, re, cs, ce = _region(rng)
+        sub = (g[rs:re, cs:ce] == B)
+        depth = ora.depth_inside_colour(g, B, rs, re, cs, ce)
+        if sub.all():
+            assert all(d is None for d in depth.values())
+            continue
+        cdt = ndimage.distance_transform_cdt(sub, metric="chessboard")
+        assert len(depth) == int(sub.sum())
+        for (r, c), d in depth.items():
+            assert d == cdt[r - rs, c - cs]
 
 
 def test_boundaries_by_hand():

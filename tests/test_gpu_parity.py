@@ -798,6 +798,60 @@ def _torch_fp64_classifier(W, gobans):
     return y.numpy().reshape(len(gobans), 100, 81)
 
 
+def _torch_fp64_maps(W, gobans):
+    """float64 torch evaluation of the network up to its two MaxPooling2D layers (shares no code with the oracle)
+    -> (pool2 (n, 100, 16, 16, 32), pool4 (n, 100, 6, 6, 90)), channels-last"""
+    import torch
+    import torch.nn.functional as F
+    w = {k: torch.from_numpy(np.ascontiguousarray(v)).double() for k, v in W.items()}
+    org = [0, 40, 80, 120, 160, 200, 240, 280, 320, 340]
+    g = torch.from_numpy(gobans).permute(0, 3, 1, 2).double()
+    patches = torch.stack([g[:, :, a:a + 40, b:b + 40] for a in org for b in org], 1).reshape(-1, 3, 40, 40)
+    conv = lambda x, k, b: F.relu(F.conv2d(x, k.flip(0, 1).permute(3, 2, 0, 1).contiguous(), b))      # noqa: E731
+    x = F.max_pool2d(conv(conv(patches, w["c1w"], w["c1b"]), w["c2w"], w["c2b"]), 2)
+    p2 = x.permute(0, 2, 3, 1).reshape(len(gobans), 100, 16, 16, 32).numpy()
+    x = F.max_pool2d(conv(conv(x, w["c3w"], w["c3b"]), w["c4w"], w["c4b"]), 2)
+    return p2, x.permute(0, 2, 3, 1).reshape(len(gobans), 100, 6, 6, 90).numpy()
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "fp32", "bf16"])
+def test_cnn_filter_maps_below_the_softmax(ck, ora, synth, mode):
+    """north_star: "intermediate float filter maps within 1e-4".  The softmax saturates and hides operand error
+    (profiles/r01_cnn_precision.txt), a wrong tap, flip or padding shows first in the maps: the outputs of the two
+    MaxPooling2D layers of create_net (stone/nn_manager.py:280-292) as the HIP kernels compute them (ck_cnn_maps)
+    against the oracle's (oracle/ora_cnn.c) AND against a float64 torch evaluation, every element of all 100 regions
+    -- including the overlapping patches at origin 340 (regions 9, 19, ..., 90-99) -- within 1e-4 relative to the
+    map's scale; random weights and the trained ones.  bf16 (BASELINE config 5) is 8-bit operands by construction: its
+    maps are held to 3e-2."""
+    from camkifu_amd import capi
+    from camkifu_amd.stone.nn_manager import NNManager
+    sc = synth.scene(480, 640, seed=31, density=0.45)
+    dst = np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32)
+    goban = ora.warp_perspective(sc["frame"].numpy(), ora.get_perspective_transform(sc["corners"], dst))
+    gobans = np.stack([goban, np.random.default_rng(17).integers(0, 256, (380, 380, 3), dtype=np.uint8)])
+    tol = 3e-2 if mode == "bf16" else 1e-4
+    for name, W in (("random", synth.cnn_weights()), ("trained", NNManager.init_net())):
+        ck.cnn_set_weights(W)
+        ck.cnn_set_mode({"f16x2": capi.CK_CNN_F16X2, "fp32": capi.CK_CNN_FP32, "bf16": capi.CK_CNN_BF16}[mode])
+        try:
+            p2, p4 = ck.cnn_maps(gobans)
+        finally:
+            ck.cnn_set_mode(capi.CK_CNN_DEFAULT)
+        t2, t4 = _torch_fp64_maps(W, gobans)
+        for k in range(len(gobans)):
+            _, o2, o4 = ora.cnn_region_maps(W, gobans[k])
+            for what, got, want, ref64 in (("pool2", p2[k], o2, t2[k]), ("pool4", p4[k], o4, t4[k])):
+                scale = float(np.abs(ref64).max())
+                assert scale > 0.1, (name, what)                      # the maps are alive (relu has not killed them)
+                err_o = float(np.abs(got - want).max()) / scale
+                err_t = float(np.abs(got - ref64).max()) / scale
+                assert err_o <= tol and err_t <= tol, (mode, name, k, what, err_o, err_t)
+                # the regions at origin 340 overlap their neighbours at 320 by 20 pixels: same bar, looked at apart
+                edge = [r for r in range(100) if r % 10 == 9 or r >= 90]
+                assert float(np.abs(got[edge] - want[edge]).max()) / scale <= tol
+    ck.cnn_set_weights(synth.cnn_weights())
+
+
 @pytest.mark.parametrize("mode", ["f16x2", "fp32", "bf16"])
 def test_cnn_against_torch_fp64(ck, ora, synth, mode):
     """K11 pinned without the oracle: the HIP classifier against a float64 torch evaluation of the same network
