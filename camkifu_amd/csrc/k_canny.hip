@@ -14,8 +14,9 @@
 #include "ck_uf.h"
 
 #ifndef NMS_MFMA
-#define NMS_MFMA 1         // gradient phase on the fp16 matrix pipe (canny_nms_mfma_kernel); 0: packed 16-bit VALU math
-#endif
+#define NMS_MFMA 0         // 1: gradient phase on the fp16 matrix pipe (canny_nms_mfma_kernel) -- built and measured in round 4:
+#endif                     // 8.1 us per 1080p frame against the packed kernel's 5.5 (profiles/r04_nms_phases.txt)
+
 #ifndef NMS_LOCAL_UF
 #define NMS_LOCAL_UF 1     // tile-local union-find of the candidates inside the NMS kernel
 #endif
@@ -26,7 +27,7 @@ constexpr int TW = 64;
 constexpr int LWD = TW / 4 + 2;              // pixel tile dwords per row (4-px halo each side)
 
 // ------------------------------------------------------------------------------------------
-// Packed variant (-DNMS_MFMA=0; the matrix-pipe variant below is the one launched).  Same results.  The
+// Packed variant (the one launched; -DNMS_MFMA=1 builds the matrix-pipe variant below instead).  The
 // kernel is VALU-bound, so what counts is instructions per pixel (round 2: ~105 lane-ops per pixel, 60 of them in the
 // gradient phase; this version: see DESIGN.md 4):
 //   * gradient phase in packed 16-bit math (v_pk_*): a thread owns 4 adjacent columns as two u16 pairs and walks PK
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
         }
     }
     __syncthreads();
-    if (NMS_STOP == 1) return;
+    if (NMS_STOP == 1) { map[((size_t)f * h + (oy < h ? oy : 0)) * w + (tid % w)] = (uint8_t)smem[tid]; return; }
 
     if (tid < 17 * 15) {
         const int cj = tid % 17, seg = tid / 17;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
         }
     }
     __syncthreads();
-    if (NMS_STOP == 2) return;
+    if (NMS_STOP == 2) { map[((size_t)f * h + (oy < h ? oy : 0)) * w + (tid % w)] = (uint8_t)mag[tid % PGR][tid % PGW]; return; }   // (keeps the phases alive)
 
     // NMS: one thread = 4 consecutive pixels of one row (one dword of the map)
     const int TG22 = 13573;   // (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
@@ -372,8 +373,9 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
 
 
 // ------------------------------------------------------------------------------------------
-// Matrix-pipe variant (the one launched).  Same results as the packed kernel; the gradient phase -- 54 % of that
-// kernel's vector instructions -- becomes two chained band-matrix products per channel on v_mfma_f32_16x16x32_f16:
+// Matrix-pipe variant (-DNMS_MFMA=1; NOT the one launched: measured slower, see the end of this comment).  Same results
+// as the packed kernel; the gradient phase -- 54 % of that kernel's vector instructions -- becomes two chained band-matrix
+// products per channel on v_mfma_f32_16x16x32_f16:
 //
 //   stage 1 (horizontal):  T = P . Bh      P  = 16 pixel rows x 32 pixel columns as the A operand: a lane holds 8
 //                                          consecutive bytes of one row, each byte b as the exact half 0x6400 | b =
@@ -395,6 +397,17 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
 // packed kernel.  Tile: 80 x 28 output pixels per 192-thread workgroup = three blocks at pixel columns 0, 28, 56 of
 // the tile's LDS image (4-byte aligned rows; neighbouring blocks overlap by four columns and compute gradient columns
 // 29, 30 / 1, 2 twice, identically).
+//
+// Measured (MI355X, 1080p, 64-frame launches, cumulative time of builds that leave after each phase, us per frame):
+//                  staging   + gradient   + NMS   + tile union-find   whole kernel
+//   packed           2.04      3.58        4.42        5.05              5.55
+//   matrix pipe      1.79      3.98        5.35        6.80              8.10
+// The gradient phase itself is slower on the matrix pipe (2.19 against 1.54 us): 48 MFMAs of 16 cycles per 900 gradients
+// are 0.8 us of matrix-pipe time per frame, the conversions and keys around them (perm, cvt_pk, |dx| + |dy|, tag, max3:
+// ~190 vector instructions per block) another 0.9 us, and the two ADD UP -- inside one wave they are one dependent
+// chain, and with 122 registers per lane (32 of them the constant band operands) only 4 waves per SIMD are there to fill
+// the other pipe.  The same register footprint halves the occupancy of the latency-bound phases behind it (NMS, LDS
+// union-find, list output: 4.1 us against 2.0).
 constexpr int MTW = 80;                      // output columns per tile
 constexpr int MPLD = 28;                     // pixel tile dwords per row: 22 used (x = ox - 4 .. ox + 83), pitch 28 keeps the
                                              // 16 rows x 4 lane groups of an A-fragment read on 64 different banks
@@ -517,7 +530,7 @@ __attribute__((amdgpu_waves_per_eu(4))) __global__ __launch_bounds__(MNT) void c
         }
     }
     __syncthreads();
-    if (NMS_STOP == 1) return;
+    if (NMS_STOP == 1) { map[((size_t)f * h + (oy < h ? oy : 0)) * w + (tid % w)] = (uint8_t)smem[tid]; return; }
 
     {
         // wave `blk` owns the pixel block at LDS columns 28 blk .. 28 blk + 31 (all 32 rows)
@@ -613,7 +626,7 @@ __attribute__((amdgpu_waves_per_eu(4))) __global__ __launch_bounds__(MNT) void c
         }
     }
     __syncthreads();
-    if (NMS_STOP == 2) return;
+    if (NMS_STOP == 2) { map[((size_t)f * h + (oy < h ? oy : 0)) * w + (tid % w)] = (uint8_t)mag[tid % PGR][tid % MGW]; return; }   // (keeps the phases alive)
 
     // NMS: one thread = 4 consecutive pixels of one row (one dword of the map)
     const int TG22 = 13573;   // (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
