@@ -24,7 +24,7 @@
 namespace {
 
 constexpr int TW = 64;
-constexpr int LWD = TW / 4 + 2;              // pixel tile dwords per row (4-px halo each side)
+
 
 // ------------------------------------------------------------------------------------------
 // Packed variant (the one launched; -DNMS_MFMA=1 builds the matrix-pipe variant below instead).  The
@@ -50,6 +50,7 @@ constexpr int PGR = 15 * PK;                 // gradient rows (1-px halo)
 constexpr int PTH = PGR - 2;                 // output rows per tile
 constexpr int PLH = PTH + 4;                 // pixel rows (2-px halo)
 constexpr int PGW = 68;                      // gradient columns held: x = ox - 2 .. ox + 65
+constexpr int PLWD = 20;                     // pixel tile dwords per row: x = ox - 8 .. ox + 71, staged with 16-byte loads
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
@@ -102,10 +103,11 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
         }
     }
     if (thr) { low = thr[2 * f]; high = thr[2 * f + 1]; }
-    // pixel tile: columns ox-4 .. ox+67 (18 aligned dwords per row), rows oy-2 .. oy+PTH+1, border replicated.
-    // The candidate buffer of the last phase reuses its space.
+    // pixel tile: columns ox-8 .. ox+71 (20 dwords per row: five 16-byte loads; the gradient needs ox-2 .. ox+65), rows
+    // oy-2 .. oy+PTH+1, border replicated.  The candidate buffer of the last phase reuses its space.
+    constexpr int LWD = PLWD;
     constexpr int PXW = 3 * PLH * LWD, CBUF = PTH * TW;
-    __shared__ uint32_t smem[PXW > CBUF ? PXW : CBUF];
+    __shared__ __attribute__((aligned(16))) uint32_t smem[PXW > CBUF ? PXW : CBUF];
     uint32_t (*pxw)[PLH][LWD] = reinterpret_cast<uint32_t (*)[PLH][LWD]>(smem);
     int32_t* cbuf = reinterpret_cast<int32_t*>(smem);
     __shared__ __attribute__((aligned(8))) uint16_t mag[PGR][PGW];          // keys: magnitude * 4 + (3 - channel)
@@ -117,21 +119,26 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
     if (tid == 0) ccount = 0;
 
     const uint32_t plane = (uint32_t)h * pitch;
-    if (ox >= 4 && ox + TW + 4 <= w && oy >= 2 && oy + PTH + 2 <= h) {
-        // interior tile (all but the frame's rim): no clamping, one address computation per dword triple
-        const uint8_t* org = base + (uint32_t)((oy - 2) * pitch) + (ox - 4);
-        for (int i = tid; i < PLH * LWD; i += 256) {
-            const int r = i / LWD, cd = i - r * LWD;
-            const uint8_t* q = org + (uint32_t)(r * pitch) + 4 * cd;
+    if (ox >= 8 && ox + TW + 8 <= w && oy >= 2 && oy + PTH + 2 <= h) {
+        // interior tile (all but the frame's rim): no clamping, 16 bytes per load (8-byte aligned: ox is a multiple of 64),
+        // one load per plane and thread: 32 rows x 5 quads
+        struct __attribute__((packed, aligned(8))) q16 { uint32_t a, b, c, d; };
+        const uint8_t* org = base + (uint32_t)((oy - 2) * pitch) + (ox - 8);
+        for (int i = tid; i < PLH * (LWD / 4); i += 256) {
+            const int r = i / (LWD / 4), v = i - r * (LWD / 4);
+            const uint8_t* q = org + (uint32_t)(r * pitch) + 16 * v;
 #pragma unroll
-            for (int c = 0; c < 3; c++) pxw[c][r][cd] = *reinterpret_cast<const uint32_t*>(q + c * plane);
+            for (int c = 0; c < 3; c++) {
+                const q16 d = *reinterpret_cast<const q16*>(q + c * plane);
+                *reinterpret_cast<uint4*>(&pxw[c][r][4 * v]) = make_uint4(d.a, d.b, d.c, d.d);
+            }
         }
     } else {
         for (int i = tid; i < PLH * LWD; i += 256) {
             const int r = i / LWD, cd = i % LWD;
             int y = oy - 2 + r;
             y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-            const int x = ox - 4 + 4 * cd;                 // pitch is a multiple of 64 and ox of 64: aligned
+            const int x = ox - 8 + 4 * cd;                 // pitch is a multiple of 64 and ox of 64: aligned
             const uint8_t* row = base + (uint32_t)(y * pitch);
             if (x >= 0 && x + 3 < w) {
 #pragma unroll
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
             const int pr = seg * PK + k;               // pixel-tile row
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const uint32_t A = pxw[c][pr][cj], B = pxw[c][pr][cj + 1];
+                const uint32_t A = pxw[c][pr][cj + 1], B = pxw[c][pr][cj + 2];
                 const u16x2 p12 = widen(B, A, 0x0c020c01u), p23 = widen(B, A, 0x0c030c02u), p34 = widen(B, A, 0x0c040c03u),
                             p45 = widen(B, A, 0x0c050c04u), p56 = widen(B, A, 0x0c060c05u);
                 hdP[k % 3][c] = __builtin_bit_cast(s16x2, (u16x2)(p34 - p12));
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
                         // dx, dy of the chosen channel from its 8 taps: gradient (gr, idx) = pixel-tile rows gr .. gr + 2,
                         // bytes idx + 1 .. idx + 3 of the row
                         const int c = 3 - (int)(kk[k] & 3u);
-                        const uint8_t* t0 = pxb + ((c * PLH + r + 1) * LWD) * 4 + col0 + k + 3;
+                        const uint8_t* t0 = pxb + ((c * PLH + r + 1) * LWD) * 4 + col0 + k + 7;
                         const uint8_t* t1 = t0 + LWD * 4;
                         const uint8_t* t2 = t1 + LWD * 4;
                         const int a00 = t0[0], a01 = t0[1], a02 = t0[2], a10 = t1[0], a12 = t1[2], a20 = t2[0], a21 = t2[1], a22 = t2[2];
