@@ -35,6 +35,8 @@
 //   * a second copy of the threshold body for levels with a single prefix (the per-row prefix test
 //     drops out, -3 of 23 ops per row on ~35 % of the thresholds): 138 VGPRs -> 3 waves/SIMD, or 9
 //     spills when held to 4; measured 40.1 / 38.8 us against 38.3 us for the single body.
+#include <type_traits>
+
 #include "ck_common.h"
 
 #ifndef MED_MFMA
@@ -216,6 +218,16 @@ __global__ __launch_bounds__(64) void median15_kernel(const uint8_t* __restrict_
 //     the 4 waves of a SIMD already fill each other's gaps.
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+#ifndef MED_DBG
+#define MED_DBG 0          // 1: count tiles / scanned tiles / scans given up / (threshold, block) box counts of both kinds
+#endif
+#if MED_DBG
+__device__ unsigned long long g_med_dbg[8];
+#define MED_COUNT(K, V) do { if (lane == 0) atomicAdd(&g_med_dbg[K], (unsigned long long)(V)); } while (0)
+#else
+#define MED_COUNT(K, V) do { } while (0)
+#endif
+
 constexpr int MT = 48;      // medians per tile edge
 
 struct BandTable {
@@ -266,7 +278,6 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
     static_assert(K % 2 == 1 && K >= 3 && MT + K - 1 <= 64, "window size");
     constexpr int HK = K / 2, RANK = (K * K + 1) / 2;
     __shared__ uint32_t flags[3][64];
-    __shared__ uint32_t otile[MT * MT / 4];                    // the finished tile, for dword stores
     const int lane = threadIdx.x;
     const int n = lane & 15, g = lane >> 4;
     // XCD-aware tile order (as in the NMS kernel): workgroups go round-robin over the 8 XCDs by linear id; XCD k takes the
@@ -287,45 +298,77 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
     }
     const int ox = bxi * MT, oy = byi * MT;
     const int f = bzi / 3, c = bzi % 3;
-    const uint8_t* src = in + (size_t)f * h * w * 3 + c;
 
-    // ---- load: column tile i, lane (n, g) <- column ox - K/2 + 16 i + n, rows oy - K/2 + 16 g + 0..15 (replicate border)
+    // ---- load, TRANSPOSED (round 4): row tile i, lane (n, g) <- row oy - K/2 + 16 i + n, columns ox - K/2 + 16 g + 0..15
+    // of channel c, as 16 bytes.  The box count is symmetric in x and y, so the same two MFMA passes run on the
+    // transposed tile (pass 1 sums along a row, pass 2 down the columns) and a lane ends up with FOUR HORIZONTALLY
+    // ADJACENT medians of one row: med[t][u][e] <-> row 16 u + n, column 16 t + 4 g + e.  What that buys is the memory
+    // side: a lane's 16 pixels are 48 contiguous bytes of the interleaved frame -- 13 aligned dwords, fetched as 16-byte
+    // loads and picked apart with v_perm -- where the column-per-lane form needed 64 single-byte loads per lane, each
+    // of which holds the texture-address unit for 16 cycles: ~1 000 cycles per tile, 31 tiles per CU and frame = the
+    // whole 15 us the kernel took, whatever its arithmetic did (round 4: neither 20 % fewer box counts nor 24 more per
+    // tile moved the time).  The finished medians leave as one dword per lane and block: no LDS transpose either.
     v4i nx[4];
-    if (ox >= HK && ox - HK + 63 < w && oy >= HK && oy - HK + 63 < h) {
-        // interior tile: one per-lane offset, everything else is wave-uniform (scalar base + immediate)
-        const uint8_t* base = src + ((size_t)(oy - HK) * w + (ox - HK)) * 3;
-        uint32_t voff = (uint32_t)((16 * g * w + n) * 3);
+    if (ox >= HK && ox - HK + 65 < w && oy >= HK && oy - HK + 63 < h) {
+        // interior tile (two spare pixels behind the region: the 52 bytes fetched per lane end up to 4 bytes behind the 48
+        // that are used, and those must still be the frame's).  The loads start SH bytes before the lane's first pixel:
+        // with rows of whole dwords (w % 4 == 0) and the usual aligned frame buffer that is an aligned dword for every
+        // lane, row and tile (3 (ox - HK + 16 g) = -3 HK mod 4: ox is a multiple of 48) -- any other pointer or width
+        // just loads unaligned, the byte positions are relative to the load address either way.  The channel's bytes sit
+        // at fixed offsets SH + c + 3 k: compile-time v_perm selectors.
+        constexpr int SH = (4 - (3 * HK) % 4) % 4;
+        struct __attribute__((packed, aligned(4))) q16 { uint32_t a, b, c, d; };
+        const uint8_t* base = in + (size_t)f * h * w * 3 + ((size_t)(oy - HK) * w + (ox - HK)) * 3 - SH;
+        uint32_t voff = (uint32_t)((n * w + 16 * g) * 3);
         asm volatile("" : "+v"(voff));          // keep it one per-lane offset: scalar base + voff + immediate per load
+        uint32_t raw[4][13];
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
-            const uint8_t* r0 = base + (size_t)(uint32_t)((4 * d) * w * 3);
-            const uint8_t* r1 = base + (size_t)(uint32_t)((4 * d + 1) * w * 3);
-            const uint8_t* r2 = base + (size_t)(uint32_t)((4 * d + 2) * w * 3);
-            const uint8_t* r3 = base + (size_t)(uint32_t)((4 * d + 3) * w * 3);
+        for (int i = 0; i < 4; i++) {
+            const uint8_t* p = base + (size_t)(uint32_t)(16 * i * w * 3) + voff;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t v = (uint32_t)(r0 + 48 * i)[voff] | ((uint32_t)(r1 + 48 * i)[voff] << 8) |
-                                   ((uint32_t)(r2 + 48 * i)[voff] << 16) | ((uint32_t)(r3 + 48 * i)[voff] << 24);
-                nx[i][d] = (int)~v;
+            for (int v = 0; v < 3; v++) {
+                const q16 d = *reinterpret_cast<const q16*>(p + 16 * v);
+                raw[i][4 * v] = d.a; raw[i][4 * v + 1] = d.b; raw[i][4 * v + 2] = d.c; raw[i][4 * v + 3] = d.d;
             }
+            raw[i][12] = *reinterpret_cast<const uint32_t*>(p + 48);
         }
+        auto pick = [&](auto c_tag) {
+            constexpr int C = decltype(c_tag)::value;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const int p0 = SH + C + 12 * d;                     // byte position of the dword's first pixel (folds: d unrolled)
+                    const int q0 = p0 >> 2, q2 = (p0 + 6) >> 2;
+                    const uint32_t sel_lo = (uint32_t)(p0 - 4 * q0) | ((uint32_t)(p0 + 3 - 4 * q0) << 8) | 0x0c0c0000u;
+                    const uint32_t sel_hi = (uint32_t)(p0 + 6 - 4 * q2) | ((uint32_t)(p0 + 9 - 4 * q2) << 8) | 0x0c0c0000u;
+                    const uint32_t lo16 = __builtin_amdgcn_perm(raw[i][q0 + 1], raw[i][q0], sel_lo);
+                    const uint32_t hi16 = __builtin_amdgcn_perm(raw[i][q2 + 1 > 12 ? 12 : q2 + 1], raw[i][q2], sel_hi);
+                    nx[i][d] = (int)~__builtin_amdgcn_perm(hi16, lo16, 0x05040100u);
+                }
+        };
+        if (c == 0) pick(std::integral_constant<int, 0>{});
+        else if (c == 1) pick(std::integral_constant<int, 1>{});
+        else pick(std::integral_constant<int, 2>{});
     } else {
-        int yo[16];
+        // rim tiles (replicate border): byte by byte
+        const uint8_t* src = in + (size_t)f * h * w * 3 + c;
+        int xo[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            int y = oy - HK + 16 * g + j;
-            y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-            yo[j] = y * w * 3;
+            int x = ox - HK + 16 * g + j;
+            x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+            xo[j] = x * 3;
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            int x = ox - HK + 16 * i + n;
-            x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
-            const uint8_t* col = src + x * 3;
+            int y = oy - HK + 16 * i + n;
+            y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+            const uint8_t* row = src + (size_t)y * w * 3;
 #pragma unroll
             for (int d = 0; d < 4; d++) {
-                const uint32_t v = (uint32_t)col[yo[4 * d]] | ((uint32_t)col[yo[4 * d + 1]] << 8) |
-                                   ((uint32_t)col[yo[4 * d + 2]] << 16) | ((uint32_t)col[yo[4 * d + 3]] << 24);
+                const uint32_t v = (uint32_t)row[xo[4 * d]] | ((uint32_t)row[xo[4 * d + 1]] << 8) |
+                                   ((uint32_t)row[xo[4 * d + 2]] << 16) | ((uint32_t)row[xo[4 * d + 3]] << 24);
                 nx[i][d] = (int)~v;
             }
         }
@@ -349,6 +392,150 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
 #pragma unroll
     for (int t = 0; t < 3; t++) flags[t][lane] = 0;
 
+    // One threshold t on the row blocks in `here`: indicator, vertical + horizontal box count, update.  R = 256 (RANK -
+    // count) per pixel: > 0 where the median is above t.  WANT & 1: is some R of a row block > 0 (bit t of `pos`);
+    // WANT & 2: is some R <= 0 (`nonpos`) -- what the linear scan below needs to know when a row block is finished.
+    auto evaluate = [&](auto want_tag, int thr, const bool (&here)[3], unsigned& pos, unsigned& nonpos) {
+        constexpr int WANT = decltype(want_tag)::value;
+        const uint32_t T = (uint32_t)(thr + 1) * 0x01010101u;       // t + 1 in every byte
+        const int C = thr + 1;
+        v4i ind[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int d = 0; d < 4; d++)
+                ind[i][d] = (int)(__builtin_amdgcn_lerp((uint32_t)nx[i][d], T, 0u) & 0x80808080u);   // -128 where x <= t
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            if (!here[t]) continue;                                  // wave-uniform
+            v4i c1v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) c1v[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ind[i], bv[t], zero, 0, 0, 0);
+            v4i r[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) r[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(c1v[u], bh[0], c113, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 3; u++) r[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(c1v[u + 1], bh[1], r[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 3; u++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) med[t][u][e] = imed3(med[t][u][e], r[u][e], C);
+            if constexpr ((WANT & 1) != 0) {
+                int m = r[0][0];
+#pragma unroll
+                for (int u = 0; u < 3; u++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) m = m > r[u][e] ? m : r[u][e];
+                if (__builtin_amdgcn_ballot_w64(m > 0) != 0) pos |= 1u << t;
+            }
+            if constexpr ((WANT & 2) != 0) {
+                int m = r[0][0];
+#pragma unroll
+                for (int u = 0; u < 3; u++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) m = m < r[u][e] ? m : r[u][e];
+                if (__builtin_amdgcn_ballot_w64(m <= 0) != 0) nonpos |= 1u << t;
+            }
+        }
+    };
+
+    // ---- flat tiles: a linear scan around a guessed level instead of the radix descent (round 4) ------------------
+    // The radix tree pays one box count per LEVEL even where a whole row block holds a single median (8 for 1 value),
+    // and a contiguous run of medians that straddles a power of two pays for the alignment as well: 10.7 box counts per
+    // row block on the flat 72 % of a board frame's tiles, which hold 4.3 distinct medians.  Where the tile's input is
+    // flat (256 sampled pixels span <= 28 levels: sensor noise around one colour, no stone, no edge), the medians hug the
+    // sample mean g, so the thresholds g, g + 1, ... are evaluated until no pixel of a row block has its median above
+    // the threshold, then g - 1, g - 2, ... until none has it at or below: every t from (lowest median - 1) to the highest
+    // median is seen, which pins every pixel exactly (a pixel of median m needs m - 1 and m) -- span + 1 box counts per
+    // row block, the lower bound for a contiguous run.  The update is the same med3: with R > 0 it is max(med, t + 1),
+    // with R <= 0 min(med, t + 1), and both leave a finished pixel where it is in either scan direction.  A tile that
+    // turns out not to be flat (a scan longer than SCAN_CAP steps) starts over with the radix descent; nothing is
+    // assumed about the guess, it only has to be cheap.  -20 % box counts per 1080p board frame (simulation against the
+    // oracle's medians: profiles/r04_median_scan.txt), other content classes take the radix path as before.
+#ifndef MED_SCAN_RANGE
+#define MED_SCAN_RANGE 28
+#endif
+#ifndef MED_SCAN_CAP
+#define MED_SCAN_CAP 12
+#endif
+    constexpr int SCAN_RANGE = MED_SCAN_RANGE, SCAN_CAP = MED_SCAN_CAP;
+    bool done = false;
+    MED_COUNT(0, 1);
+    {
+        // 4 samples per lane: rows 16 g + {1, 6, 9, 14} of columns n, 16 + n, 32 + n, 48 + n (inverted bytes)
+        const uint32_t s0 = ((uint32_t)nx[0][0] >> 8) & 0xFFu, s1 = ((uint32_t)nx[1][1] >> 16) & 0xFFu;
+        const uint32_t s2 = ((uint32_t)nx[2][2] >> 8) & 0xFFu, s3 = ((uint32_t)nx[3][3] >> 16) & 0xFFu;
+        uint32_t lo = s0 < s1 ? s0 : s1, hi = s0 < s1 ? s1 : s0;
+        lo = lo < s2 ? lo : s2; lo = lo < s3 ? lo : s3;
+        hi = hi > s2 ? hi : s2; hi = hi > s3 ? hi : s3;
+        uint32_t sum = s0 + s1 + s2 + s3;
+        // row of 16 lanes: butterflies by DPP; the four rows meet on the scalar unit
+        // (each DPP read goes through a temporary: `V = V < dpp(V) ? V : dpp(V)` with __builtin_amdgcn_mov_dpp written
+        // twice compiles to a minimum that is 0 -- tools/micro/dpp_reduce.hip)
+#define CK_DPP(V, CTRL) (uint32_t)__builtin_amdgcn_update_dpp((int)(V), (int)(V), CTRL, 0xF, 0xF, false)
+#define CK_ROW_REDUCE(V, OP)                                                                                         \
+        { uint32_t t_;                                                                                               \
+          t_ = CK_DPP(V, 0xB1); V = OP(V, t_);     /* quad_perm [1,0,3,2] */                                         \
+          t_ = CK_DPP(V, 0x4E); V = OP(V, t_);     /* quad_perm [2,3,0,1] */                                         \
+          t_ = CK_DPP(V, 0x141); V = OP(V, t_);    /* row_half_mirror */                                             \
+          t_ = CK_DPP(V, 0x140); V = OP(V, t_); }  /* row_mirror */
+#define CK_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define CK_MAX(a, b) ((a) > (b) ? (a) : (b))
+#define CK_ADD(a, b) ((a) + (b))
+        CK_ROW_REDUCE(lo, CK_MIN)
+        CK_ROW_REDUCE(hi, CK_MAX)
+        CK_ROW_REDUCE(sum, CK_ADD)
+#undef CK_ROW_REDUCE
+#undef CK_DPP
+        uint32_t wlo = 255u, whi = 0u, wsum = 0u;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)lo, 16 * rr), bq = (uint32_t)__builtin_amdgcn_readlane((int)hi, 16 * rr);
+            wlo = CK_MIN(wlo, a); whi = CK_MAX(whi, bq);
+            wsum += (uint32_t)__builtin_amdgcn_readlane((int)sum, 16 * rr);
+        }
+#undef CK_MIN
+#undef CK_MAX
+#undef CK_ADD
+        if ((int)(whi - wlo) <= SCAN_RANGE) {
+            int g0 = 255 - (int)((wsum + 128u) >> 8);                // the samples are inverted pixels: mean of 256, rounded
+            g0 = g0 < 0 ? 0 : (g0 > 254 ? 254 : g0);
+            unsigned up = 7u, down = 0u;                             // row blocks still scanning in each direction
+            int steps = 0;
+            bool gave_up = false;
+            for (int thr = g0; up && thr <= 254; thr++, steps++) {
+                if (steps == SCAN_CAP) { gave_up = true; break; }
+                const bool here[3] = {(up & 1u) != 0, (up & 2u) != 0, (up & 4u) != 0};
+                MED_COUNT(4, __builtin_popcount(up));
+                unsigned pos = 0, nonpos = 0;
+                if (thr == g0) evaluate(std::integral_constant<int, 3>{}, thr, here, pos, nonpos);
+                else evaluate(std::integral_constant<int, 1>{}, thr, here, pos, nonpos);
+                if (thr == g0) down = nonpos;                        // some median <= g: g - 1 has to be looked at
+                up = pos;
+            }
+            steps = 0;
+            for (int thr = g0 - 1; !gave_up && down && thr >= 0; thr--, steps++) {
+                if (steps == SCAN_CAP) { gave_up = true; break; }
+                const bool here[3] = {(down & 1u) != 0, (down & 2u) != 0, (down & 4u) != 0};
+                MED_COUNT(4, __builtin_popcount(down));
+                unsigned pos = 0, nonpos = 0;
+                evaluate(std::integral_constant<int, 2>{}, thr, here, pos, nonpos);
+                down = nonpos;
+            }
+            MED_COUNT(1, 1);
+            if (gave_up) {
+                MED_COUNT(2, 1);
+#pragma unroll
+                for (int t = 0; t < 3; t++)
+#pragma unroll
+                    for (int u = 0; u < 3; u++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++) med[t][u][e] = 0;
+            } else
+                done = true;
+        }
+    }
+
     // The prefixes alive at a level are kept PER ROW BLOCK of 16 output rows (bit l of ct[t][k] <-> prefix 4 l + k is held
     // by some pixel of rows 16 t .. 16 t + 15; all wave-uniform, i.e. scalar registers): a threshold is evaluated only in
     // the row blocks that hold its prefix -- a block without it would be left unchanged by the arithmetic anyway -- which
@@ -356,7 +543,7 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
     unsigned long long ct[3][4];
 #pragma unroll
     for (int t = 0; t < 3; t++) { ct[t][0] = 1ull; ct[t][1] = ct[t][2] = ct[t][3] = 0ull; }
-    for (int b = 7; b >= 0; b--) {
+    for (int b = done ? -1 : 7; b >= 0; b--) {
         const int half = 1 << b;
         unsigned long long c0 = ct[0][0] | ct[1][0] | ct[2][0], c1 = ct[0][1] | ct[1][1] | ct[2][1];
         unsigned long long c2 = ct[0][2] | ct[1][2] | ct[2][2], c3 = ct[0][3] | ct[1][3] | ct[2][3];
@@ -372,30 +559,9 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
             else if (c3) CK_TAKE(3, c3)
             else break;
 #undef CK_TAKE
-            const uint32_t T = (uint32_t)(q + half) * 0x01010101u;      // t + 1 in every byte
-            const int C = q + half;
-            v4i ind[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int d = 0; d < 4; d++)
-                    ind[i][d] = (int)(__builtin_amdgcn_lerp((uint32_t)nx[i][d], T, 0u) & 0x80808080u);   // -128 where x <= t
-#pragma unroll
-            for (int t = 0; t < 3; t++) {
-                if (!here[t]) continue;                                  // wave-uniform
-                v4i c1v[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) c1v[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ind[i], bv[t], zero, 0, 0, 0);
-                v4i r[3];
-#pragma unroll
-                for (int u = 0; u < 3; u++) r[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(c1v[u], bh[0], c113, 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 3; u++) r[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(c1v[u + 1], bh[1], r[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 3; u++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) med[t][u][e] = imed3(med[t][u][e], r[u][e], C);
-            }
+            unsigned pos = 0, nonpos = 0;
+            MED_COUNT(3, (int)here[0] + (int)here[1] + (int)here[2]);
+            evaluate(std::integral_constant<int, 0>{}, q + half - 1, here, pos, nonpos);
         }
         if (b == 0) break;
         // the distinct prefixes of each row block -> its set for the next level
@@ -418,42 +584,23 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
         }
     }
 
-    // ---- store: planar; lane (n, g) holds rows 16 t + 4 g + e of column 16 u + n
+    // ---- store: planar; lane (n, g) holds columns 16 t + 4 g + e of row 16 u + n: one aligned dword per block
     uint8_t* plane = out + ((size_t)(f * 3 + c) * h) * pitch;
-    if (ox + MT <= w && oy + MT <= h) {
-        // whole tile inside the image: through LDS, so that HBM sees dwords (12 per tile row) instead of byte stores --
-        // the byte form wrote 8.1 MB per 1080p frame for 6.2 MB of output (PMC WRITE_SIZE, partial-line writes)
-        uint8_t* tb = reinterpret_cast<uint8_t*>(otile);
 #pragma unroll
-        for (int t = 0; t < 3; t++)
+    for (int u = 0; u < 3; u++) {
+        const int y = oy + 16 * u + n;
+        if (y >= h) continue;
+        uint8_t* row = plane + (size_t)y * pitch;
 #pragma unroll
-            for (int e = 0; e < 4; e++)
+        for (int t = 0; t < 3; t++) {
+            const int x = ox + 16 * t + 4 * g;
+            const uint32_t word = (uint32_t)med[t][u][0] | ((uint32_t)med[t][u][1] << 8) | ((uint32_t)med[t][u][2] << 16) |
+                                  ((uint32_t)med[t][u][3] << 24);
+            if (x + 3 < pitch) *reinterpret_cast<uint32_t*>(row + x) = word;       // (columns w .. pitch - 1 are padding)
+            else {
 #pragma unroll
-                for (int u = 0; u < 3; u++) tb[(16 * t + 4 * g + e) * MT + 16 * u + n] = (uint8_t)med[t][u][e];
-        // one wave = the whole workgroup: its own LDS writes are visible to it after the counter wait
-        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0)
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 60) {                                        // 5 tile rows of 12 dwords per round, 10 rounds (48 rows)
-            const int r0 = lane / 12, c4 = lane % 12;
-            uint8_t* dst = plane + (size_t)(oy + r0) * pitch + ox + 4 * c4;
-#pragma unroll
-            for (int it = 0; it < 10; it++) {
-                if (5 * it + r0 < MT)
-                    *reinterpret_cast<uint32_t*>(dst + (size_t)(5 * it) * pitch) = otile[(5 * it + r0) * (MT / 4) + c4];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int u = 0; u < 3; u++) {
-            const int x = ox + 16 * u + n;
-            if (x < w) {
-#pragma unroll
-                for (int t = 0; t < 3; t++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int y = oy + 16 * t + 4 * g + e;
-                        if (y < h) plane[(size_t)y * pitch + x] = (uint8_t)med[t][u][e];
-                    }
+                for (int e = 0; e < 4; e++)
+                    if (x + e < w) row[x + e] = (uint8_t)med[t][u][e];
             }
         }
     }
@@ -501,6 +648,17 @@ int k_median_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int 
     default: return ck_fail(ctx, CK_ERR_ARG, "median window %d: odd sizes 3..17 only", ksize);
     }
 #undef CK_MEDIAN_CASE
+#if MED_DBG
+    {
+        unsigned long long c[8];
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_med_dbg), sizeof c);
+        fprintf(stderr, "[median dbg] tiles %llu  scanned %llu  given up %llu  box counts per tile: radix %.2f  scan %.2f\n", c[0], c[1], c[2],
+                (double)c[3] / (double)(c[0] ? c[0] : 1), (double)c[4] / (double)(c[0] ? c[0] : 1));
+        memset(c, 0, sizeof c);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_med_dbg), c, sizeof c);
+    }
+#endif
 #else
     if (ksize != 15) return ck_fail(ctx, CK_ERR_ARG, "the SWAR median kernel is 15x15 only");
     dim3 grid((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H, n * 3);
