@@ -6,7 +6,7 @@
 set -e
 export TMPDIR=/tmp
 O=gpurun_out
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 bench.py --no-cpu-baseline --no-extras > $O/bench_prof.json 2> $O/prof_bench.err
 echo "bench stats done"
@@ -28,6 +28,10 @@ find $O/pmc_fetch $O/pmc_write $O/pmc_valu -name "*.db" -delete 2>/dev/null || t
 # summarise here: at the bench's own scale the raw counter tables are too large to travel back (gpurun merges 64 MiB)
 python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write 128 $O/pmc_traffic.json $O/pmc_valu > /dev/null
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_valu
+# what FETCH_SIZE counts per load width, on a stream of known size (the file the traffic figures are read against)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_calib -- tools/micro/fetch_calib > $O/fetch_calib.log 2>&1 || true
+python3 tools/pmc_kernels.py $O/pmc_calib read_b8x3 "read_wide<unsigned int>" "read_wide<HIP_vector_type<unsigned int, 2" "read_wide<HIP_vector_type<unsigned int, 4" > $O/fetch_calib.txt 2>&1 || true
+rm -rf $O/pmc_calib
 du -sh $O | tail -1
 python bench.py > $O/bench_full.json 2> $O/bench_full.err
 echo "bench done"

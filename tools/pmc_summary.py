@@ -16,7 +16,9 @@ import json
 import sys
 
 # (kernel-name substring, stage, frames per dispatch cap, loads are 16 B per lane)
-STAGE = [("median_mfma_kernel<15>", "median", None, False), ("canny_nms", "canny_nms", None, False),
+# (the median reads 16 bytes per lane since round 4: its FETCH_SIZE is doubled like every wide stream's; the NMS kernel's
+# staging loads are 16 bytes per lane too)
+STAGE = [("median_mfma_kernel<15>", "median", None, True), ("canny_nms", "canny_nms", None, True),
          ("prep_runs", "ccl_prep_runs", None, False), ("link_runs", "ccl_link_runs", None, False),
          ("border_runs", "ccl_border_runs", None, False),
          ("prep_rows", "ccl_prep_rows", None, False), ("border_list", "ccl_border_list", None, False),
@@ -48,7 +50,10 @@ def main():
     valu = load(sys.argv[5], "SQ_INSTS_VALU") if len(sys.argv) > 5 else {}
     mfma = load(sys.argv[5], "SQ_INSTS_MFMA") if len(sys.argv) > 5 else {}
     frames = int(sys.argv[3])
-    out = {"_source": "rocprofv3 --pmc, one pass per counter group, the bench's own shape: `bench.py --timed-only --frames 256 --lanes 2 "
+    import datetime
+    import os
+    out = {"_head": os.environ.get("CK_HEAD", "unknown"), "_date": datetime.date.today().isoformat(),
+           "_source": "rocprofv3 --pmc, one pass per counter group, the bench's own shape: `bench.py --timed-only --frames 256 --lanes 2 "
                       "--warmup 1 --steps 2` = %d frames per launch, two lanes cycling 1.59 GB of frames (inputs come from HBM, not "
                       "from the Infinity Cache), tools/collect_profiles.sh; KiB counters; per frame" % frames,
            "_correction": "hbm_bytes_raw = (FETCH_SIZE + WRITE_SIZE) * 1024; hbm_bytes_corrected doubles FETCH_SIZE only for "

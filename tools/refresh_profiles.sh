@@ -3,10 +3,12 @@
 # (named per round): rocprofv3 kernel stats of the bench command and of the serial pass, the PMC traffic summary, the bench line.
 set -e
 cd "$(dirname "$0")/.."
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 rm -rf gpurun_out/prof_bench gpurun_out/prof_serial gpurun_out/prof_stonefind gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_valu
-/usr/local/graft/bin/gpurun --timeout 1100 -- 'timeout -k 10 1000 bash tools/collect_profiles.sh' > /tmp/collect.log 2>&1 || { tail -20 /tmp/collect.log; exit 1; }
+HEAD=$(git rev-parse --short HEAD)$(git diff --quiet || echo "+dirty")
+/usr/local/graft/bin/gpurun --timeout 1100 -- "CK_HEAD=$HEAD ROUND=$R timeout -k 10 1000 bash tools/collect_profiles.sh" > /tmp/collect.log 2>&1 || { tail -20 /tmp/collect.log; exit 1; }
 cp gpurun_out/pmc_traffic.json profiles/${R}_pmc_traffic.json
+cp gpurun_out/fetch_calib.txt profiles/${R}_fetch_calib.txt 2>/dev/null || true
 python - "$R" <<'PY'
 import csv, glob, json, sys
 R = sys.argv[1]
