@@ -459,12 +459,11 @@ def main():
                                            board_records_computed_pct=round(100.0 * lazy.board.fetched / max(1, lazy.board.seen), 1),
                                            board_fetch_calls_per_batch=round(lazy.board.calls * n_total / max(1, lazy.board.seen), 2),
                                            extra_grouping_rounds_of_recent_detections=list(lazy.board.recent),
-                                           note="NOT the headline (that one runs K1-K6 on every frame): K1-K6 only for the frames the board "
-                                                "fold looks at, all windows of a batch predicted from the frame-count phase of the library's 4-frame "
-                                                "grouping and fetched in one call over both lanes' board contexts, behind the stones core of the next "
-                                                "batch.  On this film detections need 0 to 4 extra grouping rounds (hands over the board), so the "
-                                                "windows carry slack and about half of the records are still computed: it ends level with the eager "
-                                                "path, whose board work hides behind two lanes anyway; stones path on every frame")
+                                           note="NOT the headline (that one runs K1-K6 on every frame): the reference does not run K1-K6 during the "
+                                                "hold-off after a detection (bf_auto.py:43-49); here K1-K6 run only for the frames the board fold looks "
+                                                "at, window after window where the fold's exact state puts them, on the lanes' board contexts while the "
+                                                "stones path of the same batch is on the GPU (the fold runs before the exchange thread waits for the "
+                                                "core); stones path on every frame; same game record required")
         # (2) PCIe-inclusive: the batch starts as I420 in PINNED host memory (what a video-file reader holds), is
         # uploaded and converted lane by lane (ck_i420_to_bgr), answers come back to the host; two batches in flight
         if world == 1:

@@ -182,7 +182,8 @@ class BoardFold:
         self.hold = 0
         self.seen = self.looked = self.fetched = self.calls = 0   # records offered / looked at / computed lazily / fetch calls
         self.episode = 8                                     # frames the last detection took
-        self.recent = [1]                                    # extra grouping rounds the last few detections needed (run_lazy's prediction)
+        self.recent = [1]                                    # extra grouping rounds the last few detections needed (run_lazy's first request)
+        self._run = self._opened = 0                         # frames looked at since the window in progress opened / the count it opened on
 
     @property
     def mtx(self):
@@ -225,35 +226,29 @@ class BoardFold:
     def run_lazy(self, n, fetch, chunk=8):
         """The same fold over a batch of n frames whose board records do not exist yet: `fetch(indices)` computes the
         records of those frames (-> BOARD_DTYPE array, lines (len(indices), cap, 2)) and is only asked for frames this
-        fold is going to look at.  During the hold-off the reference does not run K1..K6 at all (bf_auto.py:43-49);
-        this is that, batch-wise.  The frames looked at are predictable (below), so the windows of a whole batch are
-        requested in ONE call; a hit that comes later than predicted costs an extra call of 2 x `chunk` frames, one that
-        comes earlier leaves a few computed records unused.  Same calls to `step` in the same order as `run` over the
-        full records, hence the same corners."""
-        # A fetch is a GPU round trip of a few milliseconds whatever its size, and where window j + 1 starts depends on
-        # where window j's hit fell -- a chain of round trips unless the hits are predicted.  They can be: the library
-        # looks for corners only on frames whose running count is a multiple of 4 (bf_auto.py:85-94), so a window that
-        # opens on count c closes on the next multiple of 4 (1 to 4 frames), or 4 x `tries` frames later when the
-        # grouping needed more rounds lately.  All windows of the batch are asked for in ONE call.
-        c0 = self.finder.total_f_processed
-        slack = 4 * max(self.recent[-2:])                    # frames a hit may come late by, judging from the last two
-        want, a, late = [], self.hold, 0
-        while a < n:
-            first = (-(c0 + a)) % 4 + 1                      # the window closes here if the first grouping round hits
-            late += slack                                    # ... and every window before this one may have run late too
-            want.extend(f for f in range(a, min(n, a + first + late)) if not want or f > want[-1])
-            a += first + self.refresh_frames
+        fold is going to look at.  During the hold-off the reference does not run K1..K6 at all (bf_auto.py:43-49); this
+        is that, batch-wise.  Same calls to `step` in the same order as `run` over the full records, hence the same
+        corners.
+
+        The windows are fetched ONE AFTER THE OTHER, each where the fold's exact state puts it (round 3 asked for the
+        union of all predicted windows of the batch in one call: where window j + 1 opens depends on where window j's hit
+        fell, so the union had to carry the accumulated slack and computed 60 % of the records).  A window that opens on
+        running count c closes on the next multiple of 4 -- the library looks for corners only there (bf_auto.py:85-94) --
+        or 4 x r frames later when the grouping needs more rounds: the first request covers the typical r of the last
+        detections, a later hit costs further requests of `chunk` frames.  A request is a GPU round trip of a few tenths
+        of a millisecond on the board lanes, which the pipeline hides under the stones path of the same batch."""
         cache = {}
 
-        def load(indices):
+        def load(lo, hi):
+            indices = [f for f in range(lo, min(n, hi)) if f not in cache]
+            if not indices:
+                return
             res, lines = fetch(indices)
             self.fetched += len(indices)
             self.calls += 1
             for j, f in enumerate(indices):
                 cache[f] = (int(res["status"][j]), int(res["n_lines"][j]), lines[j])
-        if want:
-            load(want)
-        k = run = 0
+        k = 0
         while k < n:
             if self.hold > 0:
                 skip = min(self.hold, n - k)
@@ -263,16 +258,20 @@ class BoardFold:
                 k += skip
                 continue
             if k not in cache:
-                load([f for f in range(k, min(n, k + 2 * chunk)) if f not in cache])
+                if self._run == 0:                           # a window opens here: up to its probable end in one request
+                    typical = sorted(self.recent)[len(self.recent) // 2]
+                    load(k, k + (-self.finder.total_f_processed) % 4 + 1 + 4 * min(typical, 3))
+                else:
+                    load(k, k + chunk)
             status, n_lines, lines = cache[k]
-            if run == 0:
-                opened = self.finder.total_f_processed       # the count this window opens on
+            if self._run == 0:
+                self._opened = self.finder.total_f_processed  # the count this window opens on (it may span two batches)
             self.step(dict(status=status, n_lines=n_lines, lines=lines))
-            k, run = k + 1, run + 1
+            k, self._run = k + 1, self._run + 1
             if self.hold > 0:
-                self.episode = run                           # frames it took from the end of the hold-off to this hit
-                self.recent = (self.recent + [max(0, (run - ((-opened) % 4 + 1)) // 4)])[-4:]
-                run = 0
+                self.episode = self._run                     # frames it took from the end of the hold-off to this hit
+                self.recent = (self.recent + [max(0, (self._run - ((-self._opened) % 4 + 1)) // 4)])[-4:]
+                self._run = 0
         return self.mtx
 
 
@@ -648,6 +647,18 @@ class FastFilePipeline:
         """-> (records of the whole batch, counts or None, transform after this batch, failure seen by any rank)"""
         import time
         hs = self.host_seconds
+        lazy_fold = None
+        if self.board_lazy and self.rank == 0:
+            # hold-off-aware mode: the GPU core leaves the board path out, and this fold needs nothing of the core's
+            # results -- it asks the lanes' BOARD contexts (idle in this mode) for the few records it looks at.  So it
+            # runs here, while the stones path of the same batch is still on the GPU, instead of after it.
+            t_f = time.perf_counter()
+            try:
+                self._fold_board(np.zeros(t.n_total, REC), t.frames)
+                lazy_fold = (self.board.mtx, None)
+            except Exception as why:
+                lazy_fold = (None, why)
+            hs["fold_board"] += time.perf_counter() - t_f
         (board, rl, rc, fg, gobans), failure = t.core.result()
         if failure is not None:
             self.errors.append(failure)
@@ -680,9 +691,13 @@ class FastFilePipeline:
         # other ranks -- before the background model's exchange starts
         t3 = time.perf_counter()
         new, fold_error = None, None
-        if self.rank == 0:
+        if lazy_fold is not None:
+            new, fold_error = lazy_fold
+            if fold_error is not None:
+                raise fold_error
+        elif self.rank == 0:
             try:
-                self._fold_board(full, t.frames if self.board_lazy else None)
+                self._fold_board(full, None)
                 new = self.board.mtx
             except Exception as why:                           # e.g. the IndexError the reference raises on a 3-vertex hull
                 if not self.exchange:
@@ -776,7 +791,7 @@ class FastFilePipeline:
 
         def fetch(idx):
             idx = list(idx)
-            k = len(lanes) if len(idx) >= 4 * len(lanes) else 1
+            k = len(lanes) if len(idx) >= 8 * len(lanes) else 1
             cuts = [round(i * len(idx) / k) for i in range(k + 1)]
             futs = [pools[i][0].submit(lanes[i][0].board_detect, _take(frames, idx[cuts[i]:cuts[i + 1]]), -1, LMAX, True)
                     for i in range(k)]
