@@ -445,7 +445,10 @@ def main():
         # (bf_auto.py:43-49); here the fold computes only the board records it looks at.  NOT the headline workload
         # (that one is the per-frame hot path on every frame); same game record required.
         if world == 1:
-            lazy = pipeline.FastFilePipeline(H, W, ControllerHeadless(), rank=pr, world=pw, device=cdev, lanes=lanes, ctx_bg=ctx_bg,
+            # board contexts of their own for this mode, on high-priority streams: their calls are a few frames each and the
+            # fold waits for every answer, so their kernels must not queue behind the classifier's 128-frame launches
+            lazy_lanes = [(capi.Context(local_rank, priority=1), cs) for _, cs in lanes]
+            lazy = pipeline.FastFilePipeline(H, W, ControllerHeadless(), rank=pr, world=pw, device=cdev, lanes=lazy_lanes, ctx_bg=ctx_bg,
                                              board_lazy=True)
             lazy.process_batch(frames, n_total)
             if lazy.mtx is None:
@@ -454,6 +457,8 @@ def main():
             k = max(4, args.steps // 2)
             dlz = timed(lazy, k, 2, frames)
             lazy.close()
+            for cb, _ in lazy_lanes:
+                cb.close()
             extras["holdoff_aware"] = dict(value=round(n_total * k / dlz, 2), unit="frames/s", steps=k, same_game_record=bool(same),
                                            host_ms_per_step={kk: round(1e3 * v / k, 3) for kk, v in lazy.host_seconds.items()},
                                            board_records_computed_pct=round(100.0 * lazy.board.fetched / max(1, lazy.board.seen), 1),

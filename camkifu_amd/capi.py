@@ -22,7 +22,7 @@ CK_BOARD_LINES, CK_BOARD_NO_CONTOUR, CK_BOARD_TOO_SMALL = 0, 1, 2
 ZONE_LINES = 32        # CK_ZONE_LINES
 
 EXPORTS = [
-    "ck_ctx_create", "ck_ctx_destroy", "ck_last_error", "ck_backend", "ck_version", "ck_stream",
+    "ck_ctx_create", "ck_ctx_create_prio", "ck_ctx_destroy", "ck_last_error", "ck_backend", "ck_version", "ck_stream",
     "ck_timing_enable", "ck_timing_reset", "ck_timing_get",
     "ck_median15", "ck_median", "ck_canny", "ck_goban_canny", "ck_board_edges", "ck_board_lines", "ck_board_detect",
     "ck_i420_to_bgr", "ck_get_perspective_transform", "ck_warp_perspective",
@@ -121,9 +121,10 @@ def _in(a, dtype=np.uint8):
 class Context:
     """One ck_ctx: a HIP stream plus scratch buffers.  One per finder instance / thread."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, priority=0):
+        """priority: HIP stream priority of the context's stream -- 0 normal, 1 highest, -1 lowest"""
         self._h = C.c_void_p()
-        rc = lib().ck_ctx_create(int(device), C.byref(self._h))
+        rc = lib().ck_ctx_create_prio(int(device), int(priority), C.byref(self._h))
         if rc != 0:
             raise CkError("ck_ctx_create failed: " + (lib().ck_last_error(None) or b"").decode())
         self.device = device

@@ -176,7 +176,9 @@ extern "C" {
 
 int ck_version(void) { return 100; }
 
-int ck_ctx_create(int device, ck_ctx** out)
+int ck_ctx_create(int device, ck_ctx** out) { return ck_ctx_create_prio(device, 0, out); }
+
+int ck_ctx_create_prio(int device, int priority, ck_ctx** out)
 {
     if (!out) return ck_fail(nullptr, CK_ERR_ARG, "out is NULL");
     *out = nullptr;
@@ -189,7 +191,13 @@ int ck_ctx_create(int device, ck_ctx** out)
     if (e != hipSuccess) return ck_fail(nullptr, CK_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
     ck_ctx* ctx = new ck_ctx();
     ctx->device = device;
-    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (priority == 0)
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    else {
+        int least = 0, greatest = 0;                     // (numerically: greatest priority = the smaller number)
+        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, priority > 0 ? greatest : least);
+    }
     if (e != hipSuccess) { delete ctx; return ck_fail(nullptr, CK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     *out = ctx;
     return CK_OK;

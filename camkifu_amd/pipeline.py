@@ -184,6 +184,7 @@ class BoardFold:
         self.episode = 8                                     # frames the last detection took
         self.recent = [1]                                    # extra grouping rounds the last few detections needed (run_lazy's first request)
         self._run = self._opened = 0                         # frames looked at since the window in progress opened / the count it opened on
+        self.generosity = 1                                  # grouping rounds a window's first request covers beyond the recent maximum
 
     @property
     def mtx(self):
@@ -235,8 +236,9 @@ class BoardFold:
         fell, so the union had to carry the accumulated slack and computed 60 % of the records).  A window that opens on
         running count c closes on the next multiple of 4 -- the library looks for corners only there (bf_auto.py:85-94) --
         or 4 x r frames later when the grouping needs more rounds: the first request covers the typical r of the last
-        detections, a later hit costs further requests of `chunk` frames.  A request is a GPU round trip of a few tenths
-        of a millisecond on the board lanes, which the pipeline hides under the stones path of the same batch."""
+        detections (`generosity` rounds on top: a record costs 28 us of GPU time, a further request 1 to 2 ms of round trip),
+        a later hit costs further requests of `chunk` frames.  The pipeline runs this chain of requests on a thread of its
+        own, ahead of the stones path of the same batch."""
         cache = {}
 
         def load(lo, hi):
@@ -259,8 +261,8 @@ class BoardFold:
                 continue
             if k not in cache:
                 if self._run == 0:                           # a window opens here: up to its probable end in one request
-                    typical = sorted(self.recent)[len(self.recent) // 2]
-                    load(k, k + (-self.finder.total_f_processed) % 4 + 1 + 4 * min(typical, 3))
+                    rounds = min(max(self.recent) + self.generosity, 4)
+                    load(k, k + (-self.finder.total_f_processed) % 4 + 1 + 4 * rounds)
                 else:
                     load(k, k + chunk)
             status, n_lines, lines = cache[k]
@@ -463,10 +465,10 @@ class _BandExchangeBroken(RuntimeError):
 
 class _Ticket:
     """one batch on its way through the stages: GPU core -> exchange (records, transform, bands, counts) -> stones fold"""
-    __slots__ = ("core", "exchange", "mtx", "rates", "n_total", "frames", "have_mtx")
+    __slots__ = ("core", "exchange", "mtx", "rates", "n_total", "frames", "have_mtx", "lazy_fold")
 
     def __init__(self, core, mtx, rates, n_total, frames):
-        self.core, self.exchange = core, None
+        self.core, self.exchange, self.lazy_fold = core, None, None
         self.mtx, self.rates, self.n_total, self.frames = mtx, rates, n_total, frames
         self.have_mtx = mtx is not None
 
@@ -517,6 +519,7 @@ class FastFilePipeline:
         # (capi._in), so anything this thread queued there -- i.e. a wait for an all-to-all that completes when the SLOWEST
         # rank has joined -- would gate every board / warp / classifier call of the next batch.
         self._xstream = None
+        self._board_thread = None                             # hold-off-aware mode: the board folds of the batches, one after the other
         self.board = BoardFold(h, w)
         self.stones = StonesFold(controller, bg_init_frames)
         self.bg_init_frames, self.stone_frames = bg_init_frames, 0      # frames the stones path has been given (every rank counts)
@@ -624,8 +627,27 @@ class FastFilePipeline:
         rates_for_core = rates if not self.exchange else rates[mine]
         seq = self.compute.ticket() if hasattr(self.compute, "ticket") else None
         t = _Ticket(self._runner.submit(self._guarded, my_frames, mtx, rates_for_core, len(mine), seq), mtx, rates, n_total, my_frames)
+        if self.board_lazy and self.rank == 0:
+            # hold-off-aware mode: the board fold needs nothing of the GPU core's results -- it asks the lanes' BOARD contexts
+            # (idle in this mode) for the few records it looks at, a chain of small round trips that depends only on the
+            # fold before it.  It runs on a thread of its own, batch after batch, as far ahead of the cores as the batches
+            # in flight allow.
+            if self._board_thread is None:
+                self._board_thread = _pool(1, self.gpu)
+            t.lazy_fold = self._board_thread.submit(self._lazy_fold, t)
         t.exchange = self._comm.submit(self._exchange, t)
         return t
+
+    def _lazy_fold(self, t):
+        import time
+        t0 = time.perf_counter()
+        try:
+            self._fold_board(np.zeros(t.n_total, REC), t.frames)
+            return self.board.mtx, None
+        except Exception as why:
+            return None, why
+        finally:
+            self.host_seconds["fold_board"] += time.perf_counter() - t0
 
     def _exchange(self, t):
         """stage 2 on this rank's exchange thread, with that thread's own torch stream current (see __init__)"""
@@ -647,19 +669,8 @@ class FastFilePipeline:
         """-> (records of the whole batch, counts or None, transform after this batch, failure seen by any rank)"""
         import time
         hs = self.host_seconds
-        lazy_fold = None
-        if self.board_lazy and self.rank == 0:
-            # hold-off-aware mode: the GPU core leaves the board path out, and this fold needs nothing of the core's
-            # results -- it asks the lanes' BOARD contexts (idle in this mode) for the few records it looks at.  So it
-            # runs here, while the stones path of the same batch is still on the GPU, instead of after it.
-            t_f = time.perf_counter()
-            try:
-                self._fold_board(np.zeros(t.n_total, REC), t.frames)
-                lazy_fold = (self.board.mtx, None)
-            except Exception as why:
-                lazy_fold = (None, why)
-            hs["fold_board"] += time.perf_counter() - t_f
         (board, rl, rc, fg, gobans), failure = t.core.result()
+        lazy_fold = t.lazy_fold.result() if t.lazy_fold is not None else None
         if failure is not None:
             self.errors.append(failure)
         n_total = t.n_total
@@ -772,6 +783,8 @@ class FastFilePipeline:
         returns only when the batches in flight have left the contexts, so that the caller may close those next."""
         self._runner.shutdown(wait=wait)
         self._comm.shutdown(wait=wait)
+        if self._board_thread is not None:
+            self._board_thread.shutdown(wait=wait)
         if self._owns_compute and hasattr(self.compute, "close"):
             self.compute.close(wait)
 

@@ -50,6 +50,10 @@ typedef struct ck_board_result {
 
 /* ---- context ------------------------------------------------------------------------ */
 int  ck_ctx_create(int device, ck_ctx** out);
+/* The same with a HIP stream priority for the context's stream: 0 normal, 1 the device's highest, -1 its lowest.  A finder
+ * whose calls are short and waited for (the board finder of the hold-off-aware file mode: a few frames per call, the fold
+ * waits for the answer) gets its kernels onto the CUs ahead of the long launches of other contexts. */
+int  ck_ctx_create_prio(int device, int priority, ck_ctx** out);
 void ck_ctx_destroy(ck_ctx* ctx);
 const char* ck_last_error(const ck_ctx* ctx);     /* ctx may be NULL: last create error */
 int  ck_backend(const ck_ctx* ctx);               /* CK_BACKEND_HIP                     */

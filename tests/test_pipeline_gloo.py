@@ -436,7 +436,7 @@ def test_lazy_board_fold_equals_the_eager_one():
         assert a.corners.hull == b.corners.hull and a.total_f_processed == b.total_f_processed
         assert (eager.hold, eager.seen, eager.looked) == (lazy.hold, lazy.seen, lazy.looked)
     # what is computed stays close to what is looked at (the blind stretch -- 120 frames, all looked at -- included)
-    assert eager.mtx is not None and lazy.looked <= lazy.fetched < lazy.looked + 0.1 * lazy.seen
+    assert eager.mtx is not None and lazy.looked <= lazy.fetched < lazy.looked + 0.15 * lazy.seen
     assert len(asked) < 60        # a request or two per window, plus the blind stretch in chunks of 8
 
 
@@ -519,5 +519,5 @@ def test_hold_off_aware_pipeline_equals_the_eager_one_and_computes_a_fraction_of
     # computed = looked at + the overshoot of the last request of each window; well under half of the records here
     # (these synthetic line bundles need several grouping rounds per detection: 22 % of the frames are looked at)
     assert sum(lazy["asked"]) == lazy["fetched"], (sum(lazy["asked"]), lazy["fetched"])
-    assert lazy["looked"] <= lazy["fetched"] <= lazy["looked"] + 0.1 * total < 0.4 * total, (lazy["looked"], lazy["fetched"], total)
+    assert lazy["looked"] <= lazy["fetched"] <= lazy["looked"] + 0.15 * total < 0.4 * total, (lazy["looked"], lazy["fetched"], total)
     assert lazy["calls"] <= 2 * (total // 50 + 2)                    # a request or two per window
