@@ -3,11 +3,13 @@
 --kernel-trace only) into per-stage HBM traffic per frame.
 
 Units and the gfx950 correction, as MI355X_MICROARCH.md (HBM / rocprofv3 section) prescribes: both counters are KiB;
-WRITE_SIZE is exact; FETCH_SIZE reports exactly HALF of the bytes of a wide coalesced streaming read -- 16 B per lane --
-and only of those.  So the x2 is applied per kernel, only where the loads ARE 16 B per lane (column `wide_loads`):
-the classifier's weight-fragment / activation loads and the I420 converter; the median's byte loads, the NMS's and the
-row kernel's dword loads are left as counted.  Both the raw and the corrected figure are written, with the run they
-come from (frames per batch, lanes), so that nobody has to take the correction on trust.
+WRITE_SIZE is exact; FETCH_SIZE reports exactly HALF of the bytes of a streaming read.  The guide documents the halving
+for 16-byte-per-lane streams and calls other widths uncalibrated; round 4 calibrated them (tools/micro/fetch_calib.hip,
+profiles/r04_fetch_calib.txt: a 512 MiB stream reads 262 150 KiB whether it is fetched as single bytes at a 3-byte
+stride, dwords, 8 or 16 bytes per lane), so the x2 is applied to EVERY kernel.  Rounds 1-3 doubled only the 16-byte
+streams and so under-counted the median and the NMS kernel (their "0.77 x / 0.92 x of the algorithmic bytes" were 1.26 x /
+1.29 x).  Both the raw and the corrected figure are written, with the run they come from (frames per batch, lanes), so
+that nobody has to take the correction on trust.
 usage: pmc_summary.py <fetch_dir> <write_dir> <frames_per_batch> <out.json> [<valu_dir>]"""
 import collections
 import csv
@@ -16,14 +18,13 @@ import json
 import sys
 
 # (kernel-name substring, stage, frames per dispatch cap, loads are 16 B per lane)
-# (the median reads 16 bytes per lane since round 4: its FETCH_SIZE is doubled like every wide stream's; the NMS kernel's
-# staging loads are 16 bytes per lane too)
+# (last column: double FETCH_SIZE -- true for every load width on gfx950, see the module docstring)
 STAGE = [("median_mfma_kernel<15>", "median", None, True), ("canny_nms", "canny_nms", None, True),
-         ("prep_runs", "ccl_prep_runs", None, False), ("link_runs", "ccl_link_runs", None, False),
-         ("border_runs", "ccl_border_runs", None, False),
-         ("prep_rows", "ccl_prep_rows", None, False), ("border_list", "ccl_border_list", None, False),
-         ("hough_vote", "hough_vote", None, False), ("warp_kernel", "warp", None, False),
-         ("mog2_run_kernel", "mog2", None, False),
+         ("prep_runs", "ccl_prep_runs", None, True), ("link_runs", "ccl_link_runs", None, True),
+         ("border_runs", "ccl_border_runs", None, True),
+         ("prep_rows", "ccl_prep_rows", None, True), ("border_list", "ccl_border_list", None, True),
+         ("hough_vote", "hough_vote", None, True), ("warp_kernel", "warp", None, True),
+         ("mog2_run_kernel", "mog2", None, True),
          ("conv_mfma16_h2_kernel", "cnn_conv2", 128, True), ("conv34_h2_kernel", "cnn_conv4", 128, True),
          ("fc1_h2_kernel", "cnn_fc1", None, True)]
 
@@ -56,8 +57,9 @@ def main():
            "_source": "rocprofv3 --pmc, one pass per counter group, the bench's own shape: `bench.py --timed-only --frames 256 --lanes 2 "
                       "--warmup 1 --steps 2` = %d frames per launch, two lanes cycling 1.59 GB of frames (inputs come from HBM, not "
                       "from the Infinity Cache), tools/collect_profiles.sh; KiB counters; per frame" % frames,
-           "_correction": "hbm_bytes_raw = (FETCH_SIZE + WRITE_SIZE) * 1024; hbm_bytes_corrected doubles FETCH_SIZE only for "
-                          "kernels with wide_loads = true (16 B per lane), MI355X_MICROARCH.md"}
+           "_correction": "hbm_bytes_raw = (FETCH_SIZE + WRITE_SIZE) * 1024; hbm_bytes_corrected = (2 FETCH_SIZE + WRITE_SIZE) * 1024 for "
+                          "every kernel: FETCH_SIZE reports half the bytes of a stream at every load width (MI355X_MICROARCH.md for 16 B "
+                          "per lane; profiles/r04_fetch_calib.txt for 1, 4 and 8 B)"}
     for key, stage, chunk, wide in STAGE:
         if stage not in fetch or stage not in write:
             continue
