@@ -489,10 +489,11 @@ __global__ __launch_bounds__(256) void prep_runs_kernel(const uint8_t* __restric
                                                         FrameTab* __restrict__ tab, int32_t* __restrict__ elist, RunTab rt,
                                                         const int* __restrict__ canny_border_flag)
 {
-    const int lane = threadIdx.x & 63;
-    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int y = blockIdx.x * 4 + wv;
     const int f = blockIdx.y;
-    if (y >= h) return;                                  // whole wave leaves together
+    const bool row_live = y < h;                         // (rows beyond the image still meet the workgroup's barriers)
+    __shared__ int wtotal[4], wbase;
     // L holds Canny's hysteresis labels at the edge pixels: kept unless an edge touched the image frame (cleared
     // below, which may split a component)
     const bool keep_edge_parents = canny_border_flag != nullptr && canny_border_flag[f] == 0;
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(256) void prep_runs_kernel(const uint8_t* __restric
     for (int s = 0; s < NS; s++) {
         const int x = 256 * s + 4 * lane;
         v[s] = 0;
-        if (x < w && row_inner) v[s] = *reinterpret_cast<const uint32_t*>(edges + off + x);
+        if (x < w && row_inner && row_live) v[s] = *reinterpret_cast<const uint32_t*>(edges + off + x);
     }
     int nib[NS], before[NS];          // before: edge pixels of this row in earlier lanes / steps
     int total = 0;
@@ -526,11 +527,20 @@ __global__ __launch_bounds__(256) void prep_runs_kernel(const uint8_t* __restric
             total += __builtin_popcountll(b0) + __builtin_popcountll(b1) + __builtin_popcountll(b2) + __builtin_popcountll(b3);
         }
     }
-    int base = 0;
-    if (total) {
-        if (lane == 0) base = atomicAdd(&tab[f].n_edges, total);
-        base = __builtin_amdgcn_readfirstlane(base);
+    // one returning atomic per WORKGROUP (four rows) instead of one per row: the rows' counts meet in LDS, thread 0 takes
+    // the segment for all four, each row starts behind the rows before it (1 080 atomics per frame on ONE word were the
+    // kernel's longest dependency)
+    if (lane == 0) wtotal[wv] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int all = wtotal[0] + wtotal[1] + wtotal[2] + wtotal[3];
+        wbase = all ? atomicAdd(&tab[f].n_edges, all) : 0;
     }
+    __syncthreads();
+    if (!row_live) return;
+    int base = wbase;
+    for (int kk = 0; kk < wv; kk++) base += wtotal[kk];
+    base = __builtin_amdgcn_readfirstlane(base);
     if (lane == 0) {
         rt.rowbase[(size_t)f * h + y] = base;
         rp[y] = y;                                       // the run that starts at x = 0
