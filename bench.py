@@ -574,8 +574,8 @@ def main():
             try:
                 pmc = json.load(open(files[-1]))
                 row = pmc[{"cnn_conv2": "cnn_conv2", "cnn_conv4": "cnn_conv4"}.get(stage, stage)]
-                src = "%s (head %s, %s; FETCH_SIZE x2 where the loads are 16 B per lane: %s)" % (
-                    os.path.relpath(files[-1], ROOT), pmc.get("_head", "?"), pmc.get("_date", "?"), row.get("wide_loads"))
+                src = "%s (collected at head %s on %s; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE counts half the bytes at every load width: profiles/r04_fetch_calib.txt)" % (
+                    os.path.relpath(files[-1], ROOT), pmc.get("_head", "?"), pmc.get("_date", "?"))
                 return int(row["hbm_bytes_corrected"] * per_launch), src
             except (KeyError, ValueError, OSError):
                 return None, None
@@ -663,7 +663,9 @@ def main():
                 med = ctx.median15(batch)
                 ms, _ = ctx.timing_get("median")
                 ctx.timing_enable(False)
-                k1[name] = dict(us_per_frame=round(1e3 * ms / 8, 2), thresholds_per_tile=round(thresholds_per_tile(med), 2))
+                k1[name] = dict(us_per_frame=round(1e3 * ms / 8, 2), radix_thresholds_per_tile=round(thresholds_per_tile(med), 2))
+            k1["note"] = ("8 frames per launch; radix_thresholds_per_tile = distinct prefixes per level of the medians, what a pure radix "
+                          "descent evaluates -- flat tiles take the linear scan instead since round 4 (DESIGN.md 4)")
             out_line["k1_content"] = k1
             # SURVEY 8f rank 3 on the same film: SfContours.find_stones and StonesFinder.find_intersections, 64 goban images
             # per call, images resident in HBM (foreground masks from a model run over those frames in order)
