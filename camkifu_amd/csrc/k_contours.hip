@@ -54,7 +54,7 @@ struct FrameTab {        // device-side per-frame counters
 };
 
 #ifndef CCL_LIST_BLOCKS
-#define CCL_LIST_BLOCKS 48
+#define CCL_LIST_BLOCKS 32      // 16 .. 128 measured in round 4 (ccl per frame: 16: 4.36, 24: 4.42, 32: 4.35, 48: 4.5, 128: 4.98 us)
 #endif
 constexpr int LIST_BLOCKS = CCL_LIST_BLOCKS;          // grid-stride blocks per frame for the list kernels
 #ifndef CK_HOUGH_THREADS
