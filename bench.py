@@ -255,7 +255,7 @@ def launch_check(kind):
     if rank == 0:
         print(json.dumps({"launch_check": True, "world": world, "local_rank": int(os.environ["LOCAL_RANK"]), "sum": float(t.item())}))
     else:
-        print("rank %d of %d is up" % (rank, world))
+        print("rank %d of %d is up (LOCAL_RANK %s, MASTER_ADDR %s)" % (rank, world, os.environ.get("LOCAL_RANK"), os.environ.get("MASTER_ADDR")))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -24,15 +24,15 @@ def test_plain_command_starts_its_ranks_and_relays_one_line():
     assert len(lines) == 1, p.stdout                       # stdout is rank 0's ONE line; the other ranks talk on stderr
     out = json.loads(lines[0])
     assert out == {"launch_check": True, "world": 2, "local_rank": 0, "sum": 3.0}
-    assert "rank 1 of 2 is up" in p.stderr
+    assert "rank 1 of 2 is up (LOCAL_RANK 1" in p.stderr
 
 
 def test_four_ranks_get_their_own_local_rank():
     p, _ = _run("--gpus", "4", "--launch-check", "ok")
     assert p.returncode == 0, p.stderr[-2000:]
     assert json.loads(p.stdout.strip().splitlines()[-1])["sum"] == 10.0
-    for r in (1, 2, 3):
-        assert "rank %d of 4 is up" % r in p.stderr
+    for r in (1, 2, 3):                                    # every child got its own RANK and LOCAL_RANK (= its GPU), loopback rendezvous
+        assert "rank %d of 4 is up (LOCAL_RANK %d, MASTER_ADDR 127.0.0.1)" % (r, r) in p.stderr
 
 
 def test_a_rank_that_dies_fails_the_command_and_nobody_is_left_waiting():

@@ -521,3 +521,37 @@ def test_hold_off_aware_pipeline_equals_the_eager_one_and_computes_a_fraction_of
     assert sum(lazy["asked"]) == lazy["fetched"], (sum(lazy["asked"]), lazy["fetched"])
     assert lazy["looked"] <= lazy["fetched"] <= lazy["looked"] + 0.15 * total < 0.4 * total, (lazy["looked"], lazy["fetched"], total)
     assert lazy["calls"] <= 2 * (total // 50 + 2)                    # a request or two per window
+
+
+def test_every_worker_thread_of_rank_r_starts_on_gpu_r(monkeypatch):
+    """nothing has ever run with local_rank > 0 (one-GPU boxes).  torch's current device is per-thread state
+    and a new thread starts on device 0, so every pool the pipeline creates has an initializer that selects the rank's
+    GPU: checked here with torch.cuda stubbed out -- a pool for device 3 must call set_device(3) on ITS thread before the
+    first task, and a pipeline built over contexts of device 5 must hand 5 to all of its pools."""
+    import threading
+    import torch
+    calls = []
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: calls.append((threading.get_ident(), d)))
+    pool = pipeline._pool(1, 3)
+    worker = pool.submit(threading.get_ident).result()
+    pool.shutdown()
+    assert (worker, 3) in calls and worker != threading.get_ident()
+    assert pipeline._on_device(None) is None                   # stand-in contexts (CPU tests): nothing to select
+
+    from camkifu_amd import capi
+
+    class _Ctx(capi.Context):                                   # a real Context type without a library behind it
+        def __init__(self, device):
+            self.device = device
+
+        def __del__(self):
+            pass
+    made, real_pool = [], pipeline._pool
+    monkeypatch.setattr(pipeline, "_pool", lambda k, dev: (made.append(dev), real_pool(k, None))[1])
+    lanes = [(_Ctx(5), _Ctx(5)), (_Ctx(5), _Ctx(5))]
+    core = pipeline.GpuCore(lanes, bg_ctx=_Ctx(5))
+    pipe = pipeline.FastFilePipeline(H, W, ControllerHeadless(), compute=core)
+    assert core.device == 5 and pipe.gpu == 5 and made and set(made) == {5}
+    pipe.close()
+    core.close()
