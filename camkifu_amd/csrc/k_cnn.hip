@@ -105,9 +105,12 @@ constexpr float H2_WSCALE = 256.f;      // split-precision mode: weights are sto
 #endif                    // summed into g_h2_prof and printed by the host after the launch
 #if H2_DBG_TIME
 __device__ unsigned long long g_h2_prof[8];
+__device__ unsigned long long g_h34_prof[8];
+#define H34_STAMP(K) do { if (NXT_W > 0 && threadIdx.x == 0) { const unsigned long long now__ = wall_clock64(); atomicAdd(&g_h34_prof[K], now__ - t_prev__); t_prev__ = now__; } } while (0)
 #define H2_STAMP(K) do { if (FUSE1 && threadIdx.x == 0) { const unsigned long long now__ = wall_clock64(); atomicAdd(&g_h2_prof[K], now__ - t_prev__); t_prev__ = now__; } } while (0)
 #else
 #define H2_STAMP(K) do { } while (0)
+#define H34_STAMP(K) do { } while (0)
 #endif
 #ifndef H2_PRIO
 #define H2_PRIO 1         // wave priority 3 outside the k-loop (staging, fused conv1, epilogue), 0 inside: see conv_h2_body
@@ -878,6 +881,7 @@ __device__ __forceinline__ void conv_h2_body(
     }
     if constexpr (!IN_LDS) __syncthreads();
     H2_STAMP(1);                                              // conv1 tiles done (all waves)
+    H34_STAMP(4);                                             // conv3: input staged
 
     const int tile0 = tile_blk + wm * R;
     int abase[R], axr[R];
@@ -1063,6 +1067,7 @@ __device__ __forceinline__ void conv_h2_body(
     if constexpr (H2_PRIO != 0) __builtin_amdgcn_s_setprio(3);
     if constexpr (NXT_W > 0) __syncthreads();          // every wave is done with the input tile the output overlays
     H2_STAMP(2);                                       // wave 0's k-loop
+    H34_STAMP(5);                                      // conv3: k-loop + barrier
     if (idle) return;
 
 #pragma unroll
@@ -1083,6 +1088,8 @@ __device__ __forceinline__ void conv_h2_body(
             }
         } else if constexpr (NXT_W > 0) {
             static_assert(NT * 16 == NXT_CINP && M == NXT_W * NXT_W, "the next layer's tile holds exactly this layer's output");
+            // (round 4: this relayout was 6.3 of the conv3 phase's 20 us per workgroup -- a division and a remainder by
+            // NXT_W per stored VALUE; the four pixels a lane holds are consecutive, so one division per tile does)
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 float v[4];
@@ -1095,14 +1102,16 @@ __device__ __forceinline__ void conv_h2_body(
                 h2v hi2[2], lo2[2];
                 split_h2x2(v[0], v[1], hi2[0], lo2[0]);
                 split_h2x2(v[2], v[3], hi2[1], lo2[1]);
+                const int m0 = (tile0 + r) * 16 + 4 * kq;
+                int y = m0 / NXT_W, x = m0 - y * NXT_W;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const int m = (tile0 + r) * 16 + 4 * kq + e;
-                    if (r < nv && m < M) {
-                        _Float16* d = &lds[(m / NXT_W) * NXT_RS + (m % NXT_W) * NXT_PS + co];
+                    if (r < nv && m0 + e < M) {
+                        _Float16* d = &lds[y * NXT_RS + x * NXT_PS + co];
                         d[0] = hi2[e >> 1][e & 1];
                         d[NXT_CINP] = lo2[e >> 1][e & 1];
                     }
+                    if (++x == NXT_W) { x = 0; y++; }
                 }
             }
         } else {
@@ -1123,6 +1132,7 @@ __device__ __forceinline__ void conv_h2_body(
         if (overflow && !(nxt_big <= 65000.f)) *overflow = 1;
     }
     H2_STAMP(3);                                       // epilogue
+    H34_STAMP(6);                                      // conv3: outputs split into conv4's tile
 #if H2_DBG_TIME
     if (FUSE1 && threadIdx.x == 0) atomicAdd(&g_h2_prof[7], 1ull);
 #endif
@@ -1152,11 +1162,26 @@ __global__ __launch_bounds__(64 * 2 * (6 / H2C34_RN), H2C34_MINW) void conv34_h2
     constexpr int T3 = h2_tile_halves<16, 16, 32, 3, 3, 13, false, false>(), T4 = h2_tile_halves<14, 14, 90, 3, 3, 9, true, false>();
     constexpr int PS4 = 2 * 96 + h2_pspad<96, true>(), RS4 = lds_stride_b(14 * PS4, h2_rsrem<96, true, 12>(), 64);
     __shared__ __attribute__((aligned(16))) _Float16 lds[T3 > T4 ? T3 : T4];
+#if H2_DBG_TIME
+    const unsigned long long t0__ = wall_clock64();
+#endif
     conv_h2_body<16, 16, 32, 3, 3, 90, 13, 1, 2, H2C34_RN, false, H2C3_PF, H2C3_SB, false, false, false, 14, PS4, RS4, 96>(
         lds, blockIdx.x, 0, in, wt3, bias3, nullptr, wscale_inv, overflow);
+#if H2_DBG_TIME
+    const unsigned long long t1__ = wall_clock64();
+#endif
     __syncthreads();
+#if H2_DBG_TIME
+    const unsigned long long t2__ = wall_clock64();
+#endif
     conv_h2_body<14, 14, 90, 3, 3, 90, 9, 1, 2, H2C34_RN, true, H2C34_PF, true, false, false, true>(
         lds, blockIdx.x, 0, nullptr, wt4, bias4, out, wscale_inv, overflow);
+#if H2_DBG_TIME
+    if (threadIdx.x == 0) {
+        atomicAdd(&g_h34_prof[0], t1__ - t0__); atomicAdd(&g_h34_prof[1], t2__ - t1__); atomicAdd(&g_h34_prof[2], wall_clock64() - t2__);
+        atomicAdd(&g_h34_prof[3], 1ull);
+    }
+#endif
 }
 
 // conv1 in split-precision mode.  The u8 pixels are exact in fp16, so only the weights are split and a product
@@ -1849,6 +1874,17 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             // conv3 + conv4 of a patch in one workgroup; pooled 6x6x90 written directly
             hipLaunchKernelGGL(conv34_h2_kernel, dim3(np), dim3(64 * 2 * (6 / H2C34_RN)), (size_t)lds_pad_conv34(), ctx->stream, (const float*)p2, (const uint16_t*)W.c3w_h2.p,
                                (const float*)W.c3b.p, (const uint16_t*)W.c4w_h2.p, (const float*)W.c4b.p, p4, 1.f / H2_WSCALE, d_nonfinite);
+#if H2_DBG_TIME
+            {
+                unsigned long long hp[8];
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_h34_prof), sizeof hp);
+                if (hp[3]) fprintf(stderr, "[conv3+4 phases, us per workgroup over %llu workgroups] stage + conv3 + relayout (wave 0) %.2f (stage %.2f, k-loop %.2f, relayout %.2f)  barrier %.2f  conv4 + epilogue %.2f\n",
+                                   hp[3], hp[0] * 0.01 / hp[3], hp[4] * 0.01 / hp[3], hp[5] * 0.01 / hp[3], hp[6] * 0.01 / hp[3], hp[1] * 0.01 / hp[3], hp[2] * 0.01 / hp[3]);
+                memset(hp, 0, sizeof hp);
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_h34_prof), hp, sizeof hp);
+            }
+#endif
         } else {
             {
                 TimeScope ts(ctx, "cnn_conv3");

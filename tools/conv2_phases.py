@@ -10,5 +10,5 @@ ctx.cnn_regions(g)
 ctx.timing_enable(True); ctx.timing_reset()
 for _ in range(3):
     ctx.cnn_regions(g)
-ms, cnt = ctx.timing_get("cnn_conv2")
-print("conv1+2: %.2f us per frame" % (1e3 * ms / (cnt * 64)))
+ms, cnt = ctx.timing_get("cnn_conv2"); ms4, _ = ctx.timing_get("cnn_conv4")
+print("conv1+2: %.2f us per frame, conv3+4: %.2f" % (1e3 * ms / (cnt * 64), 1e3 * ms4 / (cnt * 64)))
