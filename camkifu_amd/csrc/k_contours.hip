@@ -802,6 +802,65 @@ __global__ __launch_bounds__(256) void gather_points_kernel(const uint8_t* __res
     }
 }
 
+// The same gather into one SEGMENT PER FRAME (round 4): frame f appends to seg[f * cap ...] through its own counter fcnt[f],
+// so the waves of different frames no longer queue on ONE counter word (40 000 returning atomics per 128-frame call:
+// 150 us of the kernel's 150).  compact_points_kernel then makes the dense list the host copies.
+__global__ __launch_bounds__(256) void gather_segments_kernel(const uint8_t* __restrict__ ez, int h, int w,
+                                                              const int32_t* __restrict__ labels, const int32_t* __restrict__ compid,
+                                                              int maxc, const uint8_t* __restrict__ want, int wpitch, const FrameTab* __restrict__ tab,
+                                                              const int32_t* __restrict__ blist, int32_t* __restrict__ fcnt, int cap,
+                                                              int32_t* __restrict__ seg /* per frame: cap x (x|y<<16, slot) */)
+{
+    int f, bx;
+    list_frame_block(LIST_BLOCKS, f, bx);
+    const int nb = tab[f].n_border;
+    const size_t off = (size_t)f * h * w;
+    const int32_t* B = blist + off;
+    int32_t* out = seg + (size_t)f * cap * 2;
+    const int trips = (nb + LIST_BLOCKS * 256 - 1) / (LIST_BLOCKS * 256);       // uniform trip count
+    for (int t = 0; t < trips; t++) {
+        const int i = t * LIST_BLOCKS * 256 + bx * 256 + threadIdx.x;
+        bool take = false;
+        int p = 0, slot = 0;
+        if (i < nb) {
+            p = B[i];
+            slot = compid[off + labels[off + p]];
+            take = want[(size_t)f * wpitch + slot] && !mid_of_run(ez + off, p, w);
+        }
+        const int k = wave_append(fcnt + f, take);
+        if (take && k < cap) {
+            const int y = p / w, x = p - y * w;
+            out[2 * (size_t)k] = x | (y << 16);
+            out[2 * (size_t)k + 1] = slot;
+        }
+    }
+}
+
+// segments -> the dense arrays gather_points_kernel writes: pts[2 k], pts[2 k + 1] = (x | y << 16, slot), pts[2 gcap + k] = frame;
+// total[0] = points, total[1] = 1 if some frame had more points than its segment holds (the host then falls back)
+__global__ __launch_bounds__(256) void compact_points_kernel(const int32_t* __restrict__ fcnt, int n, int cap, const int32_t* __restrict__ seg,
+                                                             int gcap, int32_t* __restrict__ pts, int32_t* __restrict__ total)
+{
+    const int f = blockIdx.x;
+    int base = 0, over = 0;
+    for (int g = 0; g < n; g++) {                          // n <= a few hundred: every block adds up the counts before it
+        const int c = fcnt[g];
+        over |= c > cap;
+        if (g < f) base += c < cap ? c : cap;
+    }
+    const int mine = fcnt[f] < cap ? fcnt[f] : cap;
+    if (f == n - 1 && threadIdx.x == 0) { total[0] = base + mine; total[1] = over; }
+    const int32_t* in = seg + (size_t)f * cap * 2;
+    for (int i = threadIdx.x; i < mine; i += 256) {
+        const int k = base + i;
+        if (k < gcap) {
+            pts[2 * (size_t)k] = in[2 * (size_t)i];
+            pts[2 * (size_t)k + 1] = in[2 * (size_t)i + 1];
+            pts[2 * (size_t)gcap + k] = f;
+        }
+    }
+}
+
 // every outer-border pixel of every map with the slot of its contour, at a position known in advance (survey only)
 __global__ __launch_bounds__(256) void survey_points_kernel(int h, int w, const int32_t* __restrict__ labels, const int32_t* __restrict__ compid,
                                                             const FrameTab* __restrict__ tab, const int32_t* __restrict__ blist,
@@ -1255,15 +1314,38 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         {
             TimeScope ts(ctx, "contour_gather");
             CK_HIP(ctx, hipMemcpyAsync(d_want, want.data(), (size_t)n * nc_max, hipMemcpyHostToDevice, ctx->stream));
-            CK_HIP(ctx, hipMemsetAsync(d_counter, 0, 4, ctx->stream));
-            hipLaunchKernelGGL(gather_points_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w,
+            // one segment per frame + compaction; a frame with more points than its segment holds (never seen: a
+            // segment is gcap / n >= 32 768 points at 1080p) sends the round through the single-counter kernel instead
+            const int segcap = gcap / n;
+            CK_TRY(ck_ensure(ctx, ctx->accum, (size_t)n * segcap * 8 + (size_t)n * 4 + 64));
+            int32_t* d_seg = (int32_t*)ctx->accum.p;
+            int32_t* d_fcnt = d_seg + (size_t)n * segcap * 2;
+            CK_HIP(ctx, hipMemsetAsync(d_fcnt, 0, (size_t)n * 4, ctx->stream));
+            CK_HIP(ctx, hipMemsetAsync(d_counter, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(gather_segments_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w,
                                (const int32_t*)L, (const int32_t*)compid, maxc, (const uint8_t*)d_want, nc_max,
-                               (const FrameTab*)d_tab, (const int32_t*)blist, d_counter, gcap, d_pts, 0);
+                               (const FrameTab*)d_tab, (const int32_t*)blist, d_fcnt, segcap, d_seg);
+            hipLaunchKernelGGL(compact_points_kernel, dim3(n), dim3(256), 0, ctx->stream, (const int32_t*)d_fcnt, n, segcap,
+                               (const int32_t*)d_seg, gcap, d_pts, d_counter);
             CK_HIP(ctx, hipGetLastError());
         }
         int npts = 0;
-        CK_HIP(ctx, hipMemcpyAsync(&npts, d_counter, 4, hipMemcpyDeviceToHost, ctx->stream));
-        CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        {
+            int two[2] = {0, 0};
+            CK_HIP(ctx, hipMemcpyAsync(two, d_counter, 8, hipMemcpyDeviceToHost, ctx->stream));
+            CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            npts = two[0];
+            if (two[1]) {                                   // a segment overflowed: the whole round again, one counter for all
+                TimeScope ts(ctx, "contour_gather");
+                CK_HIP(ctx, hipMemsetAsync(d_counter, 0, 4, ctx->stream));
+                hipLaunchKernelGGL(gather_points_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w,
+                                   (const int32_t*)L, (const int32_t*)compid, maxc, (const uint8_t*)d_want, nc_max,
+                                   (const FrameTab*)d_tab, (const int32_t*)blist, d_counter, gcap, d_pts, 0);
+                CK_HIP(ctx, hipGetLastError());
+                CK_HIP(ctx, hipMemcpyAsync(&npts, d_counter, 4, hipMemcpyDeviceToHost, ctx->stream));
+                CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
+        }
         if (npts > gcap) return ck_fail(ctx, CK_ERR_CAPACITY, "too many contour points (%d > %d)", npts, gcap);
         std::vector<int32_t> hp((size_t)npts * 2), hf((size_t)npts);
         if (npts) {
