@@ -312,17 +312,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")      # where collective buffers live
+    from camkifu_amd.pipeline import rccl_group_options
     with stdout_to_stderr():
         if world > 1:
             if args.dist_backend == "nccl":
-                dist.init_process_group("nccl", device_id=dev)
+                dist.init_process_group("nccl", device_id=dev, pg_options=rccl_group_options())
             else:
                 dist.init_process_group(args.dist_backend)
         elif args.force_exchange:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29577")
             if args.dist_backend == "nccl":
-                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=rccl_group_options())
             else:
                 dist.init_process_group(args.dist_backend, rank=0, world_size=1)
         if dist.is_initialized():
@@ -333,7 +334,9 @@ def main():
     from camkifu_amd.stone.nn_manager import NNManager, KERAS_MODEL_FILE
     H, W, F = args.height, args.width, args.frames
     lanes = [(capi.Context(local_rank), capi.Context(local_rank)) for _ in range(args.lanes)]
-    ctx_bg = capi.Context(local_rank)
+    # the background model's context sits in the exchange stage's dependent chain: its stream at high priority, like that
+    # stage's torch stream and the communicator's (pipeline._exchange)
+    ctx_bg = capi.Context(local_rank, priority=0 if "0" in (os.environ.get("CK_EXCHANGE_PRIORITY"), os.environ.get("CK_BG_PRIORITY")) else 1)
     ctx_b, ctx = lanes[0]
 
     # ---- ONE synthetic game filmed by a fixed camera, world * F frames; this rank renders its frames into HBM -------

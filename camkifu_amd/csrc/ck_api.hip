@@ -146,7 +146,8 @@ int ck_goban_canny_dev(ck_ctx* ctx, const uint8_t* d_in, int n, int h, int w, ui
     // medianBlur 13, then 7 (the kernel reads interleaved BGR and writes planes)
     CK_TRY(k_median_planar(ctx, d_in, n, h, w, 13, (uint8_t*)ctx->planes.p, pitch));
     CK_TRY(k_planar_to_interleaved(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, (uint8_t*)ctx->out_stage.p));
-    CK_TRY(k_median_planar(ctx, (const uint8_t*)ctx->out_stage.p, n, h, w, 7, (uint8_t*)ctx->planes.p, pitch));
+    CK_TRY(ck_ensure(ctx, ctx->trange, ck_range_bytes(n, h, w)));
+    CK_TRY(k_median_planar(ctx, (const uint8_t*)ctx->out_stage.p, n, h, w, 7, (uint8_t*)ctx->planes.p, pitch, (uint8_t*)ctx->trange.p));
     // grey histogram per frame -> Otsu level on the host (256 bins, double arithmetic as the library does it)
     CK_TRY(ck_ensure(ctx, ctx->misc, (size_t)n * 256 * 4 + (size_t)n * 64 + 4096));
     int* d_hist = (int*)ctx->misc.p;
@@ -169,7 +170,7 @@ int ck_goban_canny_dev(ck_ctx* ctx, const uint8_t* d_in, int n, int h, int w, ui
     CK_HIP(ctx, hipMemcpyAsync(d_thr, thr.data(), thr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     CK_HIP(ctx, hipStreamSynchronize(ctx->stream));           // thr is a local: the copy must be done before it goes
     return k_canny_planar(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, 0, 0, (uint8_t*)ctx->map.p,
-                          (int32_t*)ctx->labels.p, d_edges, nullptr, nullptr, d_thr);
+                          (int32_t*)ctx->labels.p, d_edges, nullptr, nullptr, d_thr, (const uint8_t*)ctx->trange.p);
 }
 
 extern "C" {
@@ -221,7 +222,7 @@ void ck_ctx_destroy(ck_ctx* ctx)
     }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = { &ctx->in_stage, &ctx->in_stage2, &ctx->planes, &ctx->edges, &ctx->map, &ctx->labels,
+    DevBuf* bufs[] = { &ctx->in_stage, &ctx->in_stage2, &ctx->planes, &ctx->trange, &ctx->edges, &ctx->map, &ctx->labels,
                        &ctx->labels2, &ctx->runs, &ctx->ghost, &ctx->misc, &ctx->bflag, &ctx->comp, &ctx->lists, &ctx->pts, &ctx->accum, &ctx->peaks,
                        &ctx->goban, &ctx->act0, &ctx->act1, &ctx->act2, &ctx->ybuf, &ctx->lblbuf, &ctx->confbuf,
                        &ctx->rlblbuf, &ctx->rconfbuf, &ctx->fgcbuf,
@@ -384,9 +385,11 @@ static int board_edges_dev(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int 
     CK_TRY(ck_ensure(ctx, ctx->planes, (size_t)n * 3 * h * pitch));
     CK_TRY(ck_ensure(ctx, ctx->map, npx));
     CK_TRY(ck_ensure(ctx, ctx->labels, npx * 4));
-    CK_TRY(k_median15_planar(ctx, d_bgr, n, h, w, (uint8_t*)ctx->planes.p, pitch));
+    CK_TRY(ck_ensure(ctx, ctx->trange, ck_range_bytes(n, h, w)));
+    CK_TRY(k_median15_planar(ctx, d_bgr, n, h, w, (uint8_t*)ctx->planes.p, pitch, (uint8_t*)ctx->trange.p));
     CK_TRY(k_canny_planar(ctx, (const uint8_t*)ctx->planes.p, n, h, w, pitch, 25, 75,
-                          (uint8_t*)ctx->map.p, (int32_t*)ctx->labels.p, d_edges, nullptr, d_border_flag));
+                          (uint8_t*)ctx->map.p, (int32_t*)ctx->labels.p, d_edges, nullptr, d_border_flag, nullptr,
+                          (const uint8_t*)ctx->trange.p));
     return CK_OK;
 }
 

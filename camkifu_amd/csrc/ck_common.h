@@ -68,6 +68,7 @@ struct ck_ctx {
     DevBuf in_stage;     // staged host input
     DevBuf in_stage2;
     DevBuf planes;       // median output, planar n*3*h*pitch
+    DevBuf trange;       // value bounds of the median's tiles (ck_range_bytes)
     DevBuf edges;        // n*h*w
     DevBuf map;          // n*h*w NMS map
     DevBuf labels;       // n*h*w int32 union-find parents
@@ -211,16 +212,27 @@ int ck_from_device(ck_ctx* ctx, void* dst, const void* dev, size_t bytes, int sp
 static inline int ck_pitch(int w) { return (w + 63) & ~63; }
 
 // ---- kernels (one launcher per stage; all asynchronous on ctx->stream) -----------------
-int k_median15_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, uint8_t* d_planes, int pitch);
+// d_range (nullable): per (frame, channel, CK_RANGE_TILE^2 tile) two bytes lo, hi with lo <= every median of the tile <= hi
+// (n * 3 * ceil(h / T) * ceil(w / T) * 2 bytes; what k_canny_planar takes to skip its flat tiles)
+#define CK_RANGE_TILE 48
+#ifndef CK_TILE_RANGE
+#define CK_TILE_RANGE 1        // 0: no bounds written, no tile skipped (A/B builds)
+#endif
+static inline size_t ck_range_bytes(int n, int h, int w)
+{
+    return (size_t)n * 3 * ((h + CK_RANGE_TILE - 1) / CK_RANGE_TILE) * ((w + CK_RANGE_TILE - 1) / CK_RANGE_TILE) * 2;
+}
+int k_median15_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, uint8_t* d_planes, int pitch, uint8_t* d_range = nullptr);
 int k_gray_hist(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, int* d_hist);
-int k_median_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int ksize, uint8_t* d_planes, int pitch);
+int k_median_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int ksize, uint8_t* d_planes, int pitch, uint8_t* d_range = nullptr);
 int k_planar_to_interleaved(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, uint8_t* d_out);
 int k_interleaved_to_planar(ck_ctx* ctx, const uint8_t* d_in, int n, int h, int w, int pitch, uint8_t* d_planes);
 // canny: planar 3-channel input -> map (0/1/2) -> edges (0/255); labels = scratch n*h*w int32
 // d_border_flag (nullable, n ints): set to 1 for frames that have an edge pixel on the image frame
 int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, int low, int high,
                    uint8_t* d_map, int32_t* d_labels, uint8_t* d_edges, uint8_t* d_map_out, int* d_border_flag = nullptr,
-                   const int* d_thr = nullptr /* per-frame (low, high) pairs on the device, override low / high */);
+                   const int* d_thr = nullptr /* per-frame (low, high) pairs on the device, override low / high */,
+                   const uint8_t* d_range = nullptr /* value bounds of the planes' tiles, from k_median_planar */);
 int k_i420_to_bgr(ck_ctx* ctx, const uint8_t* d_i420, int n, int h, int w, uint8_t* d_bgr);
 int k_warp(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, const double* d_minv, int m_count,
            int dsize, uint8_t* d_out);

@@ -45,6 +45,7 @@ constexpr int TW = 64;
 #ifndef NMS_STOP
 #define NMS_STOP 0         // profiling aid (tools/pmc_serial.sh): leave the kernel after phase n -- results are then WRONG
 #endif
+constexpr int RANGE_TILE = CK_RANGE_TILE;    // edge of the tiles the value bounds of k_median_planar refer to
 constexpr int PK = NMS_PK;                   // gradient rows per thread
 constexpr int PGR = 15 * PK;                 // gradient rows (1-px halo)
 constexpr int PTH = PGR - 2;                 // output rows per tile
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
                                                                int low, int high, uint8_t* __restrict__ map,
                                                                int32_t* __restrict__ labels, int32_t* __restrict__ cand,
                                                                int* __restrict__ cand_count, uint8_t* __restrict__ edges_zero,
-    const int* __restrict__ thr /* nullable: per-frame (low, high) pairs */)
+    const int* __restrict__ thr /* nullable: per-frame (low, high) pairs */,
+    const uint8_t* __restrict__ trange /* nullable: (low bound, high bound) of the pixels of every RANGE_TILE^2 tile */, int trw, int trh)
 {
     // XCD-aware tile order.  Workgroups go round-robin over the 8 XCDs by their linear id, so with the plain (x, y, frame)
     // mapping the eight horizontal neighbours of a tile row sit on eight different L2s and every halo line (a tile row
@@ -117,6 +119,42 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
     const int tid = threadIdx.x;
     const uint8_t* base = planes + (size_t)f * 3 * h * pitch;
     if (tid == 0) ccount = 0;
+
+    // Flat tile (round 4): the producer of the planes (the median kernel) leaves, per tile of its own and channel, bounds
+    // lo <= every pixel <= hi.  A Sobel response is at most 4 (hi - lo) per direction, so where the tiles under this
+    // tile's pixel region (2-px halo, replicated at the frame's rim: no new values) span R levels with 8 R <= low, no
+    // magnitude exceeds `low`: no candidate, map = 1, nothing to stage or to compute.  On a board frame that is 46 % of
+    // the tiles (paper, table, wood between the lines).
+    if (trange) {
+        bool flat = low >= 0;
+        if (tid < 3 && flat) {
+            const int xa = (ox - 2 < 0 ? 0 : ox - 2) / RANGE_TILE, xb = (ox + TW + 1 > w - 1 ? w - 1 : ox + TW + 1) / RANGE_TILE;
+            const int ya = (oy - 2 < 0 ? 0 : oy - 2) / RANGE_TILE, yb = (oy + PTH + 1 > h - 1 ? h - 1 : oy + PTH + 1) / RANGE_TILE;
+            int lo = 255, hi = 0;
+            for (int ty = ya; ty <= yb; ty++)
+                for (int tx = xa; tx <= xb; tx++) {
+                    const uint8_t* pr = trange + ((size_t)((f * 3 + tid) * trh + ty) * trw + tx) * 2;
+                    lo = lo < pr[0] ? lo : pr[0];
+                    hi = hi > pr[1] ? hi : pr[1];
+                }
+            flat = 8 * (hi - lo) <= low;
+        }
+        if (__syncthreads_and(flat)) {
+            for (int q = tid; q < PTH * 16; q += 256) {
+                const int y = oy + (q >> 4), x0 = ox + (q & 15) * 4;
+                if (y >= h) break;
+                const size_t idx = ((size_t)f * h + y) * w + x0;
+                if (x0 + 3 < w && ((idx & 3) == 0)) {
+                    *reinterpret_cast<uint32_t*>(map + idx) = 0x01010101u;
+                    *reinterpret_cast<uint32_t*>(edges_zero + idx) = 0u;
+                } else {
+                    for (int k = 0; k < 4; k++)
+                        if (x0 + k < w) { map[idx + k] = 1; edges_zero[idx + k] = 0; }
+                }
+            }
+            return;
+        }
+    }
 
     const uint32_t plane = (uint32_t)h * pitch;
     if (ox >= 8 && ox + TW + 8 <= w && oy >= 2 && oy + PTH + 2 <= h) {
@@ -875,9 +913,12 @@ __global__ __launch_bounds__(256) void canny_final_kernel(int h, int w, const in
 
 int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, int low, int high,
                    uint8_t* d_map, int32_t* d_labels, uint8_t* d_edges, uint8_t* d_map_out, int* d_border_flag,
-                   const int* d_thr)
+                   const int* d_thr, const uint8_t* d_range)
 {
     if (low > high) { int t = low; low = high; high = t; }
+#if !CK_TILE_RANGE
+    d_range = nullptr;
+#endif
     const size_t npx = (size_t)n * h * w;
     CK_TRY(ck_ensure(ctx, ctx->labels2, npx * 4));                 // candidate lists (one slab per frame)
     CK_TRY(ck_ensure(ctx, ctx->misc, (size_t)n * 64 + 4096));
@@ -893,7 +934,8 @@ int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, in
 #else
         dim3 grid((w + TW - 1) / TW, (h + PTH - 1) / PTH, n);
         hipLaunchKernelGGL(canny_nms_packed_kernel, grid, dim3(256), 0, ctx->stream, d_planes, h, w, pitch, low, high, d_map,
-                           d_labels, d_cand, d_count, d_edges, d_thr);
+                           d_labels, d_cand, d_count, d_edges, d_thr, d_range, (w + RANGE_TILE - 1) / RANGE_TILE,
+                           (h + RANGE_TILE - 1) / RANGE_TILE);
 #endif
         CK_HIP(ctx, hipGetLastError());
     }

@@ -273,9 +273,10 @@ __device__ __forceinline__ int imed3(int a, int b, int c)
 // K = window edge (odd, 3..17: a 64-pixel input tile must cover 48 + K - 1); rank (K*K+1)/2, halo K/2.
 template <int K>
 __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void median_mfma_kernel(
-    const uint8_t* __restrict__ in, int h, int w, uint8_t* __restrict__ out, int pitch)
+    const uint8_t* __restrict__ in, int h, int w, uint8_t* __restrict__ out, int pitch, uint8_t* __restrict__ range)
 {
     static_assert(K % 2 == 1 && K >= 3 && MT + K - 1 <= 64, "window size");
+    static_assert(MT == CK_RANGE_TILE, "the value bounds are per tile of this kernel");
     constexpr int HK = K / 2, RANK = (K * K + 1) / 2;
     __shared__ uint32_t flags[3][64];
     const int lane = threadIdx.x;
@@ -460,6 +461,7 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
 #endif
     constexpr int SCAN_RANGE = MED_SCAN_RANGE, SCAN_CAP = MED_SCAN_CAP;
     bool done = false;
+    int lo_bound = 0, hi_bound = 255;       // lo_bound <= every median of the tile <= hi_bound (-> range)
     MED_COUNT(0, 1);
     {
         // 4 samples per lane: rows 16 g + {1, 6, 9, 14} of columns n, 16 + n, 32 + n, 48 + n (inverted bytes)
@@ -503,7 +505,8 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
             unsigned up = 7u, down = 0u;                             // row blocks still scanning in each direction
             int steps = 0;
             bool gave_up = false;
-            for (int thr = g0; up && thr <= 254; thr++, steps++) {
+            int thr = g0;
+            for (; up && thr <= 254; thr++, steps++) {
                 if (steps == SCAN_CAP) { gave_up = true; break; }
                 const bool here[3] = {(up & 1u) != 0, (up & 2u) != 0, (up & 4u) != 0};
                 MED_COUNT(4, __builtin_popcount(up));
@@ -513,8 +516,10 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
                 if (thr == g0) down = nonpos;                        // some median <= g: g - 1 has to be looked at
                 up = pos;
             }
+            // the upward scan ended at thr - 1 with no median above it (or ran into 255)
+            const int top = up ? 255 : thr - 1;
             steps = 0;
-            for (int thr = g0 - 1; !gave_up && down && thr >= 0; thr--, steps++) {
+            for (thr = g0 - 1; !gave_up && down && thr >= 0; thr--, steps++) {
                 if (steps == SCAN_CAP) { gave_up = true; break; }
                 const bool here[3] = {(down & 1u) != 0, (down & 2u) != 0, (down & 4u) != 0};
                 MED_COUNT(4, __builtin_popcount(down));
@@ -531,9 +536,17 @@ __attribute__((amdgpu_waves_per_eu(3))) __global__ __launch_bounds__(64) void me
                     for (int u = 0; u < 3; u++)
 #pragma unroll
                         for (int e = 0; e < 4; e++) med[t][u][e] = 0;
-            } else
+            } else {
                 done = true;
+                // the downward scan ended at thr + 1 with no median at or below it (never started: none <= g0 = thr + 1)
+                hi_bound = top;
+                lo_bound = down ? 0 : thr + 2;
+            }
         }
+    }
+    if (range && lane == 0) {
+        uint8_t* rp = range + ((size_t)((f * 3 + c) * gridDim.y + byi) * gridDim.x + bxi) * 2;
+        *reinterpret_cast<uint16_t*>(rp) = (uint16_t)(lo_bound | (hi_bound << 8));
     }
 
     // The prefixes alive at a level are kept PER ROW BLOCK of 16 output rows (bit l of ct[t][k] <-> prefix 4 l + k is held
@@ -636,12 +649,15 @@ __global__ void interleaved_to_planar_kernel(const uint8_t* __restrict__ in, int
 
 }  // namespace
 
-int k_median_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int ksize, uint8_t* d_planes, int pitch)
+int k_median_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int ksize, uint8_t* d_planes, int pitch, uint8_t* d_range)
 {
     TimeScope ts(ctx, "median");
+#if !CK_TILE_RANGE
+    d_range = nullptr;
+#endif
 #if MED_MFMA
     dim3 grid((w + MT - 1) / MT, (h + MT - 1) / MT, n * 3);
-#define CK_MEDIAN_CASE(KS) case KS: hipLaunchKernelGGL(median_mfma_kernel<KS>, grid, dim3(64), 0, ctx->stream, d_bgr, h, w, d_planes, pitch); break;
+#define CK_MEDIAN_CASE(KS) case KS: hipLaunchKernelGGL(median_mfma_kernel<KS>, grid, dim3(64), 0, ctx->stream, d_bgr, h, w, d_planes, pitch, d_range); break;
     switch (ksize) {
         CK_MEDIAN_CASE(3) CK_MEDIAN_CASE(5) CK_MEDIAN_CASE(7) CK_MEDIAN_CASE(9) CK_MEDIAN_CASE(11) CK_MEDIAN_CASE(13)
         CK_MEDIAN_CASE(15) CK_MEDIAN_CASE(17)
@@ -661,6 +677,7 @@ int k_median_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int 
 #endif
 #else
     if (ksize != 15) return ck_fail(ctx, CK_ERR_ARG, "the SWAR median kernel is 15x15 only");
+    if (d_range) CK_HIP(ctx, hipMemsetD16Async((hipDeviceptr_t)d_range, 0xFF00, ck_range_bytes(n, h, w) / 2, ctx->stream));   // no bounds: 0 .. 255
     dim3 grid((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H, n * 3);
     hipLaunchKernelGGL(median15_kernel, grid, dim3(64), 0, ctx->stream, d_bgr, h, w, d_planes, pitch);
 #endif
@@ -668,9 +685,9 @@ int k_median_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int 
     return CK_OK;
 }
 
-int k_median15_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, uint8_t* d_planes, int pitch)
+int k_median15_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, uint8_t* d_planes, int pitch, uint8_t* d_range)
 {
-    return k_median_planar(ctx, d_bgr, n, h, w, 15, d_planes, pitch);
+    return k_median_planar(ctx, d_bgr, n, h, w, 15, d_planes, pitch, d_range);
 }
 
 int k_planar_to_interleaved(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, int pitch, uint8_t* d_out)

@@ -135,6 +135,16 @@ class _Group:
         return list(torch.split(recv, [int(r) for r in recv_sizes]))
 
 
+def rccl_group_options():
+    """What a host passes as `pg_options=` to `init_process_group("nccl", ...)` for the group it hands to
+    FastFilePipeline: the communicator's own stream at high priority, like the exchange thread's (see _exchange)."""
+    import os
+    import torch.distributed as dist
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = os.environ.get("CK_EXCHANGE_PRIORITY") != "0"
+    return opts
+
+
 def _on_device(device):
     """initializer of every worker thread of the pipeline: torch's current device is per-thread state and starts at
     device 0 in a new thread -- on rank r > 0 a worker would otherwise allocate, copy and synchronise on GPU 0"""
@@ -593,7 +603,7 @@ class FastFilePipeline:
                 dev = getattr(self.ctx, "device", None)
                 if dev is None:
                     raise RuntimeError("the pixel-sharded background model needs a context of its own (ctx_bg=...)")
-                self.ctx_bg = capi.Context(dev)
+                self.ctx_bg = capi.Context(dev, priority=1)       # part of the exchange stage's chain: see _exchange
             a, b = self.band
             bg = self.ctx_bg
             handle = bg.mog2_create(min(20 * b, 380) - 20 * a, 380)
@@ -658,7 +668,11 @@ class FastFilePipeline:
         if not torch.cuda.is_available():
             return self._exchange_on_stream(t)
         if self._xstream is None:
-            self._xstream = torch.cuda.Stream(device=self.gpu)
+            # high priority: the stage's small copies and the collectives' kernels are a dependent chain of short
+            # pieces between the lanes' millisecond launches -- on a normal stream each piece can sit behind one
+            # (streams share hardware queues), and the chain, not the lanes, ends up setting the step time
+            prio = 0 if os.environ.get("CK_EXCHANGE_PRIORITY") == "0" else -1       # (developer A/B knob)
+            self._xstream = torch.cuda.Stream(device=self.gpu, priority=prio)
         with torch.cuda.stream(self._xstream):
             try:
                 return self._exchange_on_stream(t)

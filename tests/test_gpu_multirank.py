@@ -43,7 +43,7 @@ def _drive(rank, world, depth=2, force_nccl=False):
     ctrl = ControllerHeadless()
     if force_nccl:           # one rank, but every collective of the exchange stage issued for real, on device buffers over RCCL
         pipe = pipeline.FastFilePipeline(H, W, ctrl, rank=0, world=1, device=torch.device("cuda", 0), lanes=lanes,
-                                         ctx_bg=capi.Context(0), bg_init_frames=BG, force_exchange=True)
+                                         ctx_bg=capi.Context(0, priority=1), bg_init_frames=BG, force_exchange=True)
     else:
         pipe = pipeline.FastFilePipeline(H, W, ctrl, rank=rank, world=world, device=torch.device("cpu") if world > 1 else None,
                                          lanes=lanes, ctx_bg=capi.Context(0), bg_init_frames=BG)
@@ -75,7 +75,8 @@ def _run(rank, world, port, q, force_nccl=False):
     if force_nccl:
         import torch
         torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from camkifu_amd.pipeline import rccl_group_options
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0), pg_options=rccl_group_options())
     elif world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -199,17 +200,19 @@ def test_bench_from_the_plain_command_with_two_ranks():
 @pytest.mark.gpu
 def test_the_exchange_stage_does_not_gate_the_lanes():
     """The exchange thread's torch work and its waits for the collectives sit on that thread's OWN stream, so the lanes'
-    default-stream synchronisation (capi._in) never waits for an all-to-all: with the whole exchange stage issued over
-    RCCL (one rank) the job runs as fast as without it, within the run-to-run noise of one box.  Best of three each,
-    interleaved."""
+    default-stream synchronisation (capi._in) never waits for an all-to-all; and that stream, the communicator's and the
+    background model's are HIGH-PRIORITY streams, so the stage's chain of short dependent pieces does not queue behind the
+    lanes' millisecond launches (on normal streams it did, in about half the runs: 11-13 ms of waits per 12 ms step, the
+    whole job 7 % slower on average -- tools/exchange_runs.sh).  With the whole exchange stage issued over RCCL (one rank)
+    the job runs as fast as without it: four runs each, interleaved, ratio of the means."""
     args = ["--frames", "256", "--steps", "12", "--warmup", "2", "--timed-only"]
     plain, forced = [], []
-    for _ in range(3):
+    for _ in range(4):
         plain.append(_bench(*args)["value"])
         forced.append(_bench(*args, "--force-exchange")["value"])
-    ratio = max(forced) / max(plain)
-    print("\n  frames/s plain %s, with the exchange stage over RCCL %s: ratio of the best %.4f" % (plain, forced, ratio), end="")
-    assert ratio > 0.97, (plain, forced)
+    ratio = sum(forced) / sum(plain)
+    print("\n  frames/s plain %s, with the exchange stage over RCCL %s: ratio of the means %.4f" % (plain, forced, ratio), end="")
+    assert ratio > 0.95, (plain, forced)
 
 
 @pytest.mark.gpu

@@ -137,6 +137,39 @@ def test_board_edges_chain(ck, ora, synth):
     assert np.array_equal(ck.board_edges(fr), ora.canny(ora.median(fr, 15), 25, 75))
 
 
+def test_board_edges_where_flat_tiles_are_skipped(ck, ora):
+    """The NMS kernel leaves a tile whose pixel region (2-px halo) the median kernel bounded to 8 (hi - lo) <= low.
+    Faint steps of 1..8 levels and strong ones, placed on and next to the borders of the NMS tiles (64 x 28), of the
+    median tiles (48 x 48) and of their halos: every edge pixel has to survive, and none may appear."""
+    rng = np.random.default_rng(77)
+    h, w = 330, 520
+    frames = []
+    for k in range(4):
+        f = np.full((h, w, 3), 100 + 10 * k, np.int64)
+        for _ in range(14):
+            # corners near multiples of 64 / 48 (x) and 28 / 48 (y), +-3
+            x0 = int(rng.choice([64, 48]) * rng.integers(1, 6) + rng.integers(-3, 4))
+            y0 = int(rng.choice([28, 48]) * rng.integers(1, 6) + rng.integers(-3, 4))
+            x1, y1 = min(w, x0 + int(rng.integers(20, 200))), min(h, y0 + int(rng.integers(20, 150)))
+            step = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 40])) * int(rng.choice([-1, 1]))
+            f[y0:y1, x0:x1, rng.integers(0, 3)] += step
+        f += rng.integers(0, 2 + k, (h, w, 3))           # sensor noise of 0 .. k + 1 levels
+        frames.append(np.clip(f, 0, 255).astype(np.uint8))
+    frames.append(np.full((h, w, 3), 7, np.uint8))        # nothing at all
+    one = np.full((h, w, 3), 200, np.uint8)
+    one[:, 64 + 65:] = 20                                   # a strong edge two pixels behind a tile: inside its halo
+    frames.append(one)
+    frames = np.stack(frames)
+    e = ck.board_edges(frames)
+    for k in range(len(frames)):
+        assert np.array_equal(e[k], ora.canny(ora.median(frames[k], 15), 25, 75)), k
+    assert e[:4].any() and not e[4].any() and e[5].any()
+    # per-frame thresholds (Otsu) through the same kernels
+    g = ck.goban_canny(frames)
+    for k in range(len(frames)):
+        assert np.array_equal(g[k], ora.goban_canny(frames[k])), k
+
+
 # ---------------------------------------------------------------- K3..K6
 def _cmp_board(out, ghost, o):
     """out: one entry of Context.board_lines; o: oracle.board_lines dict."""
