@@ -292,6 +292,8 @@ def main():
     ap.add_argument("--launch-check", default=None, metavar="ok|fail:R",
                     help="test the N-rank launcher alone (gloo, no GPU): every rank joins a group and rank 0 prints one line")
     args = ap.parse_args()
+    if os.environ.get("CK_SWITCH_INTERVAL"):                   # (developer A/B knob: the interpreter's thread switch interval)
+        sys.setswitchinterval(float(os.environ["CK_SWITCH_INTERVAL"]))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # the plain command: be the launcher (before any GPU call)
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))

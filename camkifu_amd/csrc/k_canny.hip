@@ -121,10 +121,11 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
     if (tid == 0) ccount = 0;
 
     // Flat tile (round 4): the producer of the planes (the median kernel) leaves, per tile of its own and channel, bounds
-    // lo <= every pixel <= hi.  A Sobel response is at most 4 (hi - lo) per direction, so where the tiles under this
-    // tile's pixel region (2-px halo, replicated at the frame's rim: no new values) span R levels with 8 R <= low, no
-    // magnitude exceeds `low`: no candidate, map = 1, nothing to stage or to compute.  On a board frame that is 46 % of
-    // the tiles (paper, table, wood between the lines).
+    // lo <= every pixel <= hi.  With all nine pixels of a Sobel window within R levels, |dx| + |dy| = max(|dx + dy|, |dx - dy|)
+    // and dx + dy = 2 (i - a) + 2 (f - d) + 2 (h - b), dx - dy = 2 (c - g) + 2 (f - d) - 2 (h - b) for the window a b c /
+    // d e f / g h i: at most 6 R.  So where the tiles under this tile's pixel region (2-px halo, replicated at the frame's
+    // rim: no new values) span R levels with 6 R <= low, no magnitude exceeds `low`: no candidate, map = 1, nothing to
+    // stage or to compute.  On a board frame that is half of the tiles (paper, table, wood between the lines).
     if (trange) {
         bool flat = low >= 0;
         if (tid < 3 && flat) {
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
                     lo = lo < pr[0] ? lo : pr[0];
                     hi = hi > pr[1] ? hi : pr[1];
                 }
-            flat = 8 * (hi - lo) <= low;
+            flat = 6 * (hi - lo) <= low;
         }
         if (__syncthreads_and(flat)) {
             for (int q = tid; q < PTH * 16; q += 256) {

@@ -138,7 +138,7 @@ def test_board_edges_chain(ck, ora, synth):
 
 
 def test_board_edges_where_flat_tiles_are_skipped(ck, ora):
-    """The NMS kernel leaves a tile whose pixel region (2-px halo) the median kernel bounded to 8 (hi - lo) <= low.
+    """The NMS kernel leaves a tile whose pixel region (2-px halo) the median kernel bounded to 6 (hi - lo) <= low.
     Faint steps of 1..8 levels and strong ones, placed on and next to the borders of the NMS tiles (64 x 28), of the
     median tiles (48 x 48) and of their halos: every edge pixel has to survive, and none may appear."""
     rng = np.random.default_rng(77)
