@@ -444,6 +444,9 @@ __global__ __launch_bounds__(256) void border_list_kernel(const uint8_t* __restr
 //     stay in the dense label image, which only ever holds them at edge pixels: Canny's labels when no edge touched
 //     the image frame, rebuilt here otherwise.
 // prep then moves 2 MB in + 2.4 MB out per 1080p frame instead of 2 + 10.3.
+#ifndef CCL_PRELINK
+#define CCL_PRELINK 1
+#endif
 struct RunTab {
     unsigned long long* bits;
     uint16_t* rank;
@@ -543,7 +546,10 @@ __global__ __launch_bounds__(256) void prep_runs_kernel(const uint8_t* __restric
     base = __builtin_amdgcn_readfirstlane(base);
     if (lane == 0) {
         rt.rowbase[(size_t)f * h + y] = base;
-        rp[y] = y;                                       // the run that starts at x = 0
+        // the run that starts at x = 0.  Column 0 of the cleared frame is background in every row: these runs are one
+        // component by construction, so they start out pointing at node 0 (row 0, the root of the outer background)
+        // instead of being chained row to row by h - 1 unions
+        rp[y] = CCL_PRELINK ? 0 : y;
     }
     unsigned long long* bw = rt.bits + ((size_t)f * h + y) * rt.w64;
     uint16_t* rw = rt.rank + ((size_t)f * h + y) * rt.w64;
@@ -566,7 +572,9 @@ __global__ __launch_bounds__(256) void prep_runs_kernel(const uint8_t* __restric
                     if (nb & (1 << k)) {
                         const int p = y * w + x + k;
                         E[slot] = p;
-                        rp[h + slot] = h + slot;
+                        // the stretch right of the row's LAST edge pixel reaches column w - 1, background in every row and
+                        // joined to row 0 through it: born into the outer background as well
+                        rp[h + slot] = (CCL_PRELINK && slot == base + total - 1) ? 0 : h + slot;
                         if (!keep_edge_parents) L[(size_t)f * h * w + p] = p;
                         slot++;
                     }
@@ -575,8 +583,10 @@ __global__ __launch_bounds__(256) void prep_runs_kernel(const uint8_t* __restric
     }
 }
 
-// B'. unions: the background stretches that open right of an edge pixel (this row and the row below), the runs at
-// x = 0 of consecutive rows, and -- only when Canny's labels could not be kept -- the edge pixels themselves
+// B'. unions: the background stretches that open right of an edge pixel (this row and the row below) and -- only when
+// Canny's labels could not be kept -- the edge pixels themselves.  (The runs at x = 0 and those that reach x = w - 1 are
+// born linked to node 0 in A': round 4.  Chained by unions, 1 080 of them on one growing path per frame, they were the
+// long dependency of this kernel.)
 __global__ __launch_bounds__(256) void link_runs_kernel(int h, int w, int32_t* __restrict__ labels, const FrameTab* __restrict__ tab,
                                                         const int32_t* __restrict__ elist, RunTab rt,
                                                         const int* __restrict__ canny_border_flag)
@@ -591,7 +601,7 @@ __global__ __launch_bounds__(256) void link_runs_kernel(int h, int w, int32_t* _
     const uint16_t* rk = rt.rank + (size_t)f * h * w64;
     const int32_t* rb = rt.rowbase + (size_t)f * h;
     int32_t* rp = rt.rp + (size_t)f * rt.rp_stride;
-    for (int i = bx * 256 + threadIdx.x; i < ne + h - 1; i += LIST_BLOCKS * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < ne + (CCL_PRELINK ? 0 : h - 1); i += LIST_BLOCKS * 256) {
         if (i < ne) {
             const int p = E[i];                        // 1 <= x <= w-2, 1 <= y <= h-2
             const int y = p / w, x = p - y * w;
