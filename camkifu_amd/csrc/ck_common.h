@@ -5,6 +5,10 @@
 #include <stdio.h>
 #include <string.h>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <exception>
 #include <map>
 #include <stdexcept>
@@ -164,35 +168,57 @@ struct CtxCall {
         if (rc__ != CK_OK) return rc__;  \
     } while (0)
 
-// Host loop over independent items on a few threads.  The caller works too; a helper that cannot be started (thread
-// limit) is simply absent; an exception inside a helper is carried back and rethrown on the caller's thread, where
-// the entry point's bracket turns it into an error code.
+// Host loop over independent items on the library's worker threads (ck_pool.cpp: a process-wide pool, started on first
+// use).  The caller works too and claims items like a helper, so a pool that is busy with another context's loop only
+// means fewer helpers, never a wait for them to START: a helper that arrives late finds nothing to claim and touches
+// nothing but the (shared, heap) job record.  An exception inside an item is carried back and rethrown on the
+// caller's thread, where the entry point's bracket turns it into an error code.
+// (Threads used to be created per loop: ~25 us each, 0.4 ms of a 16-frame board call's 1.3 -- tools/board_call_latency.py.)
+int ck_pool_size();
+void ck_pool_submit(std::function<void()> task);
+struct CkLoopJob {
+    int n = 0;
+    std::atomic<int> next{0}, active{0};
+    std::atomic<bool> failed{false};
+    std::mutex m;
+    std::condition_variable cv;
+};
 template <typename F>
 void ck_parallel_for(int n, int max_threads, F fn)
 {
-    unsigned hw = std::thread::hardware_concurrency();
-    int nt = (int)(hw ? hw : 4);
+    int nt = ck_pool_size() + 1;
     if (nt > max_threads) nt = max_threads;
     if (nt > n) nt = n;
     if (nt <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
-    std::atomic<int> next{0};
-    std::atomic<bool> failed{false};
-    auto worker = [&]() {
-        try {
-            for (int i; !failed.load(std::memory_order_relaxed) && (i = next.fetch_add(1)) < n;) fn(i);
-        } catch (...) {
-            failed.store(true);
+    auto job = std::make_shared<CkLoopJob>();
+    job->n = n;
+    F* body = &fn;                                   // only dereferenced for a claimed item, i.e. while this frame is alive
+    auto claim = [job, body]() {
+        CkLoopJob& j = *job;
+        j.active.fetch_add(1);
+        for (int i; !j.failed.load(std::memory_order_relaxed) && (i = j.next.fetch_add(1)) < j.n;) {
+            try {
+                (*body)(i);
+            } catch (...) {
+                j.failed.store(true);
+            }
+        }
+        if (j.active.fetch_sub(1) == 1) {
+            std::lock_guard<std::mutex> lock(j.m);
+            j.cv.notify_all();
         }
     };
-    std::vector<std::thread> th;
     try {
-        th.reserve(nt - 1);
-        for (int t = 1; t < nt; t++) th.emplace_back(worker);
-    } catch (...) {
+        for (int t = 1; t < nt; t++) ck_pool_submit(claim);
+    } catch (...) {                                  // (no memory for the queue entry: fewer helpers)
     }
-    worker();
-    for (auto& t : th) t.join();
-    if (failed.load()) throw std::runtime_error("a host worker thread failed (out of memory?)");
+    claim();
+    {
+        // every item has been claimed by now; wait for the helpers that are still inside one
+        std::unique_lock<std::mutex> lock(job->m);
+        job->cv.wait(lock, [&] { return job->active.load() == 0; });
+    }
+    if (job->failed.load()) throw std::runtime_error("a host worker failed (out of memory?)");
 }
 
 // timing brackets: record HIP events on the ctx stream around a group of launches

@@ -61,6 +61,10 @@ constexpr int LIST_BLOCKS = CCL_LIST_BLOCKS;          // grid-stride blocks per 
 #define CK_HOUGH_THREADS 1024    // the theta slab fills a CU's LDS (one workgroup per CU): all the latency hiding comes from its own waves
 #endif
 constexpr int HOUGH_THREADS = CK_HOUGH_THREADS;
+#ifndef CK_HOUGH_SMALL_N
+#define CK_HOUGH_SMALL_N 32      // calls of at most this many frames use the small Hough slabs (k_board_lines)
+#endif
+constexpr int HOUGH_SMALL_N = CK_HOUGH_SMALL_N;
 
 // ---- A. frame clearing + parent initialisation + edge list -----------------------------
 // one wave per image row; walks the row in 64-pixel segments carrying the position of the
@@ -1099,11 +1103,12 @@ __global__ __launch_bounds__(HOUGH_THREADS) void hough_vote_peaks_kernel(const u
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) uint32_t slab16[];
     const int f = blockIdx.y;
+    const int nthreads = blockDim.x;                      // HOUGH_THREADS, or fewer for the small-batch launch
     const int n0 = blockIdx.x * rb;                       // first inner row
     const int stride = numrho + 2;                        // as the global accumulator had: a zero guard cell either side
     const int rowdw = (stride + 1) >> 1;                  // dwords per LDS row
     const int nrows = rb + 2;                             // LDS row j <-> theta row n0 - 1 + j
-    for (int i = threadIdx.x; i < nrows * rowdw; i += HOUGH_THREADS) slab16[i] = 0u;
+    for (int i = threadIdx.x; i < nrows * rowdw; i += nthreads) slab16[i] = 0u;
     __syncthreads();
     int npts = tab[f].n_hough_pts;
     if (npts > pcap) npts = pcap;
@@ -1112,7 +1117,7 @@ __global__ __launch_bounds__(HOUGH_THREADS) void hough_vote_peaks_kernel(const u
     const int j_lo = n0 == 0 ? 1 : 0;
     int j_hi = NUMANGLE - (n0 - 1);                       // exclusive: rows past theta 179 stay zero
     if (j_hi > nrows) j_hi = nrows;
-    for (int i = threadIdx.x; i < npts; i += HOUGH_THREADS) {
+    for (int i = threadIdx.x; i < npts; i += nthreads) {
         const uint32_t pk = P[i];
         const float xf = (float)(pk & 0xFFFF), yf = (float)(pk >> 16);
         for (int j = j_lo; j < j_hi; j++) {
@@ -1131,7 +1136,7 @@ __global__ __launch_bounds__(HOUGH_THREADS) void hough_vote_peaks_kernel(const u
         const int n = n0 + k;
         if (n >= NUMANGLE) break;
         const uint16_t* row = cnt + (k + 1) * rowhw;
-        for (int r = threadIdx.x; r < numrho; r += HOUGH_THREADS) {
+        for (int r = threadIdx.x; r < numrho; r += nthreads) {
             const int v = row[r + 1];
             if (v <= threshold) continue;
             if (v > row[r] && v >= row[r + 2] && v > row[r + 1 - rowhw] && v >= row[r + 1 + rowhw]) {
@@ -1444,9 +1449,19 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
         int rb = (int)((144 * 1024) / row_bytes) - 2;                      // inner rows per workgroup (+ 2 halo rows)
         if (rb > 10) rb = 10;
         if (rb < 1) return ck_fail(ctx, CK_ERR_ARG, "image too large for the Hough LDS slab");
+        int threads = HOUGH_THREADS;
+        // A call of a few frames (the hold-off-aware fold's windows, a live finder's single frame) is a latency matter, and
+        // next to the classifier -- two workgroups of 79 KB on every CU -- a workgroup that wants a whole CU's LDS waits until
+        // that kernel's grid drains: 1.5 ms of a 16-frame call's 3.0 (tools/board_call_latency.py).  Small batches take
+        // slabs that fit the hole ONE retiring classifier workgroup leaves (<= 72 KB, 512 threads): same peaks (rows with
+        // their halo, sorted on the host), more workgroups re-reading the point list.
+        if (n <= HOUGH_SMALL_N) {
+            const int rs = (int)((72 * 1024) / row_bytes) - 2;
+            if (rs >= 1) { rb = rs < rb ? rs : rb; threads = HOUGH_THREADS < 512 ? HOUGH_THREADS : 512; }
+        }
         CK_HIP(ctx, hipFuncSetAttribute((const void*)hough_vote_peaks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)((rb + 2) * row_bytes)));
-        hipLaunchKernelGGL(hough_vote_peaks_kernel, dim3((NUMANGLE + rb - 1) / rb, n), dim3(HOUGH_THREADS), (rb + 2) * row_bytes, ctx->stream,
+                                        (int)(144 * 1024)));
+        hipLaunchKernelGGL(hough_vote_peaks_kernel, dim3((NUMANGLE + rb - 1) / rb, n), dim3(threads), (rb + 2) * row_bytes, ctx->stream,
                            (const uint32_t*)d_hpts, d_tab, pcap, (const float*)d_trig, numrho, rb, hough_thresh, d_peaks);
         CK_HIP(ctx, hipGetLastError());
     }

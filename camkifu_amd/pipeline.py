@@ -816,13 +816,24 @@ class FastFilePipeline:
             return self.board.run(full)
         lanes, pools = self.compute.lanes, self.compute.pools
 
+        def timed_detect(ctx, part):
+            import time
+            t0 = time.perf_counter()
+            out = ctx.board_detect(part, -1, LMAX, True)
+            return out, time.perf_counter() - t0
+
         def fetch(idx):
+            import time
+            t0 = time.perf_counter()
             idx = list(idx)
             k = len(lanes) if len(idx) >= 8 * len(lanes) else 1
             cuts = [round(i * len(idx) / k) for i in range(k + 1)]
-            futs = [pools[i][0].submit(lanes[i][0].board_detect, _take(frames, idx[cuts[i]:cuts[i + 1]]), -1, LMAX, True)
-                    for i in range(k)]
+            futs = [pools[i][0].submit(timed_detect, lanes[i][0], _take(frames, idx[cuts[i]:cuts[i + 1]])) for i in range(k)]
             got = [f.result() for f in futs]
+            hs = self.host_seconds                           # diagnostics: the requests' wall time and the library calls inside
+            hs["lazy_fetch"] = hs.get("lazy_fetch", 0.0) + time.perf_counter() - t0
+            hs["lazy_detect"] = hs.get("lazy_detect", 0.0) + max(g[1] for g in got)
+            got = [g[0] for g in got]
             return np.concatenate([g[0] for g in got]), np.concatenate([g[1] for g in got])
         return self.board.run_lazy(len(full), fetch)
 
