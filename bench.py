@@ -476,6 +476,24 @@ def main():
                                                 "at, window after window where the fold's exact state puts them, on the lanes' board contexts while the "
                                                 "stones path of the same batch is on the GPU (the fold runs before the exchange thread waits for the "
                                                 "core); stones path on every frame; same game record required")
+        # (1c) BASELINE config 2: ONE frame per call, as the per-frame finders issue them (results back on the host)
+        if world == 1:
+            def med_ms(fn, reps=20):
+                ts = []
+                for i in range(reps + 3):
+                    t0 = time.perf_counter()
+                    fn(i)
+                    ts.append(1e3 * (time.perf_counter() - t0))
+                return round(statistics.median(ts[3:]), 3)
+            one_host = [frames[i].cpu().numpy()[None] for i in range(4)]
+            extras["single_frame"] = dict(
+                unit="ms per call",
+                board_detect_frame_in_hbm=med_ms(lambda i: ctx_b.board_detect(frames[i % 4:i % 4 + 1], -1, pipeline.LMAX, True)),
+                stones_run_frame_in_hbm=med_ms(lambda i: ctx.stones_run(frames[i % 4:i % 4 + 1], M, want_grid=True)),
+                board_detect_frame_in_host_memory=med_ms(lambda i: ctx_b.board_detect(one_host[i % 4], -1, pipeline.LMAX, True)),
+                stones_run_frame_in_host_memory=med_ms(lambda i: ctx.stones_run(one_host[i % 4], M, want_grid=True)),
+                note="BASELINE config 2 (one 1920x1080 frame, board + stones detect): median of 20 calls on an otherwise idle GPU; "
+                     "host memory = a pageable numpy frame, upload included")
         # (2) PCIe-inclusive: the batch starts as I420 in PINNED host memory (what a video-file reader holds), is
         # uploaded and converted lane by lane (ck_i420_to_bgr), answers come back to the host; two batches in flight
         if world == 1:
