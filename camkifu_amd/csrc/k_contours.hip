@@ -50,7 +50,8 @@ struct FrameTab {        // device-side per-frame counters
     int n_hough_pts;
     int n_peaks;
     int overflow;
-    int pad0, pad1;
+    int runs_overflow;      // run-table form: more edge pixels than run nodes were provided for (-> dense form, on the host's say)
+    int pad1;
 };
 
 #ifndef CCL_LIST_BLOCKS
@@ -457,6 +458,7 @@ struct RunTab {
     int32_t* rowbase;
     int32_t* rp;
     int w64;
+    int cap_e;                   // edge pixels per frame that have a run node (rp holds h + cap_e parents per frame)
     size_t rp_stride;            // ints per frame in rp
 };
 
@@ -548,6 +550,10 @@ __global__ __launch_bounds__(256) void prep_runs_kernel(const uint8_t* __restric
     int base = wbase;
     for (int kk = 0; kk < wv; kk++) base += wtotal[kk];
     base = __builtin_amdgcn_readfirstlane(base);
+    // the run nodes are provided for cap_e edge pixels per frame (a quarter of the pixels: Canny output is a few percent
+    // dense); a frame beyond that says so and is redone in the dense form by the host -- nothing below indexes rp then
+    const bool nodes_fit = base + total <= rt.cap_e;
+    if (!nodes_fit && lane == 0) tab[f].runs_overflow = 1;
     if (lane == 0) {
         rt.rowbase[(size_t)f * h + y] = base;
         // the run that starts at x = 0.  Column 0 of the cleared frame is background in every row: these runs are one
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(256) void prep_runs_kernel(const uint8_t* __restric
                         E[slot] = p;
                         // the stretch right of the row's LAST edge pixel reaches column w - 1, background in every row and
                         // joined to row 0 through it: born into the outer background as well
-                        rp[h + slot] = (CCL_PRELINK && slot == base + total - 1) ? 0 : h + slot;
+                        if (nodes_fit) rp[h + slot] = (CCL_PRELINK && slot == base + total - 1) ? 0 : h + slot;
                         if (!keep_edge_parents) L[(size_t)f * h * w + p] = p;
                         slot++;
                     }
@@ -597,6 +603,7 @@ __global__ __launch_bounds__(256) void link_runs_kernel(int h, int w, int32_t* _
 {
     int f, bx;
     list_frame_block(LIST_BLOCKS, f, bx);
+    if (tab[f].runs_overflow) return;                  // this call is redone in the dense form (k_board_lines)
     const bool edges_linked = canny_border_flag != nullptr && canny_border_flag[f] == 0;   // parents kept from Canny
     const int ne = tab[f].n_edges, w64 = rt.w64;
     int32_t* L = labels + (size_t)f * h * w;
@@ -639,6 +646,7 @@ __global__ __launch_bounds__(256) void flatten_runs_kernel(int h, int w, int32_t
 {
     int f, bx;
     list_frame_block(LIST_BLOCKS, f, bx);
+    if (tab[f].runs_overflow) return;                  // this call is redone in the dense form (k_board_lines)
     const bool edges_flat = canny_border_flag != nullptr && canny_border_flag[f] == 0;
     const int ne = tab[f].n_edges;
     int32_t* L = labels + (size_t)f * h * w;
@@ -659,6 +667,7 @@ __global__ __launch_bounds__(256) void roots_runs_kernel(int h, int w, const int
 {
     int f, bx;
     list_frame_block(LIST_BLOCKS, f, bx);
+    if (tab[f].runs_overflow) return;                  // this call is redone in the dense form (k_board_lines)
     const int ne = tab[f].n_edges;
     const size_t off = (size_t)f * h * w;
     const int32_t* L = labels + off;
@@ -688,6 +697,7 @@ __global__ __launch_bounds__(256) void border_runs_kernel(int h, int w, const in
 {
     int f, bx;
     list_frame_block(LIST_BLOCKS, f, bx);
+    if (tab[f].runs_overflow) return;                  // this call is redone in the dense form (k_board_lines)
     const int ne = tab[f].n_edges, w64 = rt.w64;
     const size_t off = (size_t)f * h * w;
     const int32_t* L = labels + off;
@@ -1204,18 +1214,23 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
     uint8_t* d_want = (uint8_t*)(d_aabb + (size_t)n * maxc * 4);
 
     const dim3 lgrid = list_grid(LIST_BLOCKS, n), lblock(256);
-    {
+    // the dword path needs 4-byte aligned rows: w % 4 == 0 and an aligned base pointer
+    const bool dwords = (w & 3) == 0 && ((uintptr_t)d_edges & 3) == 0;
+    bool run_table = dwords && w <= 4096;
+    auto launch_ccl = [&](bool runs) -> int {
         TimeScope ts(ctx, "ccl");
         CK_HIP(ctx, hipMemsetAsync(d_tab, 0, tab_bytes, ctx->stream));
-        // the dword path needs 4-byte aligned rows: w % 4 == 0 and an aligned base pointer
-        const bool dwords = (w & 3) == 0 && ((uintptr_t)d_edges & 3) == 0;
-        // reuse of Canny's component roots (ck_board_detect only) needs the row kernel that preserves them
-        const int* kflag = (dwords && w <= 4096) ? d_canny_border_flag : nullptr;
-        if (dwords && w <= 4096) {
-            // run-table form: no dense parent image
+        if (runs) {
+            // run-table form: no dense parent image.  Reuse of Canny's component roots (ck_board_detect only) needs this
+            // form's row kernel, which preserves them.
+            const int* kflag = d_canny_border_flag;
             RunTab rt;
             rt.w64 = (w + 63) / 64;
-            rt.rp_stride = fpx + (size_t)h;
+            // run nodes for a quarter of the pixels (at least 64 K): a frame with more edge pixels than that sends the
+            // call to the dense form below
+            const size_t cap_e = std::min(fpx, std::max(fpx / 4, (size_t)1 << 16));
+            rt.cap_e = (int)cap_e;
+            rt.rp_stride = cap_e + (size_t)h;
             const size_t bits_b = (size_t)n * h * rt.w64 * 8, rank_b = (size_t)n * h * rt.w64 * 2, rb_b = (size_t)n * h * 4;
             const size_t rank_o = bits_b, rb_o = (rank_o + rank_b + 15) & ~(size_t)15, rp_o = (rb_o + rb_b + 15) & ~(size_t)15;
             CK_TRY(ck_ensure(ctx, ctx->runs, rp_o + (size_t)n * rt.rp_stride * 4));
@@ -1236,27 +1251,40 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
             hipLaunchKernelGGL(border_runs_kernel, lgrid, lblock, 0, ctx->stream, h, w, (const int32_t*)L, (const int32_t*)compid, maxc,
                                d_tab, d_aabb, (const int32_t*)elist, blist, rt);
         } else {
+            // dense form: every label rebuilt from the edge map (Canny's are not reused)
             if (dwords)
                 hipLaunchKernelGGL(prep_rows4_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
             else
                 hipLaunchKernelGGL(prep_rows_kernel, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist);
             hipLaunchKernelGGL(link_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
-                               (const FrameTab*)d_tab, (const int32_t*)elist, kflag);
+                               (const FrameTab*)d_tab, (const int32_t*)elist, (const int*)nullptr);
             hipLaunchKernelGGL(flatten_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, L,
-                               (const FrameTab*)d_tab, (const int32_t*)elist, kflag);
+                               (const FrameTab*)d_tab, (const int32_t*)elist, (const int*)nullptr);
             hipLaunchKernelGGL(roots_list_kernel, lgrid, lblock, 0, ctx->stream, h, w, (const int32_t*)L, compid, d_tab, maxc,
                                d_roots, d_aabb, (const int32_t*)elist);
             hipLaunchKernelGGL(border_list_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w, (const int32_t*)L,
                                (const int32_t*)compid, maxc, d_tab, d_aabb, (const int32_t*)elist, blist);
         }
         CK_HIP(ctx, hipGetLastError());
-    }
+        return CK_OK;
+    };
+    CK_TRY(launch_ccl(run_table));
 
     lap("ccl kernels");
     // ---- host: component tables (one strided copy each) -------------------------------------
     std::vector<FrameTab> tab((size_t)n);
     CK_HIP(ctx, hipMemcpyAsync(tab.data(), d_tab, tab_bytes, hipMemcpyDeviceToHost, ctx->stream));
     CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (run_table) {
+        bool redo = false;
+        for (int f = 0; f < n; f++) redo = redo || tab[f].runs_overflow;
+        if (redo) {                                       // an edge map denser than the run nodes provided for: dense form
+            run_table = false;
+            CK_TRY(launch_ccl(false));
+            CK_HIP(ctx, hipMemcpyAsync(tab.data(), d_tab, tab_bytes, hipMemcpyDeviceToHost, ctx->stream));
+            CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
     int nc_max = 0;
     for (int f = 0; f < n; f++) {
         if (tab[f].overflow) return ck_fail(ctx, CK_ERR_CAPACITY, "frame %d: more than %d external contours", f, maxc);

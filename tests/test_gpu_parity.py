@@ -243,6 +243,36 @@ def test_board_lines_run_table_widths(ck, ora, h, w):
         _cmp_board(out[0], ghost, ref)
 
 
+def test_board_lines_map_denser_than_the_run_nodes(ck, ora):
+    """the run-table labelling provides run nodes for a quarter of the pixels (at least 65 536 per frame); a frame with more
+    edge pixels than that sends the whole call to the dense form -- same answers, for the dense frame and for the sparse
+    one that shares its call"""
+    rng = np.random.default_rng(4711)
+    h, w = 280, 400
+    dense = (rng.random((h, w)) < 0.7).astype(np.uint8) * 255
+    assert int((dense[1:-1, 1:-1] > 0).sum()) > 65536
+    sparse = np.zeros((h, w), np.uint8)
+    sparse[40:240, 60] = sparse[40:240, 330] = 255
+    sparse[40, 60:331] = sparse[239, 60:331] = 255
+    sparse[100:110, 100:110] = (rng.random((10, 10)) < 0.5) * 255
+    maps = np.stack([sparse, dense, sparse[::-1].copy()])
+    ck.timing_enable(True)
+    try:
+        ck.timing_reset()
+        out, ghost = ck.board_lines(maps, hough_thresh=60, cap=4096, want_ghost=True)
+        assert ck.timing_get("ccl")[1] == 2                  # the labelling ran twice: run table, then dense
+        for k in range(len(maps)):
+            _cmp_board(out[k], ghost[k], ora.board_lines(maps[k], hough_thresh=60))
+        # and the run-table form again right after, on the same context
+        ck.timing_reset()
+        out, ghost = ck.board_lines(maps[[0, 2]], hough_thresh=60, cap=4096, want_ghost=True)
+        assert ck.timing_get("ccl")[1] == 1
+    finally:
+        ck.timing_enable(False)
+    for k, m in enumerate((maps[0], maps[2])):
+        _cmp_board(out[k], ghost[k], ora.board_lines(m, hough_thresh=60))
+
+
 def test_board_lines_edge_cases(ck, ora):
     z = np.zeros((20, 30), np.uint8)
     out = ck.board_lines(z)
