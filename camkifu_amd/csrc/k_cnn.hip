@@ -112,6 +112,9 @@ __device__ unsigned long long g_h34_prof[8];
 #define H2_STAMP(K) do { } while (0)
 #define H34_STAMP(K) do { } while (0)
 #endif
+#ifndef H2_REBALANCE
+#define H2_REBALANCE 1    // conv2: the tiles of a patch's short last block dealt out evenly over its waves
+#endif
 #ifndef H2_PRIO
 #define H2_PRIO 1         // wave priority 3 outside the k-loop (staging, fused conv1, epilogue), 0 inside: see conv_h2_body
 #endif
@@ -883,7 +886,15 @@ __device__ __forceinline__ void conv_h2_body(
     H2_STAMP(1);                                              // conv1 tiles done (all waves)
     H34_STAMP(4);                                             // conv3: input staged
 
-    const int tile0 = tile_blk + wm * R;
+    // The last block of a patch may hold fewer tiles than TB (conv2: 64 pooling tiles = 24 + 24 + 16).  With the fixed
+    // R tiles per wave five of its eight waves would do three tiles and the rest next to nothing, and the block would take as
+    // long as a full one for two thirds of the work: its tiles are dealt out evenly instead (H2_REBALANCE).
+    int r_blk = R;
+    if constexpr (H2_REBALANCE && FUSE1) {
+        const int left = RT - tile_blk;
+        if (left < TB) r_blk = (left + WAVES_M - 1) / WAVES_M;
+    }
+    const int tile0 = tile_blk + wm * r_blk;
     int abase[R], axr[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -917,6 +928,13 @@ __device__ __forceinline__ void conv_h2_body(
 
     int nv = TB - wm * R;
     nv = nv > R ? R : nv;
+    if constexpr (H2_REBALANCE && FUSE1) {
+        const int left = RT - tile_blk;
+        if (left < TB) {
+            nv = left - wm * r_blk;
+            nv = nv > r_blk ? r_blk : (nv < 0 ? 0 : nv);
+        }
+    }
     // B fragments: [tile][step][plane][lane] uint4
     const uint4* wq = reinterpret_cast<const uint4*>(wt) + (size_t)(wn * RN) * KS * 128 + lane;
     auto k_loop = [&](auto nv_tag) {
@@ -1060,7 +1078,10 @@ __device__ __forceinline__ void conv_h2_body(
     if constexpr (H2_PRIO != 0) __builtin_amdgcn_s_setprio(0);
     if (!idle && H2_DBG_SKIP != 1) {
         if (nv == R) k_loop(std::integral_constant<int, R>{});
-        else if constexpr (R * WAVES_M > TB) k_loop(std::integral_constant<int, R - 1>{});
+        else if constexpr (R * WAVES_M > TB || (H2_REBALANCE && FUSE1)) {
+            if (nv == R - 1 || !(H2_REBALANCE && FUSE1)) k_loop(std::integral_constant<int, R - 1>{});
+            else if constexpr (R >= 3) { if (nv == R - 2) k_loop(std::integral_constant<int, R - 2>{}); }
+        }
     }
 
     float nxt_big = 0.f;
