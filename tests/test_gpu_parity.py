@@ -2,6 +2,8 @@
 seeded inputs.  Bars: bit-exact for every byte / integer / index result (median, NMS map,
 edges, ghost, contour counts, Hough votes -> (rho,theta) floats, warp, MOG2 masks, labels);
 1e-4 absolute on the CNN's softmax outputs (north_star's float tolerance)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -913,6 +915,35 @@ def test_cnn_filter_maps_below_the_softmax(ck, ora, synth, mode):
                 edge = [r for r in range(100) if r % 10 == 9 or r >= 90]
                 assert float(np.abs(got[edge] - want[edge]).max()) / scale <= tol
     ck.cnn_set_weights(synth.cnn_weights())
+
+
+def test_conv12_two_group_form_is_bit_identical():
+    """CK_CONV2_PIPE=1 runs the fused conv1 + conv2 layer as one workgroup of a producer and a consumer wave group per CU
+    (conv12_pipe_kernel: built and measured in round 4, not the default -- DESIGN 4).  Same device code, same order of
+    operations: every output of the classifier, filter maps included, must equal the default form's bit for bit.  The knob
+    is read once per process, hence the two child processes."""
+    import hashlib
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from camkifu_amd import capi, synth\n"
+        "ck = capi.Context(0)\n"
+        "ck.cnn_set_weights(synth.cnn_weights())\n"
+        "g = np.random.default_rng(5).integers(0, 256, (3, 380, 380, 3), dtype=np.uint8)\n"
+        "p2, p4 = ck.cnn_maps(g[:2])\n"
+        "out = ck.cnn_regions(g)\n"
+        "h = hashlib.sha256()\n"
+        "for a in (p2, p4, np.asarray(out[0]), np.asarray(out[1])):\n"
+        "    h.update(np.ascontiguousarray(a).tobytes())\n"
+        "print('DIGEST', h.hexdigest())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for knob in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CK_CONV2_PIPE=knob), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1]
 
 
 @pytest.mark.parametrize("mode", ["f16x2", "fp32", "bf16"])
