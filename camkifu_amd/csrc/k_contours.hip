@@ -449,6 +449,9 @@ __global__ __launch_bounds__(256) void border_list_kernel(const uint8_t* __restr
 //     stay in the dense label image, which only ever holds them at edge pixels: Canny's labels when no edge touched
 //     the image frame, rebuilt here otherwise.
 // prep then moves 2 MB in + 2.4 MB out per 1080p frame instead of 2 + 10.3.
+#ifndef CCL_RUNS_EZ
+#define CCL_RUNS_EZ 0           // 1: prep_runs also writes the cleared-frame edge bytes (round 3; nothing in the run-table form reads them)
+#endif
 #ifndef CCL_PRELINK
 #define CCL_PRELINK 1
 #endif
@@ -569,8 +572,9 @@ __global__ __launch_bounds__(256) void prep_runs_kernel(const uint8_t* __restric
         const int nb = nib[s];
         const unsigned long long word = row16_or((unsigned long long)nb << (4 * (lane & 15)));
         if (x < w) {
-            *reinterpret_cast<uint32_t*>(ez + off + x) =
-                (nb & 1 ? 1u : 0u) | (nb & 2 ? 0x100u : 0u) | (nb & 4 ? 0x10000u : 0u) | (nb & 8 ? 0x1000000u : 0u);
+            if (ez)                                      // (the run-table form itself never reads the cleared bytes: round 4)
+                *reinterpret_cast<uint32_t*>(ez + off + x) =
+                    (nb & 1 ? 1u : 0u) | (nb & 2 ? 0x100u : 0u) | (nb & 4 ? 0x10000u : 0u) | (nb & 8 ? 0x1000000u : 0u);
             if ((lane & 15) == 0) {
                 bw[4 * s + (lane >> 4)] = word;
                 rw[4 * s + (lane >> 4)] = (uint16_t)before[s];
@@ -793,13 +797,25 @@ __device__ __forceinline__ bool mid_of_run(const uint8_t* e, int p, int w)
            (e[p - w - 1] && e[p + w + 1]) || (e[p - w + 1] && e[p + w - 1]);
 }
 
+// the same test on the edge image as it came in (frame not cleared): a neighbour on the image frame counts as background
+__device__ __forceinline__ bool mid_of_run_raw(const uint8_t* e, int p, int w, int h)
+{
+    const int y = p / w, x = p - y * w;
+    auto at = [&](int dy, int dx) {
+        const int yy = y + dy, xx = x + dx;
+        return xx > 0 && xx < w - 1 && yy > 0 && yy < h - 1 && e[yy * w + xx] != 0;
+    };
+    return (at(0, -1) && at(0, 1)) || (at(-1, 0) && at(1, 0)) || (at(-1, -1) && at(1, 1)) || (at(-1, 1) && at(1, -1));
+}
+
 // ---- F. gather hull-candidate points of the components the host asked for ---------------
 __global__ __launch_bounds__(256) void gather_points_kernel(const uint8_t* __restrict__ ez, int h, int w,
                                                             const int32_t* __restrict__ labels, const int32_t* __restrict__ compid,
                                                             int maxc, const uint8_t* __restrict__ want, int wpitch, const FrameTab* __restrict__ tab,
                                                             const int32_t* __restrict__ blist, int32_t* __restrict__ counter, int cap,
                                                             int32_t* __restrict__ pts /* x|y<<16, slot ; then frame */,
-                                                            int keep_mid /* 1: every border pixel, not only hull candidates */)
+                                                            int keep_mid /* 1: every border pixel, not only hull candidates */,
+                                                            int raw = 0 /* 1: `ez` is the edge image as it came in (frame not cleared) */)
 {
     int f, bx;
     list_frame_block(LIST_BLOCKS, f, bx);
@@ -814,7 +830,7 @@ __global__ __launch_bounds__(256) void gather_points_kernel(const uint8_t* __res
         if (i < nb) {
             p = B[i];
             slot = compid[off + labels[off + p]];
-            take = want[(size_t)f * wpitch + slot] && (keep_mid || !mid_of_run(ez + off, p, w));
+            take = want[(size_t)f * wpitch + slot] && (keep_mid || !(raw ? mid_of_run_raw(ez + off, p, w, h) : mid_of_run(ez + off, p, w)));
         }
         const int k = wave_append(counter, take);           // one atomic per wave
         if (take && k < cap) {
@@ -833,7 +849,8 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const uint8_t* __r
                                                               const int32_t* __restrict__ labels, const int32_t* __restrict__ compid,
                                                               int maxc, const uint8_t* __restrict__ want, int wpitch, const FrameTab* __restrict__ tab,
                                                               const int32_t* __restrict__ blist, int32_t* __restrict__ fcnt, int cap,
-                                                              int32_t* __restrict__ seg /* per frame: cap x (x|y<<16, slot) */)
+                                                              int32_t* __restrict__ seg /* per frame: cap x (x|y<<16, slot) */,
+                                                              int raw /* 1: `ez` is the edge image as it came in (frame not cleared) */)
 {
     int f, bx;
     list_frame_block(LIST_BLOCKS, f, bx);
@@ -849,7 +866,7 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const uint8_t* __r
         if (i < nb) {
             p = B[i];
             slot = compid[off + labels[off + p]];
-            take = want[(size_t)f * wpitch + slot] && !mid_of_run(ez + off, p, w);
+            take = want[(size_t)f * wpitch + slot] && !(raw ? mid_of_run_raw(ez + off, p, w, h) : mid_of_run(ez + off, p, w));
         }
         const int k = wave_append(fcnt + f, take);
         if (take && k < cap) {
@@ -1239,11 +1256,11 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
             rt.rowbase = (int32_t*)((char*)ctx->runs.p + rb_o);
             rt.rp = (int32_t*)((char*)ctx->runs.p + rp_o);
             if (w <= 1024)
-                hipLaunchKernelGGL(prep_runs_kernel<4>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist, rt, kflag);
+                hipLaunchKernelGGL(prep_runs_kernel<4>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, CCL_RUNS_EZ ? ez : (uint8_t*)nullptr, L, d_tab, elist, rt, kflag);
             else if (w <= 2048)
-                hipLaunchKernelGGL(prep_runs_kernel<8>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist, rt, kflag);
+                hipLaunchKernelGGL(prep_runs_kernel<8>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, CCL_RUNS_EZ ? ez : (uint8_t*)nullptr, L, d_tab, elist, rt, kflag);
             else
-                hipLaunchKernelGGL(prep_runs_kernel<16>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, ez, L, d_tab, elist, rt, kflag);
+                hipLaunchKernelGGL(prep_runs_kernel<16>, dim3((h + 3) / 4, n), dim3(256), 0, ctx->stream, d_edges, h, w, CCL_RUNS_EZ ? ez : (uint8_t*)nullptr, L, d_tab, elist, rt, kflag);
             hipLaunchKernelGGL(link_runs_kernel, lgrid, lblock, 0, ctx->stream, h, w, L, (const FrameTab*)d_tab, (const int32_t*)elist, rt, kflag);
             hipLaunchKernelGGL(flatten_runs_kernel, lgrid, lblock, 0, ctx->stream, h, w, L, (const FrameTab*)d_tab, (const int32_t*)elist, rt, kflag);
             hipLaunchKernelGGL(roots_runs_kernel, lgrid, lblock, 0, ctx->stream, h, w, (const int32_t*)L, compid, d_tab, maxc,
@@ -1365,9 +1382,12 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
             int32_t* d_fcnt = d_seg + (size_t)n * segcap * 2;
             CK_HIP(ctx, hipMemsetAsync(d_fcnt, 0, (size_t)n * 4, ctx->stream));
             CK_HIP(ctx, hipMemsetAsync(d_counter, 0, 8, ctx->stream));
-            hipLaunchKernelGGL(gather_segments_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w,
+            // (run-table form: the cleared-frame bytes were not written; the hull-candidate test reads the edge image as it came in)
+            const bool raw_edges = run_table && !CCL_RUNS_EZ;
+            const uint8_t* e_img = raw_edges ? d_edges : (const uint8_t*)ez;
+            hipLaunchKernelGGL(gather_segments_kernel, lgrid, lblock, 0, ctx->stream, e_img, h, w,
                                (const int32_t*)L, (const int32_t*)compid, maxc, (const uint8_t*)d_want, nc_max,
-                               (const FrameTab*)d_tab, (const int32_t*)blist, d_fcnt, segcap, d_seg);
+                               (const FrameTab*)d_tab, (const int32_t*)blist, d_fcnt, segcap, d_seg, (int)raw_edges);
             hipLaunchKernelGGL(compact_points_kernel, dim3(n), dim3(256), 0, ctx->stream, (const int32_t*)d_fcnt, n, segcap,
                                (const int32_t*)d_seg, gcap, d_pts, d_counter);
             CK_HIP(ctx, hipGetLastError());
@@ -1381,9 +1401,10 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
             if (two[1]) {                                   // a segment overflowed: the whole round again, one counter for all
                 TimeScope ts(ctx, "contour_gather");
                 CK_HIP(ctx, hipMemsetAsync(d_counter, 0, 4, ctx->stream));
-                hipLaunchKernelGGL(gather_points_kernel, lgrid, lblock, 0, ctx->stream, (const uint8_t*)ez, h, w,
+                const bool raw_edges = run_table && !CCL_RUNS_EZ;
+                hipLaunchKernelGGL(gather_points_kernel, lgrid, lblock, 0, ctx->stream, raw_edges ? d_edges : (const uint8_t*)ez, h, w,
                                    (const int32_t*)L, (const int32_t*)compid, maxc, (const uint8_t*)d_want, nc_max,
-                                   (const FrameTab*)d_tab, (const int32_t*)blist, d_counter, gcap, d_pts, 0);
+                                   (const FrameTab*)d_tab, (const int32_t*)blist, d_counter, gcap, d_pts, 0, (int)raw_edges);
                 CK_HIP(ctx, hipGetLastError());
                 CK_HIP(ctx, hipMemcpyAsync(&npts, d_counter, 4, hipMemcpyDeviceToHost, ctx->stream));
                 CK_HIP(ctx, hipStreamSynchronize(ctx->stream));
