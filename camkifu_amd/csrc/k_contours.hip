@@ -1163,15 +1163,24 @@ __global__ __launch_bounds__(HOUGH_THREADS) void hough_vote_peaks_kernel(const u
         const int n = n0 + k;
         if (n >= NUMANGLE) break;
         const uint16_t* row = cnt + (k + 1) * rowhw;
-        for (int r = threadIdx.x; r < numrho; r += nthreads) {
-            const int v = row[r + 1];
-            if (v <= threshold) continue;
-            if (v > row[r] && v >= row[r + 2] && v > row[r + 1 - rowhw] && v >= row[r + 1 + rowhw]) {
-                const int i = atomicAdd(&tab[f].n_peaks, 1);
-                if (i < PEAK_CAP) {
-                    peaks[((size_t)f * PEAK_CAP + i) * 2] = (n + 1) * stride + r + 1;
-                    peaks[((size_t)f * PEAK_CAP + i) * 2 + 1] = v;
-                } else tab[f].overflow = 1;
+        // two cells per dword: nearly every cell is below the threshold, and then one load and two compares settle both
+        const uint32_t* roww = slab16 + (k + 1) * rowdw;
+        for (int d = threadIdx.x; d < rowdw; d += nthreads) {
+            const uint32_t two = roww[d];
+            if ((int)(two & 0xFFFFu) <= threshold && (int)(two >> 16) <= threshold) continue;
+#pragma unroll
+            for (int hlf = 0; hlf < 2; hlf++) {
+                const int c = 2 * d + hlf, r = c - 1;           // cell c of the row <-> rho index r (cell 0 and the last are guards)
+                if (r < 0 || r >= numrho) continue;
+                const int v = hlf ? (int)(two >> 16) : (int)(two & 0xFFFFu);
+                if (v <= threshold) continue;
+                if (v > row[r] && v >= row[r + 2] && v > row[r + 1 - rowhw] && v >= row[r + 1 + rowhw]) {
+                    const int i = atomicAdd(&tab[f].n_peaks, 1);
+                    if (i < PEAK_CAP) {
+                        peaks[((size_t)f * PEAK_CAP + i) * 2] = (n + 1) * stride + r + 1;
+                        peaks[((size_t)f * PEAK_CAP + i) * 2 + 1] = v;
+                    } else tab[f].overflow = 1;
+                }
             }
         }
     }
