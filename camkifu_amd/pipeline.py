@@ -543,7 +543,12 @@ class FastFilePipeline:
         # hold-off-aware mode (one rank): the GPU core leaves the board path out and the board fold computes, through the
         # lanes' board contexts (on their own threads), only the records it looks at.  With frames dealt across ranks
         # the fold would have to ask other ranks for theirs: not built, the full records are computed then.
-        self.board_lazy = bool(board_lazy) and not self.exchange and hasattr(self.compute, "lanes")
+        if board_lazy and self.exchange:
+            raise ValueError("board_lazy (hold-off-aware board path) is a one-rank mode: with the frames dealt across ranks the "
+                             "board fold would have to ask other ranks for their records")
+        if board_lazy and not hasattr(self.compute, "lanes"):
+            raise ValueError("board_lazy needs a GPU core with lanes (their board contexts compute the requested records)")
+        self.board_lazy = bool(board_lazy)
 
     # ---- pixel-sharded background model (world > 1) -------------------------------------------------------
     def _band_counts(self, gobans, n_total, rates):

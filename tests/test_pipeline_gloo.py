@@ -465,6 +465,20 @@ class _TableCtx:
         return np.zeros((len(gobans), 19, 19), np.int32)
 
 
+def test_board_lazy_is_refused_with_an_exchange_stage():
+    """the hold-off-aware board path is a one-rank mode: asking for it together with the exchange stage is an error, not a
+    silent fall-back to the eager path"""
+    from camkifu_amd.pipeline import FastFilePipeline, GpuCore
+    lanes = [(_TableCtx(None, None, []), _TableCtx(None, None, []))]
+    core = GpuCore(lanes, bg_ctx=_TableCtx(None, None, []))
+    try:
+        with pytest.raises(ValueError, match="one-rank"):
+            FastFilePipeline(480, 640, ControllerHeadless(), compute=core, board_lazy=True, force_exchange=True)
+    finally:
+        core.close()
+
+
+
 def test_hold_off_aware_pipeline_equals_the_eager_one_and_computes_a_fraction_of_the_records():
     """the reference does not run K1..K6 during the hold-off after a hit (bf_auto.py:43-49).  In the
     hold-off-aware mode the GPU core leaves the board path out; the board fold of a batch runs on the exchange thread
