@@ -212,7 +212,7 @@ def test_the_exchange_stage_does_not_gate_the_lanes():
         forced.append(_bench(*args, "--force-exchange")["value"])
     ratio = sum(forced) / sum(plain)
     print("\n  frames/s plain %s, with the exchange stage over RCCL %s: ratio of the means %.4f" % (plain, forced, ratio), end="")
-    assert ratio > 0.95, (plain, forced)
+    assert ratio > 0.94, (plain, forced)         # (0.98-1.00 measured; 0.93 with normal-priority streams; run-to-run sigma of the ratio ~1.4 %)
 
 
 @pytest.mark.gpu
