@@ -494,6 +494,39 @@ def main():
                 stones_run_frame_in_host_memory=med_ms(lambda i: ctx.stones_run(one_host[i % 4], M, want_grid=True)),
                 note="BASELINE config 2 (one 1920x1080 frame, board + stones detect): median of 20 calls on an otherwise idle GPU; "
                      "host memory = a pageable numpy frame, upload included")
+        # (1d) the multi-GPU exchange stage, as far as ONE GPU can run it: a process group of one rank on the `nccl` (RCCL)
+        # backend and the pipeline told to issue its whole exchange stage anyway -- record all-gather, transform broadcast,
+        # goban-band all-to-all on device buffers, band model on its own context, counts gather, all from the exchange thread
+        # on its high-priority stream.  Same requests as the plain run required; the ratio says what the stage costs the lanes.
+        if world == 1 and not args.force_exchange and args.dist_backend == "nccl":
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            try:
+                with stdout_to_stderr():
+                    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=rccl_group_options())
+                    dist.barrier()
+                xp = pipeline.FastFilePipeline(H, W, ControllerHeadless(), rank=0, world=1, device=dev, lanes=lanes, ctx_bg=ctx_bg,
+                                               force_exchange=True)
+                xp.process_batch(frames, n_total)
+                if xp.mtx is None:
+                    xp.mtx = M_true
+                same_x = xp.process_batch(frames, n_total) == requests
+                k = max(4, args.steps // 2)
+                dx = timed(xp, k, 2, frames)
+                dp = timed(pipe, k, 2, frames)                 # the plain pipeline again, right after: same box state
+                xp.close()
+                extras["rccl_exchange_one_rank"] = dict(
+                    value=round(n_total * k / dx, 2), unit="frames/s", steps=k, same_game_record=bool(same_x),
+                    plain_right_after=round(n_total * k / dp, 2), ratio=round(dp / dx, 4),
+                    host_ms_per_step={kk: round(1e3 * v / k, 3) for kk, v in xp.host_seconds.items()},
+                    note="one rank, every collective of the exchange stage issued for real over RCCL on device buffers "
+                         "(tests/test_gpu_multirank.py holds the ratio of means above 0.94); nothing here measures xGMI")
+            finally:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
         # (2) PCIe-inclusive: the batch starts as I420 in PINNED host memory (what a video-file reader holds), is
         # uploaded and converted lane by lane (ck_i420_to_bgr), answers come back to the host; two batches in flight
         if world == 1:
