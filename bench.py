@@ -471,6 +471,7 @@ def main():
                                            board_records_computed_pct=round(100.0 * lazy.board.fetched / max(1, lazy.board.seen), 1),
                                            board_fetch_calls_per_batch=round(lazy.board.calls * n_total / max(1, lazy.board.seen), 2),
                                            extra_grouping_rounds_of_recent_detections=list(lazy.board.recent),
+                                           detections_by_extra_grouping_rounds={str(kk): v for kk, v in sorted(lazy.board.rounds_seen.items())},
                                            note="NOT the headline (that one runs K1-K6 on every frame): the reference does not run K1-K6 during the "
                                                 "hold-off after a detection (bf_auto.py:43-49); here K1-K6 run only for the frames the board fold looks "
                                                 "at, window after window where the fold's exact state puts them, on the lanes' board contexts while the "

@@ -195,6 +195,7 @@ class BoardFold:
         self.recent = [1]                                    # extra grouping rounds the last few detections needed (run_lazy's first request)
         self._run = self._opened = 0                         # frames looked at since the window in progress opened / the count it opened on
         self.generosity = 1                                  # grouping rounds a window's first request covers beyond the recent maximum
+        self.rounds_seen = {}                                # how many detections needed 0, 1, 2 ... extra grouping rounds (diagnostics)
 
     @property
     def mtx(self):
@@ -283,6 +284,7 @@ class BoardFold:
             if self.hold > 0:
                 self.episode = self._run                     # frames it took from the end of the hold-off to this hit
                 self.recent = (self.recent + [max(0, (self._run - ((-self._opened) % 4 + 1)) // 4)])[-4:]
+                self.rounds_seen[self.recent[-1]] = self.rounds_seen.get(self.recent[-1], 0) + 1
                 self._run = 0
         return self.mtx
 
