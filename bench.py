@@ -473,8 +473,9 @@ def main():
                                            extra_grouping_rounds_of_recent_detections=list(lazy.board.recent),
                                            detections_by_extra_grouping_rounds={str(kk): v for kk, v in sorted(lazy.board.rounds_seen.items())},
                                            note="NOT the headline (that one runs K1-K6 on every frame): the reference does not run K1-K6 during the "
-                                                "hold-off after a detection (bf_auto.py:43-49); here K1-K6 run only for the frames the board fold looks "
-                                                "at, window after window where the fold's exact state puts them, on the lanes' board contexts while the "
+                                                "hold-off after a detection (bf_auto.py:43-49); here K1-K6 run only for frames the board fold may look "
+                                                "at -- a request covers a hypothesis for the rest of the batch (later windows placed as if each hits on "
+                                                "its first opportunity; BoardFold.run_lazy) --, on the lanes' board contexts while the "
                                                 "stones path of the same batch is on the GPU (the fold runs before the exchange thread waits for the "
                                                 "core); stones path on every frame; same game record required")
         # (1c) BASELINE config 2: ONE frame per call, as the per-frame finders issue them (results back on the host)

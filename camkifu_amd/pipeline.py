@@ -14,6 +14,8 @@ by PIXEL instead: with world > 1 every rank keeps the mixtures of a band of inte
 band of every goban image of the batch in one all-to-all (xGMI), runs the band through the whole batch in frame
 order (ck_mog2_band_run) and contributes its foreground counts to the gather.  With world == 1 the whole chain
 is one call (ck_stones_run)."""
+import os
+
 import numpy as np
 
 from . import capi, cvconf
@@ -235,32 +237,52 @@ class BoardFold:
             k += 1
         return self.mtx
 
-    def run_lazy(self, n, fetch, chunk=8):
+    def run_lazy(self, n, fetch, chunk=8, plan_ahead=True):
         """The same fold over a batch of n frames whose board records do not exist yet: `fetch(indices)` computes the
         records of those frames (-> BOARD_DTYPE array, lines (len(indices), cap, 2)) and is only asked for frames this
         fold is going to look at.  During the hold-off the reference does not run K1..K6 at all (bf_auto.py:43-49); this
         is that, batch-wise.  Same calls to `step` in the same order as `run` over the full records, hence the same
-        corners.
+        corners: what is computed never changes what is folded (the cache is keyed by frame).
 
-        The windows are fetched ONE AFTER THE OTHER, each where the fold's exact state puts it (round 3 asked for the
-        union of all predicted windows of the batch in one call: where window j + 1 opens depends on where window j's hit
-        fell, so the union had to carry the accumulated slack and computed 60 % of the records).  A window that opens on
-        running count c closes on the next multiple of 4 -- the library looks for corners only there (bf_auto.py:85-94) --
-        or 4 x r frames later when the grouping needs more rounds: the first request covers the typical r of the last
-        detections (`generosity` rounds on top: a record costs 28 us of GPU time, a further request 1 to 2 ms of round trip),
-        a later hit costs further requests of `chunk` frames.  The pipeline runs this chain of requests on a thread of its
-        own, ahead of the stones path of the same batch."""
+        A window that opens on running count c can only close on a multiple of 4 of that count -- the library looks for
+        corners only there (bf_auto.py:85-94): on its first opportunity, (-c) % 4 + 1 frames in, or r rounds of four frames
+        later.  Where window j + 1 opens depends on where window j's hit fell, so fetching window by window is a chain of
+        dependent GPU round trips (4.6 per 256-frame batch, 2 ms each next to the classifier: as long as the eager step),
+        and fetching every place a window MIGHT be computes most of the records (round 3: 60 %).
+
+        plan_ahead (round 4): two detections in three come on the first opportunity and nearly all others three or four
+        rounds later (bench film: r = 0 for 57 of 86, r >= 3 for 28).  So a request covers a HYPOTHESIS for the rest of
+        the batch: when a window opens and its first frame is not there, the frames up to the first opportunity of this
+        window and of every later one, each placed as if its predecessor hits at once; when a first opportunity has
+        passed without a hit, the window's frames up to round 4 plus the same chain of later windows placed after a
+        hit in round 3 and after one in round 4.  A batch then costs one request plus one per deviation (~2.5) instead
+        of one per window and follow-up, for ~20 % of the records.
+
+        Without it: one request per window up to its probable end (the typical r of the last detections plus `generosity`
+        rounds), further requests of `chunk` frames for a later hit."""
         cache = {}
+        H = self.refresh_frames
 
-        def load(lo, hi):
-            indices = [f for f in range(lo, min(n, hi)) if f not in cache]
-            if not indices:
+        def load(want):
+            want = [f for f in want if 0 <= f < n and f not in cache]
+            if not want:
                 return
-            res, lines = fetch(indices)
-            self.fetched += len(indices)
+            res, lines = fetch(want)
+            self.fetched += len(want)
             self.calls += 1
-            for j, f in enumerate(indices):
+            for j, f in enumerate(want):
                 cache[f] = (int(res["status"][j]), int(res["n_lines"][j]), lines[j])
+
+        def chain(k, c, j):
+            """frames looked at from frame k on running count c if the window in progress hits on its j-th upcoming
+            opportunity and every later window of the batch on its first"""
+            out = []
+            span = (-c) % 4 + 1 + 4 * j
+            while k < n:
+                out.extend(range(k, min(n, k + span)))
+                k, c = k + span + H, c + span + H
+                span = (-c) % 4 + 1
+            return out
         k = 0
         while k < n:
             if self.hold > 0:
@@ -271,11 +293,22 @@ class BoardFold:
                 k += skip
                 continue
             if k not in cache:
-                if self._run == 0:                           # a window opens here: up to its probable end in one request
-                    rounds = min(max(self.recent) + self.generosity, 4)
-                    load(k, k + (-self.finder.total_f_processed) % 4 + 1 + 4 * rounds)
+                c = self.finder.total_f_processed
+                if not plan_ahead:
+                    if self._run == 0:                       # a window opens here: up to its probable end in one request
+                        rounds = min(max(self.recent) + self.generosity, 4)
+                        load(range(k, k + (-c) % 4 + 1 + 4 * rounds))
+                    else:
+                        load(range(k, k + chunk))
+                elif self._run == 0:
+                    load(chain(k, c, 0))
                 else:
-                    load(k, k + chunk)
+                    # opportunities this window has had: its first after (-opened) % 4 + 1 frames, then one every four
+                    first = (-self._opened) % 4 + 1
+                    had = 0 if self._run < first else 1 + (self._run - first) // 4
+                    # hit in round 3 or 4 of the window; a window already past that: two or four opportunities from here
+                    ahead = [3 - had, 4 - had] if had <= 2 else [1, 3]
+                    load(sorted(set().union(*[chain(k, c, j) for j in ahead])))
             status, n_lines, lines = cache[k]
             if self._run == 0:
                 self._opened = self.finder.total_f_processed  # the count this window opens on (it may span two batches)
@@ -842,7 +875,7 @@ class FastFilePipeline:
             hs["lazy_detect"] = hs.get("lazy_detect", 0.0) + max(g[1] for g in got)
             got = [g[0] for g in got]
             return np.concatenate([g[0] for g in got]), np.concatenate([g[1] for g in got])
-        return self.board.run_lazy(len(full), fetch)
+        return self.board.run_lazy(len(full), fetch, plan_ahead=os.environ.get("CK_LAZY_PLAN") != "0")      # (developer A/B knob)
 
     def fold(self, full, counts, have_mtx=True, frames=None):
         """both ordered folds of one batch, one after the other (what finish() does across its stages)"""
