@@ -172,6 +172,11 @@ class Context:
         if _is_torch(like) and like.is_cuda:
             import torch
             t = torch.empty(shape, dtype=getattr(torch, np.dtype(dtype).name), device=like.device)
+            # The block may have been freed a moment ago by ANOTHER thread whose last kernel on it is still queued on torch's
+            # stream (torch reuses a block within a stream at once); the library writes on its own stream, which that
+            # kernel is not ordered with.  Whatever torch has queued runs first (round 4: a memory fault in a gather whose
+            # index tensor was recycled this way).
+            torch.cuda.current_stream(like.device).synchronize()
             return t, C.c_void_p(t.data_ptr()), CK_DEVICE
         a = np.empty(shape, dtype)
         return a, a.ctypes.data_as(C.c_void_p), CK_HOST
@@ -274,7 +279,7 @@ class Context:
         elif to_device is not None and sp == CK_HOST:
             import torch
             out = torch.empty(oshape, dtype=torch.uint8, device=to_device)
-            op, osp = C.c_void_p(out.data_ptr()), CK_DEVICE
+            op, osp, _ = _in(out)                          # (and whatever torch has queued on a recycled block runs first: see _out)
         else:
             out, op, osp = self._out(i420, oshape, np.uint8)
         self._chk(lib().ck_i420_to_bgr(self._h, p, n, int(h), int(w), sp, op, osp))

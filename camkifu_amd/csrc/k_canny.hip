@@ -127,18 +127,21 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
     // rim: no new values) span R levels with 6 R <= low, no magnitude exceeds `low`: no candidate, map = 1, nothing to
     // stage or to compute.  On a board frame that is half of the tiles (paper, table, wood between the lines).
     if (trange) {
+        // max hi - min lo over the (at most 3 x 2) tiles of a channel is within bounds iff hi_i - lo_j is for every pair (i, j):
+        // one pair per lane (3 channels x 6 x 6), its two bytes loaded at once -- the test costs ONE memory latency instead of
+        // a chain of up to six (the tile waits for it before it stages anything, and a flat tile is nothing but this wait)
+        static_assert(TW + 4 <= 2 * RANGE_TILE + 1 && PTH + 4 <= RANGE_TILE + 1, "a tile's pixel region spans at most 3 x 2 range tiles");
         bool flat = low >= 0;
-        if (tid < 3 && flat) {
+        if (tid < 108 && flat) {
             const int xa = (ox - 2 < 0 ? 0 : ox - 2) / RANGE_TILE, xb = (ox + TW + 1 > w - 1 ? w - 1 : ox + TW + 1) / RANGE_TILE;
             const int ya = (oy - 2 < 0 ? 0 : oy - 2) / RANGE_TILE, yb = (oy + PTH + 1 > h - 1 ? h - 1 : oy + PTH + 1) / RANGE_TILE;
-            int lo = 255, hi = 0;
-            for (int ty = ya; ty <= yb; ty++)
-                for (int tx = xa; tx <= xb; tx++) {
-                    const uint8_t* pr = trange + ((size_t)((f * 3 + tid) * trh + ty) * trw + tx) * 2;
-                    lo = lo < pr[0] ? lo : pr[0];
-                    hi = hi > pr[1] ? hi : pr[1];
-                }
-            flat = 6 * (hi - lo) <= low;
+            const int c = tid / 36, pair = tid % 36, ti = pair / 6, tj = pair % 6;
+            const int yi = ya + ti / 3, xi = xa + ti % 3, yj = ya + tj / 3, xj = xa + tj % 3;
+            if (yi <= yb && xi <= xb && yj <= yb && xj <= xb) {
+                const uint8_t* rc = trange + (size_t)(f * 3 + c) * trh * trw * 2;
+                const int hi = rc[((size_t)yi * trw + xi) * 2 + 1], lo = rc[((size_t)yj * trw + xj) * 2];
+                flat = 6 * (hi - lo) <= low;
+            }
         }
         if (__syncthreads_and(flat)) {
             for (int q = tid; q < PTH * 16; q += 256) {

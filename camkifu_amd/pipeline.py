@@ -177,7 +177,14 @@ def _take(frames, indices):
         return frames[indices[0]:indices[-1] + 1]
     if hasattr(frames, "index_select"):
         import torch
-        return frames.index_select(0, torch.as_tensor(indices, device=frames.device))
+        out = frames.index_select(0, torch.as_tensor(indices, device=frames.device))
+        if out.is_cuda:
+            # The index tensor dies with this statement, and torch hands a freed block to the next allocation on the same
+            # stream -- from ANY thread.  A lane thread that gets it for an output buffer has the library write it on the
+            # context's own stream, i.e. possibly before the gather above has run: the gather then reads indices that are no
+            # longer indices (a memory fault, seen once in five runs).  Wait for the gather before anything is freed.
+            torch.cuda.current_stream(out.device).synchronize()
+        return out
     return np.ascontiguousarray(np.asarray(frames)[list(indices)])
 
 
