@@ -399,10 +399,12 @@ def test_a_board_fold_exception_on_rank_0_reaches_every_rank():
         assert outcome[2].startswith("raised: a rank failed"), (rank, outcome)
 
 
-def test_lazy_board_fold_equals_the_eager_one():
+@pytest.mark.parametrize("plan_ahead", [True, False])
+def test_lazy_board_fold_equals_the_eager_one(plan_ahead):
     """BoardFold.run_lazy (records computed only for the frames the fold looks at: the reference skips K1..K6 during its
     hold-off) against BoardFold.run over the full records: same corners, same transform, same counters, batch after
-    batch -- with steady inputs, with hits that come later than predicted, with frames that show no board"""
+    batch -- with steady inputs, with hits that come later than predicted, with frames that show no board.  Both request
+    strategies: a hypothesis for the rest of the batch per request (plan_ahead) and window by window."""
     from camkifu_amd import capi
     from camkifu_amd.pipeline import BoardFold, LMAX
     from tests.test_fold_cpu import _hough_like, _sides
@@ -430,7 +432,7 @@ def test_lazy_board_fold_equals_the_eager_one():
             asked.append(len(idx))
             assert len(set(idx)) == len(idx) and min(idx) >= 0 and max(idx) < n
             return res[list(idx)], lines[list(idx)]
-        lazy.run_lazy(n, fetch)
+        lazy.run_lazy(n, fetch, plan_ahead=plan_ahead)
         a, b = eager.finder, lazy.finder
         assert (eager.mtx is None) == (lazy.mtx is None) and (eager.mtx is None or np.array_equal(eager.mtx, lazy.mtx))
         assert a.corners.hull == b.corners.hull and a.total_f_processed == b.total_f_processed
