@@ -216,6 +216,50 @@ def test_the_exchange_stage_does_not_gate_the_lanes():
 
 
 @pytest.mark.gpu
+def test_hold_off_aware_pipeline_equals_the_eager_one_on_the_gpu():
+    """FastFilePipeline(board_lazy=True) with the real kernels: the board fold asks the lanes' board contexts for the frames
+    of its hypotheses (non-consecutive frame sets: gathered on the device, see pipeline._take), the stones path runs on
+    every frame.  Requests, transform after every batch, game record and counters equal the eager pipeline's on the same
+    film, two batches in flight, a short hold-off so that several windows fall into every batch."""
+    import torch
+    from camkifu_amd import capi, pipeline
+    from camkifu_amd.controller import ControllerHeadless
+    from camkifu_amd.stone.nn_manager import NNManager
+    torch.cuda.set_device(0)
+    frames = _film(list(range(FILM)))
+    weights = NNManager.init_net()
+
+    def drive(lazy):
+        lanes = [(capi.Context(0, priority=1 if lazy else 0), capi.Context(0)) for _ in range(2)]
+        for _, c in lanes:
+            c.cnn_set_weights(weights)
+        ctrl = ControllerHeadless()
+        pipe = pipeline.FastFilePipeline(H, W, ctrl, lanes=lanes, ctx_bg=capi.Context(0), bg_init_frames=BG, board_lazy=lazy)
+        pipe.board.refresh_frames = 9                    # several windows per batch, and windows that straddle batches
+        tickets, emitted, mtxs = [], [], []
+        for b0 in range(0, FILM, BATCH):
+            tickets.append(pipe.submit(frames[b0:b0 + BATCH], BATCH))
+            if len(tickets) == 2:
+                emitted.append(pipe.finish(tickets.pop(0)))
+                mtxs.append(None if pipe.mtx is None else pipe.mtx.tolist())
+        while tickets:
+            emitted.append(pipe.finish(tickets.pop(0)))
+            mtxs.append(None if pipe.mtx is None else pipe.mtx.tolist())
+        b = pipe.board
+        out = dict(emitted=emitted, mtxs=mtxs, sgf=ctrl.kifu.to_sgf(), looked=b.looked, seen=b.seen, hold=b.hold, fetched=b.fetched, calls=b.calls)
+        pipe.close()
+        for pair in lanes:
+            for c in pair:
+                c.close()
+        return out
+    eager, lazy = drive(False), drive(True)
+    assert eager["mtxs"] == lazy["mtxs"] and any(m is not None for m in eager["mtxs"])
+    assert eager["emitted"] == lazy["emitted"] and eager["sgf"] == lazy["sgf"]
+    assert (eager["looked"], eager["seen"], eager["hold"]) == (lazy["looked"], lazy["seen"], lazy["hold"])
+    assert lazy["looked"] <= lazy["fetched"] < FILM and lazy["calls"] > 0, lazy
+
+
+@pytest.mark.gpu
 def test_closing_the_pipeline_then_the_contexts_with_a_batch_in_flight():
     """close() waits for the batches in flight, and ck_ctx_destroy waits for a thread still inside a call --
     the with-statement pattern (close the pipeline, drop the contexts) cannot free a stream under a lane's thread"""
