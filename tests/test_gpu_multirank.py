@@ -110,9 +110,19 @@ def _spawn(world, force_nccl=False):
     return [out for _, out in res]
 
 
+_ONE_RANK = []
+
+
+def _one_rank():
+    """the plain one-process run, made once for the tests that compare against it (a spawn costs ~30 s of imports)"""
+    if not _ONE_RANK:
+        _ONE_RANK.append(_spawn(1)[0])
+    return _ONE_RANK[0]
+
+
 @pytest.mark.gpu
 def test_two_ranks_with_real_kernels_equal_one_rank():
-    one = _spawn(1)[0]
+    one = _one_rank()
     changes = [k for k in range(1, len(one["mtxs"])) if one["mtxs"][k] != one["mtxs"][k - 1]]
     assert one["mtxs"][0] is not None and len(changes) >= 1, one["mtxs"]          # found, then moved by the bump
     assert any(req for batch in one["emitted"] for req in batch)                  # the policy did record stones
@@ -131,7 +141,7 @@ def test_the_exchange_stage_over_rccl_with_one_rank():
     told to run its whole exchange stage anyway -- all-gather of the records, transform broadcast, all-to-all of goban
     bands on device buffers, band model on its own context, counts gather, all issued from the exchange thread.  Same
     requests, transforms and game record as the plain one-rank run (which has no exchange stage at all)."""
-    plain = _spawn(1)[0]
+    plain = _one_rank()
     rccl = _spawn(1, force_nccl=True)[0]
     assert rccl["emitted"] == plain["emitted"] and rccl["mtxs"] == plain["mtxs"]
     assert rccl["sgf"] == plain["sgf"] and rccl["targets"] == plain["targets"]
