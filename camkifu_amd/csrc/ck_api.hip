@@ -229,7 +229,7 @@ void ck_ctx_destroy(ck_ctx* ctx)
                        &ctx->out_stage, &ctx->mats,
                        &ctx->cnn.c1w, &ctx->cnn.c1b, &ctx->cnn.c2w, &ctx->cnn.c2b, &ctx->cnn.c3w, &ctx->cnn.c3b,
                        &ctx->cnn.c4w, &ctx->cnn.c4b, &ctx->cnn.d1w, &ctx->cnn.d1b, &ctx->cnn.d2w, &ctx->cnn.d2b,
-                       &ctx->cnn.c2w_bf, &ctx->cnn.c3w_bf, &ctx->cnn.c4w_bf, &ctx->cnn.d1w_bf, &ctx->cnn.d1w_h2,
+                       &ctx->cnn.c2w_bf, &ctx->cnn.c3w_bf, &ctx->cnn.c4w_bf, &ctx->cnn.d1w_bf, &ctx->cnn.c1w_f16, &ctx->cnn.d1w_h2,
                        &ctx->cnn.c1w_h2, &ctx->cnn.c2w_h2, &ctx->cnn.c3w_h2, &ctx->cnn.c4w_h2 };
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (ctx->cnn_flag_host) (void)hipHostFree(ctx->cnn_flag_host);

@@ -1807,6 +1807,7 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
         CK_HIP(ctx, hipMemcpy(dst.p, v.data(), v.size() * 2, hipMemcpyHostToDevice));
         return CK_OK;
     };
+    CK_TRY(k_cnn_bf16_pack_conv1(ctx, host[0].data(), ctx->cnn.c1w_f16));
     CK_TRY(pack_bf(host[2].data(), 5, 5, 32, 32, 32, 32, ctx->cnn.c2w_bf));
     CK_TRY(pack_bf(host[4].data(), 3, 3, 32, 32, 90, 96, ctx->cnn.c3w_bf));
     CK_TRY(pack_bf(host[6].data(), 3, 3, 90, 96, 90, 96, ctx->cnn.c4w_bf));
@@ -1912,40 +1913,14 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
     float* h1 = p4_all + (size_t)nframes * 100 * 3240;
     const CnnWeights& W = ctx->cnn;
     if (ctx->cnn_mode == CK_CNN_BF16) {
-        // conv1 stays on the f32 MFMA (K = 75 is tiny; u8 pixels and f32 weights are exact) but
-        // writes bf16; conv2..4 and the first dense layer run v_mfma_f32_32x32x16_bf16
-        uint16_t* b1 = (uint16_t*)ctx->act0.p;           // conv1 out 36*36*32, later conv3 out 14*14*96
-        uint16_t* b2 = (uint16_t*)ctx->act1.p;           // conv2+pool out 16*16*32, later conv4 out 12*12*96
-        uint16_t* q4_all = (uint16_t*)ctx->act2.p;       // pooled conv4 out, all frames: 36*96
+        // k_cnn_bf16.hip: conv1 + conv2 and conv3 + conv4 fused, one bf16 MFMA per product (conv1 on the fp16 pipe: its u8
+        // operand is exact there); the first dense layer on v_mfma_f32_32x32x16_bf16
+        uint16_t* b2 = (uint16_t*)ctx->act1.p;           // pooled conv2 output of a chunk: 16*16*32 per patch
+        uint16_t* q4_all = (uint16_t*)ctx->act2.p;       // pooled conv4 output, all frames: 36*96 per patch
         float* hb = (float*)(q4_all + (((size_t)nframes * 100 * 3456 + 7) & ~(size_t)7));
         for (int f0 = 0; f0 < nframes; f0 += CHUNK) {
             const int nf = nframes - f0 < CHUNK ? nframes - f0 : CHUNK;
-            const int np = nf * 100;
-            const uint8_t* gob = d_goban + (size_t)f0 * 380 * 380 * 3;
-            uint16_t* q4 = q4_all + (size_t)f0 * 100 * 3456;
-            {
-                TimeScope ts(ctx, "cnn_conv1");
-                hipLaunchKernelGGL((conv1_mfma16_kernel<C1_R, true>), dim3(std::min(np * 3, C1_GRID)), dim3(64 * (27 / C1_R)), 0,
-                                   ctx->stream, gob, (const float*)W.c1w.p, (const float*)W.c1b.p, (void*)b1, np * 3);
-            }
-            {
-                TimeScope ts(ctx, "cnn_conv2");
-                hipLaunchKernelGGL((conv_mfma16_bf16_kernel<36, 36, 32, 5, 5, 32, 32, 16, 4, 4, true>), dim3(np, 4), dim3(512), 0,
-                                   ctx->stream, (const uint16_t*)b1, (const uint16_t*)W.c2w_bf.p, (const float*)W.c2b.p, b2);
-            }
-            uint16_t* b3 = b1;
-            {
-                TimeScope ts(ctx, "cnn_conv3");
-                hipLaunchKernelGGL((conv_mfma16_bf16_kernel<16, 16, 32, 3, 3, 90, 96, 13, 1, 2, false>), dim3(np), dim3(768), 0,
-                                   ctx->stream, (const uint16_t*)b2, (const uint16_t*)W.c3w_bf.p, (const float*)W.c3b.p, b3);
-            }
-            {
-                TimeScope ts(ctx, "cnn_conv4");
-                // pooled 6x6x96 written directly
-                hipLaunchKernelGGL((conv_mfma16_bf16_kernel<14, 14, 96, 3, 3, 90, 96, 9, 1, 2, true>), dim3(np), dim3(768), 0,
-                                   ctx->stream, (const uint16_t*)b3, (const uint16_t*)W.c4w_bf.p, (const float*)W.c4b.p, q4);
-            }
-            CK_HIP(ctx, hipGetLastError());
+            CK_TRY(k_cnn_bf16_convs(ctx, d_goban + (size_t)f0 * 380 * 380 * 3, nf * 100, b2, q4_all + (size_t)f0 * 100 * 3456));
         }
         TimeScope ts(ctx, "cnn_tail");
         const int np = nframes * 100;
