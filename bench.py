@@ -39,6 +39,7 @@ MFMA_F16_PEAK_TF = 2500.0        # dense fp16 / bf16 MFMA
 MACS = dict(cnn_conv1=311.04e6, cnn_conv2=2621.44e6, cnn_conv3=508.03e6, cnn_conv4=1049.76e6)
 FUSED_FILTER_BYTES = lambda h, w: 4 * h * w          # noqa: E731  read the frame once, write the edge map
 DST = [(0, 0), (380, 0), (380, 380), (0, 380)]
+DTYPE = {"fp32": "u8+f32", "bf16": "u8+bf16(f32 accumulate)", "f16x2": "u8+f16x2(f32 accumulate)"}
 
 
 def thresholds_per_tile(med):
@@ -367,6 +368,112 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- per-kernel durations: HIP events on each context's own stream over a short SERIAL pass (with the paths overlapped,
+    # an event pair on one stream also counts the time other streams hold the CUs); used after the timed region and by the
+    # secondary legs (bf16, 4K) at their own shape
+    prof_steps = 2
+    STAGE_NAMES = ["median", "canny_nms", "canny_hyst", "ccl", "contour_gather", "ghost", "hough_vote", "hough_peaks",
+                   "warp", "mog2", "cnn_conv1", "cnn_conv2", "cnn_conv3", "cnn_conv4", "cnn_tail"]
+
+    def stage_pass(fr, mtx, nf, board=True):
+        handle = ctx.mog2_create(380, 380)
+        rates = np.full(nf, 0.005)
+        # one untimed pass at this pass's own shape (a whole batch in one call): scratch buffers grow to it outside the brackets
+        if board:
+            ctx_b.board_detect(fr, cap=pipeline.LMAX, raw=True)
+        ctx.stones_run(fr, mtx, mog2=handle, learning_rates=rates)
+        torch.cuda.synchronize()
+        for c in (ctx, ctx_b):
+            c.timing_enable(True)
+            c.timing_reset()
+        for _ in range(prof_steps):
+            if board:
+                ctx_b.board_detect(fr, cap=pipeline.LMAX, raw=True)
+            ctx.stones_run(fr, mtx, mog2=handle, learning_rates=rates)
+        torch.cuda.synchronize()
+        st = {}
+        for nme in STAGE_NAMES:
+            ms, cnt = [a + b for a, b in zip(ctx.timing_get(nme), ctx_b.timing_get(nme))]
+            if cnt:
+                st[nme] = dict(ms_total=round(ms, 3), launches=cnt, us_per_frame=round(1e3 * ms / (prof_steps * nf), 3))
+        for c in (ctx, ctx_b):
+            c.timing_enable(False)
+        ctx.mog2_destroy(handle)
+        if st.get("cnn_conv1", {}).get("us_per_frame", 1.0) < 0.5:
+            st.pop("cnn_conv1", None)                     # conv1 runs inside conv2's kernel (f16x2 and bf16 modes)
+        return st
+
+    def counted_traffic(stage, per_launch):
+        """HBM bytes per launch from the committed PMC summary (separate rocprofv3 --pmc passes at this bench's shape:
+        counters cannot be collected inside the timed run) -> (bytes or None, where they come from)"""
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        if not files:
+            return None, None
+        try:
+            pmc = json.load(open(files[-1]))
+            row = pmc[stage]
+            calib = os.path.basename(files[-1]).split("_")[0] + "_fetch_calib.txt"
+            if not os.path.exists(os.path.join(ROOT, "profiles", calib)):
+                calib = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fetch_calib.txt")))[-1:]
+                calib = os.path.basename(calib[0]) if calib else "no calibration file"
+            src = "%s (collected at head %s on %s; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE counts half the bytes at every load width: profiles/%s)" % (
+                os.path.relpath(files[-1], ROOT), pmc.get("_head", "?"), pmc.get("_date", "?"), calib)
+            return int(row["hbm_bytes_corrected"] * per_launch), src
+        except (KeyError, ValueError, OSError):
+            return None, None
+
+    def roofline_of(stage, st, cnn, nf, hh, ww, with_traffic=True):
+        per_launch = prof_steps * nf / st[stage]["launches"]           # frames per launch
+        avg_s = st[stage]["ms_total"] / st[stage]["launches"] * 1e-3
+        fused1, fused34 = "cnn_conv1" not in st, "cnn_conv3" not in st
+        if stage in MACS:
+            peak = MFMA_F32_PEAK_TF if cnn == "fp32" else MFMA_F16_PEAK_TF
+            macs = MACS[stage]
+            if fused1 and stage == "cnn_conv2":
+                macs += MACS["cnn_conv1"]
+            if fused34 and stage == "cnn_conv4":
+                macs += MACS["cnn_conv3"]
+            ach = 2.0 * macs * per_launch / avg_s / 1e12              # ALGORITHMIC flops (SURVEY 8a), not executed MFMAs
+            tr, tr_src = counted_traffic(stage, per_launch) if with_traffic else (None, None)
+            r = dict(kernel=stage, bound="mfma", achieved=round(ach, 3), peak=peak, unit="TFLOP/s",
+                     frac=round(ach / peak, 5), traffic=tr, traffic_source=tr_src)
+            if cnn == "f16x2":
+                mult = (3.0 * macs - (MACS["cnn_conv1"] if fused1 and stage == "cnn_conv2" else 0.0)) / macs
+                r["executed_mfma_frac"] = round(mult * ach / peak, 5)
+                r["note"] = ("split precision: every f32-equivalent product is three fp16 MFMAs (two in conv1); `frac` prices "
+                             "the ALGORITHMIC flops against the fp16 peak, executed_mfma_frac the instructions executed")
+            return r
+        per_frame = {"median": 2 * 3 * ww * hh, "canny_nms": 4 * ww * hh, "warp": 433200 + 3 * ww * hh, "ccl": 6 * ww * hh,
+                     "canny_hyst": 2 * ww * hh, "mog2": 433200 + 1444}.get(stage, 4 * ww * hh)
+        ach = per_frame * per_launch / avg_s / 1e9
+        tr, tr_src = counted_traffic(stage, per_launch) if with_traffic else (None, None)
+        r = dict(kernel=stage, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                 frac=round(ach / HBM_PEAK_GBS, 5), traffic=tr, traffic_source=tr_src,
+                 algorithmic_bytes_per_launch=int(per_frame * per_launch), avg_launch_ms=round(avg_s * 1e3, 4))
+        if stage == "median":
+            r["note"] = ("nominally HBM-bound (SURVEY 8d: 2 x 3WH bytes per frame), in fact bound by the matrix pipe: per 48x48 "
+                         "tile and 16-pixel block one 15x15 box count (10 i8 MFMAs + 12 updates) per threshold looked at -- a "
+                         "linear scan around the sample mean on flat tiles, a radix descent elsewhere; `traffic` is read from "
+                         "the committed PMC summary (separate rocprofv3 --pmc passes at this run's shape), not measured here")
+        return r
+
+    def filter_fused_of(st, hh, ww):
+        us = sum(st[x]["us_per_frame"] for x in ("median", "canny_nms", "canny_hyst") if x in st)
+        gbs = FUSED_FILTER_BYTES(hh, ww) / (us * 1e-6) / 1e9
+        return dict(bytes_per_frame=FUSED_FILTER_BYTES(hh, ww), us_per_frame=round(us, 3), achieved=round(gbs, 2), unit="GB/s",
+                    frac=round(gbs / HBM_PEAK_GBS, 5),
+                    note="SURVEY 8d's fused floor (read the frame once, write the edge map) over median + NMS + hysteresis")
+
+    def game_quality(reqs, truth_, moves_, nt):
+        import difflib
+        sym = "EBW"
+        first = [(sym[truth_[50][r, c]], r, c) for r in range(19) for c in range(19) if truth_[50][r, c]]
+        played = [(sym[col], r, c) for col, r, c, f in moves_ if f + 14 < nt]
+        seen = [m for per_frame in reqs for kind, ms in per_frame for m in ms]
+        ratio = difflib.SequenceMatcher(a=["%s%d,%d" % m for m in first + played], b=["%s%d,%d" % m for m in seen]).ratio()
+        return round(ratio, 4), len(first) + len(played), len(seen)
+
     # ---- untimed: find the board (the stones path needs its transform), then one validated pass ---------------------
     pipe.process_batch(frames, n_total)
     board_found = pipe.mtx is not None
@@ -376,14 +483,7 @@ def main():
     requests = pipe.process_batch(frames, n_total)            # fresh policy, fresh background model: frames 0 .. n_total-1
     quality = {}
     if rank == 0:
-        sym = "EBW"
-        first = [(sym[truth[50][r, c]], r, c) for r in range(19) for c in range(19) if truth[50][r, c]]
-        played = [(sym[col], r, c) for col, r, c, f in true_moves if f + 14 < n_total]
-        seen = [m for per_frame in requests for kind, ms in per_frame for m in ms]
-        import difflib
-        quality["move_sequence_ratio"] = round(difflib.SequenceMatcher(a=["%s%d,%d" % m for m in first + played],
-                                                                       b=["%s%d,%d" % m for m in seen]).ratio(), 4)
-        quality["moves_true"], quality["moves_recorded"] = len(first) + len(played), len(seen)
+        quality["move_sequence_ratio"], quality["moves_true"], quality["moves_recorded"] = game_quality(requests, truth, true_moves, n_total)
     # 19x19 grids of this rank's frames against the truth (frames with a hand over the board excluded)
     if not args.timed_only:                                   # (a 64-frame launch: kept out of the profiling runs)
         calm = ~hands[mine]
@@ -392,24 +492,25 @@ def main():
         quality["stone_grid_match_pct"] = round(100.0 * float((grid[calm[:64]] == truth[mine[:64]][calm[:64]]).mean()), 3)
 
     # ---- timed region: two batches in flight ------------------------------------------------------------------------
-    def run_steps(p, k, batch):
+    def run_steps(p, k, batch, nt):
         DEPTH = int(os.environ.get("CK_BENCH_DEPTH", "2"))      # batches in flight (developer knob; 3 measured no faster)
-        tickets = [p.submit(batch, n_total) for _ in range(min(DEPTH, k))]
+        tickets = [p.submit(batch, nt) for _ in range(min(DEPTH, k))]
         for i in range(k):
             t = tickets.pop(0)
             if i + DEPTH < k:
-                tickets.append(p.submit(batch, n_total))
+                tickets.append(p.submit(batch, nt))
             p.stones = pipeline.StonesFold(ControllerHeadless())        # every step folds the same film from its start
             p.finish(t)
 
-    def timed(p, steps, warmup, batch):
+    def timed(p, steps, warmup, batch, nt=None):
+        nt = n_total if nt is None else nt
         if warmup:
-            run_steps(p, warmup, batch)
+            run_steps(p, warmup, batch, nt)
         sync()
         for k in p.host_seconds:
             p.host_seconds[k] = 0.0
         t0 = time.perf_counter()
-        run_steps(p, steps, batch)
+        run_steps(p, steps, batch, nt)
         sync()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -446,6 +547,39 @@ def main():
                                         note="same timed region with CK_CNN_FP32 (k-ordered f32 MFMA chain)")
             for _, c in lanes:
                 c.cnn_set_mode(mode)
+        # (1a) BASELINE config 5's classifier at this rank count: the same timed region with the stone classifier in bf16
+        # (k_cnn_bf16.hip: one bf16 MFMA per product, conv1 + conv2 and conv3 + conv4 fused).  With --streams every rank
+        # runs exactly this on its own film; at one rank the two coincide.  Same game record as the default mode required.
+        if args.cnn != "bf16":
+            for _, c in lanes:
+                c.cnn_set_mode(capi.CK_CNN_BF16)
+            pb = new_pipe()
+            pb.process_batch(frames, n_total)
+            if pb.mtx is None:
+                pb.mtx = M_true
+            req_b = pb.process_batch(frames, n_total)
+            k = max(6, args.steps // 2)
+            db = timed(pb, k, 2, frames)
+            pb.close()
+            leg = dict(value=round((world if args.streams else 1) * n_total * k / db, 2), unit="frames/s", steps=k, dtype=DTYPE["bf16"],
+                       same_game_record=bool(req_b == requests),
+                       note="BASELINE config 5 (one 1080p stream per GPU, stone-CNN in bf16 on MFMA) at this run's rank count: the "
+                            "headline's timed region with CK_CNN_BF16; labels are held to the oracle's by "
+                            "tests/test_gpu_fullsize.py::test_config5_bf16_labels_against_the_oracle, the filter maps to 3e-2")
+            if rank == 0:
+                st_b = stage_pass(frames, M, F, board=False)
+                conv_b = {x: st_b[x] for x in st_b if x.startswith("cnn_")}
+                leg["move_sequence_ratio"] = game_quality(req_b, truth, true_moves, n_total)[0]
+                gb = pipeline.grid_of(ctx.stones_run(frames[:64], M)["region_label"].cpu().numpy())
+                calm = ~hands[mine]
+                leg["stone_grid_match_pct"] = round(100.0 * float((gb[calm[:64]] == truth[mine[:64]][calm[:64]]).mean()), 3)
+                leg["stages"] = conv_b
+                leg["classifier_us_per_frame"] = round(sum(v["us_per_frame"] for v in conv_b.values()), 3)
+                leg["mfma_kernel"] = roofline_of(max((x for x in conv_b if x in MACS), key=lambda x: conv_b[x]["ms_total"]), st_b, "bf16", F, H, W,
+                                                 with_traffic=False)
+            for _, c in lanes:
+                c.cnn_set_mode(mode)
+            extras["bf16_streams"] = leg
         # (1b) hold-off-aware scheduling (one rank): the reference does not run K1..K6 during the hold-off after a hit
         # (bf_auto.py:43-49); here the fold computes only the board records it looks at.  NOT the headline workload
         # (that one is the per-frame hot path on every frame); same game record required.
@@ -591,93 +725,43 @@ def main():
                                                  "answers on the host; never the headline value")
             del host_i420, landing
 
+        # (3) BASELINE config 4's frame size on this GPU: 3840 x 2160, 64-frame batches, its own film and pipeline
+        if world == 1:
+            H4, W4, F4 = 2160, 3840, 64
+            fr4, corners4, truth4, moves4, hands4 = synth.film(F4, H4, W4, seed=synth.SEED, device=dev, quiet=52, move_every=32, hand_frames=12)
+            p4 = pipeline.FastFilePipeline(H4, W4, ControllerHeadless(), rank=0, world=1, device=cdev, lanes=lanes, ctx_bg=ctx_bg)
+            p4.process_batch(fr4, F4)
+            found4 = p4.mtx is not None
+            if not found4:
+                p4.mtx = capi.get_perspective_transform(corners4, np.array(DST, np.float32))
+            M4 = p4.mtx.copy()
+            req4 = p4.process_batch(fr4, F4)
+            k = max(6, args.steps // 2)
+            d4 = timed(p4, k, 2, fr4, F4)
+            p4.close()
+            st4 = stage_pass(fr4, M4, F4)
+            g4 = pipeline.grid_of(ctx.stones_run(fr4, M4)["region_label"].cpu().numpy())
+            calm4 = ~np.asarray(hands4)
+            ratio4, n_true4, n_seen4 = game_quality(req4, truth4, moves4, F4)
+            extras["uhd_4k"] = dict(
+                value=round(F4 * k / d4, 2), unit="frames/s", steps=k, ms_per_step=round(1e3 * d4 / k, 3), frames_per_batch=F4, height=H4, width=W4,
+                board_found_by_fold=found4, move_sequence_ratio=ratio4, moves_true=n_true4, moves_recorded=n_seen4,
+                stone_grid_match_pct=round(100.0 * float((g4[calm4] == np.asarray(truth4)[calm4]).mean()), 3),
+                stages=st4, filter_pass=roofline_of("median", st4, args.cnn, F4, H4, W4, with_traffic=False),
+                filter_pass_fused=filter_fused_of(st4, H4, W4),
+                note="BASELINE config 4's frame size (3840 x 2160) in 64-frame batches resident in HBM on ONE GPU: same pipeline, same "
+                     "timed-region protocol as the headline; the 8-GPU half of config 4 is the driver's scaling run")
+            del fr4
+
     sync()
-    # ---- per-kernel durations: HIP events on each context's own stream over a short SERIAL pass right after the timed
-    # region (with the paths overlapped, an event pair on one stream also counts the time other streams hold the CUs)
-    prof_steps = 2
     out_line = None
     if rank == 0:
-        handle = ctx.mog2_create(380, 380)
-        rates = np.full(F, 0.005)
-        # one untimed pass at this pass's own shape (a whole batch in one call): scratch buffers grow to it outside the brackets
-        ctx_b.board_detect(frames, cap=pipeline.LMAX, raw=True)
-        ctx.stones_run(frames, M, mog2=handle, learning_rates=rates)
-        torch.cuda.synchronize()
-        for c in (ctx, ctx_b):
-            c.timing_enable(True)
-            c.timing_reset()
-        for _ in range(prof_steps):
-            ctx_b.board_detect(frames, cap=pipeline.LMAX, raw=True)
-            ctx.stones_run(frames, M, mog2=handle, learning_rates=rates)
-        torch.cuda.synchronize()
-        names = ["median", "canny_nms", "canny_hyst", "ccl", "contour_gather", "ghost", "hough_vote", "hough_peaks",
-                 "warp", "mog2", "cnn_conv1", "cnn_conv2", "cnn_conv3", "cnn_conv4", "cnn_tail"]
-        stages = {}
-        for nme in names:
-            ms, cnt = [a + b for a, b in zip(ctx.timing_get(nme), ctx_b.timing_get(nme))]
-            if cnt:
-                stages[nme] = dict(ms_total=round(ms, 3), launches=cnt, us_per_frame=round(1e3 * ms / (prof_steps * F), 3))
-        for c in (ctx, ctx_b):
-            c.timing_enable(False)
-        fused_conv1 = args.cnn == "f16x2" and stages.get("cnn_conv1", {}).get("us_per_frame", 1.0) < 0.5
-        if fused_conv1:
-            del stages["cnn_conv1"]                       # conv1 runs inside conv2's staging in the default mode
-        fused_conv34 = args.cnn == "f16x2" and "cnn_conv4" in stages and "cnn_conv3" not in stages
-
-        def counted_traffic(stage, per_launch):
-            """HBM bytes per launch from the committed PMC summary (separate rocprofv3 --pmc passes at this bench's shape:
-            counters cannot be collected inside the timed run) -> (bytes or None, where they come from)"""
-            import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-            if not files:
-                return None, None
-            try:
-                pmc = json.load(open(files[-1]))
-                row = pmc[{"cnn_conv2": "cnn_conv2", "cnn_conv4": "cnn_conv4"}.get(stage, stage)]
-                src = "%s (collected at head %s on %s; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE counts half the bytes at every load width: profiles/r04_fetch_calib.txt)" % (
-                    os.path.relpath(files[-1], ROOT), pmc.get("_head", "?"), pmc.get("_date", "?"))
-                return int(row["hbm_bytes_corrected"] * per_launch), src
-            except (KeyError, ValueError, OSError):
-                return None, None
+        stages = stage_pass(frames, M, F)
 
         def roof_of(stage):
-            per_launch = prof_steps * F / stages[stage]["launches"]           # frames per launch
-            avg_s = stages[stage]["ms_total"] / stages[stage]["launches"] * 1e-3
-            if stage in MACS:
-                f32_kernel = args.cnn == "fp32" or (args.cnn == "bf16" and stage == "cnn_conv1")
-                peak = MFMA_F32_PEAK_TF if f32_kernel else MFMA_F16_PEAK_TF
-                macs = MACS[stage]
-                if fused_conv1 and stage == "cnn_conv2":
-                    macs += MACS["cnn_conv1"]
-                if fused_conv34 and stage == "cnn_conv4":
-                    macs += MACS["cnn_conv3"]
-                ach = 2.0 * macs * per_launch / avg_s / 1e12              # ALGORITHMIC flops (SURVEY 8a), not executed MFMAs
-                tr, tr_src = counted_traffic(stage, per_launch)
-                r = dict(kernel=stage, bound="mfma", achieved=round(ach, 3), peak=peak, unit="TFLOP/s",
-                         frac=round(ach / peak, 5), traffic=tr, traffic_source=tr_src)
-                if args.cnn == "f16x2":
-                    mult = (3.0 * macs - (MACS["cnn_conv1"] if fused_conv1 and stage == "cnn_conv2" else 0.0)) / macs
-                    r["executed_mfma_frac"] = round(mult * ach / peak, 5)
-                    r["note"] = ("split precision: every f32-equivalent product is three fp16 MFMAs (two in conv1); `frac` prices "
-                                 "the ALGORITHMIC flops against the fp16 peak, executed_mfma_frac the instructions executed")
-                return r
-            per_frame = {"median": 2 * 3 * W * H, "canny_nms": 4 * W * H, "warp": 433200 + 3 * W * H, "ccl": 6 * W * H,
-                         "canny_hyst": 2 * W * H, "mog2": 433200 + 1444}.get(stage, 4 * W * H)
-            ach = per_frame * per_launch / avg_s / 1e9
-            tr, tr_src = counted_traffic(stage, per_launch)
-            r = dict(kernel=stage, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                     frac=round(ach / HBM_PEAK_GBS, 5), traffic=tr, traffic_source=tr_src,
-                     algorithmic_bytes_per_launch=int(per_frame * per_launch), avg_launch_ms=round(avg_s * 1e3, 4))
-            if stage == "median":
-                r["note"] = ("nominally HBM-bound (SURVEY 8d: 2 x 3WH bytes per frame), in fact bound by the matrix pipe: per 48x48 "
-                             "tile and 16-pixel block one 15x15 box count (10 i8 MFMAs + 12 updates) per threshold looked at -- a "
-                             "linear scan around the sample mean on flat tiles, a radix descent elsewhere; `traffic` is read from "
-                             "the committed PMC summary (separate rocprofv3 --pmc passes at this run's shape), not measured here")
-            return r
+            return roofline_of(stage, stages, args.cnn, F, H, W)
         dom = max(stages, key=lambda s: stages[s]["ms_total"])
         conv = [s for s in stages if s in MACS]
-        filt_us = sum(stages[s]["us_per_frame"] for s in ("median", "canny_nms", "canny_hyst") if s in stages)
-        fused = FUSED_FILTER_BYTES(H, W) / (filt_us * 1e-6) / 1e9
         out_line = {
             "metric": "frames/sec on 1920x1080 video + 19x19 stone-grid match % vs reference SGF",
             "value": round((world if args.streams else 1) * n_total * args.steps / dt, 2),
@@ -685,7 +769,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "u8+f32", "bf16": "u8+bf16", "f16x2": "u8+f16x2(f32 accumulate)"}[args.cnn], "data": "synthetic",
+            "dtype": DTYPE[args.cnn], "data": "synthetic",
             "config": {"workload": "%dx%d synthetic video (a filmed game with hands), %d-frame batch per GPU, FRAMES RESIDENT IN HBM "
                                    "(rendered there before the timed region); per frame board detect K1-K6 + stones path K8, K9, "
                                    "K10-K12 (cnn %s); records gathered and folded in order by the library's policy" % (W, H, F, args.cnn),
@@ -694,9 +778,7 @@ def main():
             "roofline": roof_of(dom),
             "mfma_kernel": roof_of(max(conv, key=lambda s: stages[s]["ms_total"])) if conv else None,
             "filter_pass": roof_of("median") if "median" in stages else None,
-            "filter_pass_fused": dict(bytes_per_frame=FUSED_FILTER_BYTES(H, W), us_per_frame=round(filt_us, 3),
-                                      achieved=round(fused, 2), unit="GB/s", frac=round(fused / HBM_PEAK_GBS, 5),
-                                      note="SURVEY 8d's fused floor (read the frame once, write the edge map) over median + NMS + hysteresis"),
+            "filter_pass_fused": filter_fused_of(stages, H, W),
             "stages": stages,
             "stage_timing": "HIP events per context stream over %d serial steps after the timed region (256-frame launches); "
                             "the timed region overlaps board and stones paths of two lanes on five streams" % prof_steps,

@@ -11,7 +11,7 @@
 //              this part against 138 for 32x32x2 (tools/micro/mfma_peak.hip).  f32 MFMA runs on the
 //              vector ALUs (same 157.3 TFLOP/s peak): it does not overlap VALU work of other waves
 //              (tools/micro/coexec.hip), so MFMA-bound and VALU-bound kernels simply add up.
-//   bf16 mode: v_mfma_f32_32x32x16_bf16, fp32 accumulate (conv1 stays f32: K = 75 is tiny).
+//   bf16 mode: k_cnn_bf16.hip (conv1 + conv2 and conv3 + conv4 fused, one bf16 MFMA per product); here only its dense tail.
 // A (activations) is staged in LDS with pixel / row strides chosen so that one ds_read_b32 of a
 // half-wave hits 32 distinct banks; B (weights) streams from L2 as coalesced dwordx4 fragments and
 // is reused by the R register-blocked pixel tiles of a wave.  Wave counts per workgroup are
@@ -371,11 +371,11 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN)) void conv_mfm
 // consecutive channels of one pixel and the result leaves as 16-byte stores.
 //   work unit = 12 output rows of one patch = 27 pixel tiles, WAVES waves x R tiles
 //   wf : [2 channel tiles][19 steps][64 lanes] f32 (pack_conv1)
-//   out: [patch][36*36][32] f32 (or bf16 when OUTBF)
-template <int R, bool OUTBF>
+//   out: [patch][36*36][32] f32
+template <int R>
 __global__ __launch_bounds__(64 * (27 / R)) void conv1_mfma16_kernel(
     const uint8_t* __restrict__ goban, const float* __restrict__ wf, const float* __restrict__ bias,
-    void* __restrict__ out_, int nunits)
+    float* __restrict__ out, int nunits)
 {
 #pragma clang fp contract(off)
     constexpr int WAVES = 27 / R, NTHREADS = 64 * WAVES;
@@ -468,156 +468,15 @@ __global__ __launch_bounds__(64 * (27 / R)) void conv1_mfma16_kernel(
                 float4 v;
                 v.x = acc[r][n][0] + bv[n].x; v.y = acc[r][n][1] + bv[n].y; v.z = acc[r][n][2] + bv[n].z; v.w = acc[r][n][3] + bv[n].w;
                 v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-                if constexpr (OUTBF) {
-                    uint2 pk;
-                    pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-                    pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out_) + m * 32 + n * 16 + 4 * kq) = pk;
-                } else {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out_) + m * 32 + n * 16 + 4 * kq) = v;
-                }
+                *reinterpret_cast<float4*>(out + m * 32 + n * 16 + 4 * kq) = v;
             }
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// bf16 mode (CK_CNN_BF16): the same implicit GEMM on v_mfma_f32_16x16x32_bf16 (fp32 accumulate).
-// Same work split, tiling, in-lane pooling and wave balance as conv_mfma16_f32_kernel; one k-step is
-// 32 input channels of one kernel tap (a lane's fragment = 8 consecutive channels = one ds_read_b128).
-//   in : [patch][H][W][CINP] bf16, CINP a multiple of 32 (padding channels are zero)
-//   wt : [16-channel tile][k-step][lane][8] bf16 (pack_mfma16_bf16): a wave's B operand is one coalesced 1 KB load
-//   out: [patch][pixels or pooled][COUTS] bf16 (channels >= COUT written as zero)
-// LDS pixel stride is CINP + 8 elements (16-byte fragments of 8 consecutive pixels land on disjoint bank
-// groups); the row stride keeps that walk going across a tile's row wrap / its second pixel row.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __host__ __device__ constexpr int lds_stride_b(int n, int rem, int mod) { return n + ((rem - n % mod) + mod) % mod; }
-
-template <int H, int W, int CINP, int KH, int KW, int COUT, int COUTS, int TB, int YB, int WAVES_M, bool POOL>
-__global__ __launch_bounds__(64 * WAVES_M * (COUTS / 16)) void conv_mfma16_bf16_kernel(
-    const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt, const float* __restrict__ bias,
-    uint16_t* __restrict__ out)
-{
-    constexpr int OH = H - KH + 1, OW = W - KW + 1, M = OH * OW;
-    constexpr int NT = COUTS / 16;
-    static_assert(CINP % 32 == 0 && COUTS % 16 == 0, "channels padded to the MFMA shape");
-    constexpr int CS = CINP + 8;                                   // elements; 2*CS = 80 (mod 128) bytes
-    // row stride in elements: bytes = 64 (mod 128) for 4x4 pooling tiles, = 80*OW (mod 128) for plain tiles
-    constexpr int RS = lds_stride_b(W * CS, POOL ? 32 : (40 * OW) % 64, 64);
-    constexpr int KS = KH * KW * (CINP / 32);
-    constexpr int NTHREADS = 64 * WAVES_M * NT;
-    constexpr int R = cdiv(TB, WAVES_M);
-    constexpr int RT = POOL ? (OH / 4) * (OW / 4) : cdiv(M, 16);
-    static_assert(TB * YB >= RT && R * WAVES_M - TB <= 1, "tile split");
-    static_assert(!POOL || (OW % 4 == 0 && OH % 4 == 0 && TB % (OW / 4) == 0), "pooling tiles are 4x4 output pixels");
-    constexpr int ROWS_RAW = POOL ? 4 * (TB / (OW / 4)) + KH - 1 : (TB * 16 + OW - 2) / OW + 1 + KH - 1;
-    constexpr int ROWS = ROWS_RAW < H ? ROWS_RAW : H;
-    __shared__ __attribute__((aligned(16))) uint16_t lds[ROWS * RS];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave % NT, wm = wave / NT;
-    const int l15 = lane & 15, kq = lane >> 4;
-    const int patch = blockIdx.x;
-    const int tile_blk = blockIdx.y * TB;
-    const int oy_min = POOL ? 4 * (tile_blk / (OW / 4)) : (tile_blk * 16) / OW;
-    int row_cnt = H - oy_min;
-    if (row_cnt > ROWS) row_cnt = ROWS;
-    {
-        constexpr int CH8 = CINP / 8;
-        const uint4* g = reinterpret_cast<const uint4*>(in + ((size_t)patch * H + oy_min) * W * CINP);
-        const int total = row_cnt * W * CH8;
-#pragma unroll 4
-        for (int i = tid; i < total; i += NTHREADS) {
-            const int pxl = i / CH8, ch = i % CH8;
-            *reinterpret_cast<uint4*>(&lds[(pxl / W) * RS + (pxl % W) * CS + ch * 8]) = g[i];
-        }
-    }
-    __syncthreads();
-
-    const int tile0 = tile_blk + wm * R;
-    int abase[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        int t = tile0 + r;
-        if (t > RT - 1) t = RT - 1;
-        int oy, ox;
-        if constexpr (POOL) {
-            const int ty = t / (OW / 4), tx = t % (OW / 4), q = l15 >> 2, sub = l15 & 3;
-            oy = 4 * ty + 2 * (q >> 1) + (sub >> 1);
-            ox = 4 * tx + 2 * (q & 1) + (sub & 1);
-        } else {
-            int m = t * 16 + l15;
-            if (m > M - 1) m = M - 1;
-            oy = m / OW; ox = m % OW;
-        }
-        abase[r] = (oy - oy_min) * RS + ox * CS + 8 * kq;
-    }
-    f32x4 acc[R];
-#pragma unroll
-    for (int r = 0; r < R; r++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) acc[r][e] = 0.f;
-
-    int nv = TB - wm * R;
-    nv = nv > R ? R : nv;
-    const uint4* wq = reinterpret_cast<const uint4*>(wt) + (size_t)wn * KS * 64 + lane;
-    auto k_loop = [&](auto nv_tag) {
-        constexpr int NV = decltype(nv_tag)::value;
-        constexpr int PF = 4;
-        uint4 bq[PF];
-#pragma unroll
-        for (int u = 0; u < PF; u++) bq[u] = u < KS ? wq[(size_t)u * 64] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < KH; i++) {
-#pragma unroll
-            for (int j = 0; j < KW; j++) {
-#pragma unroll
-                for (int cc = 0; cc < CINP / 32; cc++) {
-                    const int step = (i * KW + j) * (CINP / 32) + cc;
-                    const bf16x8 b = __builtin_bit_cast(bf16x8, bq[step % PF]);
-                    if (step + PF < KS) bq[step % PF] = wq[(size_t)(step + PF) * 64];
-#pragma unroll
-                    for (int r = 0; r < NV; r++) {
-                        const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&lds[abase[r] + i * RS + j * CS + 32 * cc]));
-                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[r], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    };
-    if (nv == R) k_loop(std::integral_constant<int, R>{});
-    else if constexpr (R * WAVES_M > TB) k_loop(std::integral_constant<int, R - 1>{});
-
-    const int co = wn * 16 + l15;
-    const float bv = co < COUT ? bias[co] : 0.f;
-    if constexpr (POOL) {
-        uint16_t* o = out + (size_t)patch * (M / 4) * COUTS;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int t = tile0 + r;
-            float mx = acc[r][0] > acc[r][1] ? acc[r][0] : acc[r][1];
-            const float m2 = acc[r][2] > acc[r][3] ? acc[r][2] : acc[r][3];
-            mx = mx > m2 ? mx : m2;
-            mx = mx + bv;
-            mx = mx > 0.f ? mx : 0.f;
-            const int py = 2 * (t / (OW / 4)) + (kq >> 1), px = 2 * (t % (OW / 4)) + (kq & 1);
-            if (r < nv && t < RT) o[(size_t)(py * (OW / 2) + px) * COUTS + co] = co < COUT ? f2bf(mx) : (uint16_t)0;
-        }
-    } else {
-        uint16_t* o = out + (size_t)patch * M * COUTS;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int m = (tile0 + r) * 16 + 4 * kq + e;
-                float v = acc[r][e] + bv;
-                v = v > 0.f ? v : 0.f;
-                if (r < nv && m < M) o[(size_t)m * COUTS + co] = co < COUT ? f2bf(v) : (uint16_t)0;
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // Split-precision mode (CK_CNN_F16X2): f32-accurate convolutions on the fp16 matrix pipe.
@@ -1946,8 +1805,8 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
                 hipLaunchKernelGGL((conv1_h2_kernel<C1_R>), dim3(std::min(np * 3, C1_GRID)), dim3(64 * (27 / C1_R)), 0, ctx->stream, gob,
                                    (const uint16_t*)W.c1w_h2.p, (const float*)W.c1b.p, a1, np * 3, 1.f / H2_WSCALE);
             else
-            hipLaunchKernelGGL((conv1_mfma16_kernel<C1_R, false>), dim3(std::min(np * 3, C1_GRID)), dim3(64 * (27 / C1_R)), 0,
-                               ctx->stream, gob, (const float*)W.c1w.p, (const float*)W.c1b.p, (void*)a1, np * 3);
+            hipLaunchKernelGGL((conv1_mfma16_kernel<C1_R>), dim3(std::min(np * 3, C1_GRID)), dim3(64 * (27 / C1_R)), 0,
+                               ctx->stream, gob, (const float*)W.c1w.p, (const float*)W.c1b.p, a1, np * 3);
         }
         {
             TimeScope ts(ctx, "cnn_conv2");

@@ -18,11 +18,35 @@
 #ifndef BF_C12_MINW
 #define BF_C12_MINW 3        // workgroups (of four waves) per CU the compiler is asked to leave room for: 3 x 54 KB of LDS
 #endif
+#ifndef BF_C2_D
+#define BF_C2_D 5            // conv2: depth of the fragment ring (reads in flight + the one in use)
+#endif
+#ifndef BF_DBG_TIME
+#define BF_DBG_TIME 0        // profiling aid: phase times per workgroup (wave 0, 100 MHz wall clock) summed into g_bf_prof,
+#endif                       // printed by the host after every launch pair
+#ifndef BF_C3_D
+#define BF_C3_D 4            // conv3: depth of the fragment ring
+#endif
+#ifndef BF_C4_D
+#define BF_C4_D 6            // conv4: depth of the fragment ring (two MFMAs per fragment)
+#endif
+#ifndef BF_C4_PF
+#define BF_C4_PF 2           // conv4: k-steps the weight fragments run ahead
+#endif
 #ifndef BF_C34_MINW
 #define BF_C34_MINW 3        // 4 workgroups of three waves per CU
 #endif
 
 namespace {
+
+#if BF_DBG_TIME
+__device__ unsigned long long g_bf_prof[16];
+#define BF_STAMP(K) do { if (threadIdx.x == 0) { const unsigned long long now__ = wall_clock64(); atomicAdd(&g_bf_prof[K], now__ - t_prev__); t_prev__ = now__; } } while (0)
+#define BF_STAMP_BEGIN unsigned long long t_prev__ = wall_clock64()
+#else
+#define BF_STAMP(K) do { } while (0)
+#define BF_STAMP_BEGIN do { } while (0)
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -78,6 +102,7 @@ __global__ __launch_bounds__(256, BF_C12_MINW) void conv12_bf16_kernel(
     const int patch = blockIdx.x >> 1, half = blockIdx.x & 1;
     const int frame = patch / 100, reg = patch % 100;
     const int py0 = region_origin(reg / 10) + 16 * half, px0 = region_origin(reg % 10);
+    BF_STAMP_BEGIN;
 
     // ---- the 24 x 40 pixels this half needs, as halves: a thread turns 12 bytes (4 pixels) into 32.  Byte b becomes the
     // half 0x6400 | b = 1024 + b (one v_perm_b32 per two values against a constant), minus 1024 by one packed subtraction.
@@ -121,6 +146,7 @@ __global__ __launch_bounds__(256, BF_C12_MINW) void conv12_bf16_kernel(
         foff[s] = (f / 3) * C12_PIX_RS + 8 * (f % 3);
     }
     __syncthreads();
+    BF_STAMP(0);                                           // pixels staged, conv1's weights here
 
     // ---- conv1: 20 rows x 36 pixels = 45 tiles of 16 raster pixels.  D = W x P: a lane ends up with four consecutive
     // channels of one pixel per channel tile -> relu, two packed conversions, one 8-byte store into the swizzled tile.
@@ -145,7 +171,9 @@ __global__ __launch_bounds__(256, BF_C12_MINW) void conv12_bf16_kernel(
             *reinterpret_cast<uint2*>(tp + (((2 * n + (kq >> 1)) ^ sw) << 3)) = v;
         }
     }
+    BF_STAMP(1);                                           // wave 0's conv1 tiles
     __syncthreads();
+    BF_STAMP(2);                                           // ... the other waves'
 
     // ---- conv2: wave = (channel tile n, 8 output rows, both 16-column strips).  Per tap column j the five weight
     // fragments (taps (0..4, j)) are held in registers (the next column's are in flight); input row y of a strip is read
@@ -163,33 +191,48 @@ __global__ __launch_bounds__(256, BF_C12_MINW) void conv12_bf16_kernel(
     uint4 bq[2][5];
 #pragma unroll
     for (int i = 0; i < 5; i++) bq[0][i] = wq[(i * 5) * 64];
+    // The 120 fragment reads (5 tap columns x 12 input rows x 2 strips) run BF_C2_D - 1 reads ahead of their MFMAs through a
+    // register ring, the next column's weights are requested when a column starts; scheduling barriers keep the compiler
+    // from sinking either next to its first use (which is what it does otherwise: 2 reads, lgkmcnt(1), 5 MFMAs, ...).
+    int ab[5][2];
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
-        if (j + 1 < 5) {
-#pragma unroll
-            for (int i = 0; i < 5; i++) bq[(j + 1) & 1][i] = wq[(i * 5 + j + 1) * 64];
-        }
-        int ab[2];
+    for (int j = 0; j < 5; j++)
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             const int x = 16 * s + l15 + j;
-            ab[s] = (8 * rh) * C12_TILE_RS + 32 * x + ((kq ^ swz32(x)) << 3);
+            ab[j][s] = (8 * rh) * C12_TILE_RS + 32 * x + ((kq ^ swz32(x)) << 3);
         }
+    constexpr int D = BF_C2_D, NT = 5 * 24;
+    uint4 ar[D];
+    auto a_read = [&](int t) { return *reinterpret_cast<const uint4*>(&tile[ab[t / 24][t % 2] + ((t % 24) / 2) * C12_TILE_RS]); };
+#pragma unroll
+    for (int t = 0; t < D - 1; t++) ar[t] = a_read(t);
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
 #pragma unroll
         for (int y = 0; y < 12; y++) {
 #pragma unroll
             for (int s = 0; s < 2; s++) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&tile[ab[s] + y * C12_TILE_RS]));
+                const int t = 24 * j + 2 * y + s;
+                if (t + D - 1 < NT) ar[(t + D - 1) % D] = a_read(t + D - 1);
+                if (t % 24 == 0 && j + 1 < 5) {
+#pragma unroll
+                    for (int i = 0; i < 5; i++) bq[(j + 1) & 1][i] = wq[(i * 5 + j + 1) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 a = __builtin_bit_cast(bf16x8, ar[t % D]);
 #pragma unroll
                 for (int i = 0; i < 5; i++) {
                     const int r = y - i;
                     if (r >= 0 && r < 8)
                         acc[r][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, bq[j & 1][i]), acc[r][s], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
 
+    BF_STAMP(3);                                           // wave 0's k-loop
     // ---- 2x2 max-pool in the lane (the bias is in the sums already; max commutes with the relu), bf16, out
     uint16_t* o = out + (size_t)patch * 256 * 32 + 16 * n + l15;
 #pragma unroll
@@ -202,6 +245,10 @@ __global__ __launch_bounds__(256, BF_C12_MINW) void conv12_bf16_kernel(
                 const int py = 8 * half + 4 * rh + r2, px = 8 * s + 2 * kq + p;
                 o[(py * 16 + px) * 32] = bf16_relu(v);
             }
+    BF_STAMP(4);                                           // epilogue issued
+#if BF_DBG_TIME
+    if (threadIdx.x == 0) atomicAdd(&g_bf_prof[7], 1ull);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -226,6 +273,7 @@ __global__ __launch_bounds__(192, BF_C34_MINW) void conv34_bf16_kernel(
     __shared__ __attribute__((aligned(16))) uint16_t lds[14 * C34_T4_RS];
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const int patch = blockIdx.x;
+    BF_STAMP_BEGIN;
 
     {
         const uint4* g = reinterpret_cast<const uint4*>(in + (size_t)patch * 256 * 32);
@@ -235,6 +283,7 @@ __global__ __launch_bounds__(192, BF_C34_MINW) void conv34_bf16_kernel(
         }
     }
     __syncthreads();
+    BF_STAMP(8);                                           // input staged
 
     // ---- conv3: rows 7 .. 13 first -- their place in conv4's tile lies behind conv3's input (7 x 2 688 B > 16 KB), so they
     // are stored at once; rows 0 .. 6 wait packed in registers for the barrier behind which the input may be overwritten
@@ -263,27 +312,47 @@ __global__ __launch_bounds__(192, BF_C34_MINW) void conv34_bf16_kernel(
             for (int r = 0; r < 7; r++)
 #pragma unroll
                 for (int n = 0; n < 2; n++) { acc[r][n][0] = bv[n].x; acc[r][n][1] = bv[n].y; acc[r][n][2] = bv[n].z; acc[r][n][3] = bv[n].w; }
+            // fragment reads BF_C3_D - 1 ahead of their MFMAs, the weights of the next tap column requested when a column
+            // starts (as in conv12_bf16_kernel)
+            constexpr int D = BF_C3_D, NT = 27;
+            int ab[3];
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                uint4 wa[3][2];
-#pragma unroll
-                for (int i = 0; i < 3; i++)
-#pragma unroll
-                    for (int n = 0; n < 2; n++) wa[i][n] = wq[((size_t)n * 9 + i * 3 + j) * 64];
                 const int x = l15 + j;
-                const int ab = 32 * x + ((kq ^ swz32(x)) << 3);
+                ab[j] = 32 * x + ((kq ^ swz32(x)) << 3) + 7 * pass * 512;
+            }
+            auto p_read = [&](int t) { return *reinterpret_cast<const uint4*>(&lds[ab[t / 9] + (t % 9) * 512]); };
+            uint4 ar[D], wa[2][3][2];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int n = 0; n < 2; n++) wa[0][i][n] = wq[((size_t)n * 9 + i * 3) * 64];
+#pragma unroll
+            for (int t = 0; t < D - 1; t++) ar[t] = p_read(t);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
 #pragma unroll
                 for (int y = 0; y < 9; y++) {
-                    const bf16x8 p = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&lds[ab + (7 * pass + y) * 512]));
+                    const int t = 9 * j + y;
+                    if (t + D - 1 < NT) ar[(t + D - 1) % D] = p_read(t + D - 1);
+                    if (y == 0 && j + 1 < 3) {
+#pragma unroll
+                        for (int i = 0; i < 3; i++)
+#pragma unroll
+                            for (int n = 0; n < 2; n++) wa[(j + 1) & 1][i][n] = wq[((size_t)n * 9 + i * 3 + j + 1) * 64];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8 p = __builtin_bit_cast(bf16x8, ar[t % D]);
 #pragma unroll
                     for (int i = 0; i < 3; i++) {
                         const int r = y - i;
                         if (r >= 0 && r < 7) {
 #pragma unroll
                             for (int n = 0; n < 2; n++)
-                                acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[i][n]), p, acc[r][n], 0, 0, 0);
+                                acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[j & 1][i][n]), p, acc[r][n], 0, 0, 0);
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
 #pragma unroll
@@ -296,12 +365,14 @@ __global__ __launch_bounds__(192, BF_C34_MINW) void conv34_bf16_kernel(
                 }
         }
     }
+    BF_STAMP(9);                                           // wave 0's conv3
     __syncthreads();                                       // every wave is done with conv3's input, which rows 0 .. 6 overlay
 #pragma unroll
     for (int oy = 0; oy < 7; oy++)
 #pragma unroll
         for (int n = 0; n < 2; n++) store_row(oy, n, c3[oy][n][0], c3[oy][n][1]);
     __syncthreads();
+    BF_STAMP(10);                                          // barrier, rows 0 .. 6 stored, barrier
 
     // ---- conv4: pooling tile t = (ty, tx): lane row l15 = window q, corner `sub`
     f32x4 acc[9][2];
@@ -317,32 +388,37 @@ __global__ __launch_bounds__(192, BF_C34_MINW) void conv34_bf16_kernel(
     const int a_even = dy * C34_T4_RS + dx * C34_T4_PS + ((kq ^ ((dy & 1) << 1)) << 3);
     const int a_odd = dy * C34_T4_RS + dx * C34_T4_PS + ((kq ^ (((dy + 1) & 1) << 1)) << 3);
     const uint4* wq4 = reinterpret_cast<const uint4*>(w4) + (size_t)(2 * wn) * 27 * 64 + lane;
-#ifndef BF_C4_PF
-#define BF_C4_PF 2
-#endif
-    constexpr int PF = BF_C4_PF;
-    uint4 bq[PF + 1][2];
+    constexpr int PF = BF_C4_PF, D = BF_C4_D, NT = 27 * 9;
+    uint4 bq[PF + 1][2], ar[D];
+    auto a_read = [&](int u) {
+        const int step = u / 9, t = u % 9, i = step / 9, j = (step / 3) % 3, cc = step % 3, ty = t / 3, tx = t % 3;
+        return *reinterpret_cast<const uint4*>(&lds[((i & 1) ? a_odd : a_even) + (4 * ty + i) * C34_T4_RS + (4 * tx + j) * C34_T4_PS + 32 * cc]);
+    };
 #pragma unroll
     for (int u = 0; u < PF; u++)
 #pragma unroll
         for (int n = 0; n < 2; n++) bq[u][n] = wq4[((size_t)n * 27 + u) * 64];
 #pragma unroll
-    for (int step = 0; step < 27; step++) {
-        const int i = step / 9, j = (step / 3) % 3, cc = step % 3;
-        if (step + PF < 27) {
+    for (int u = 0; u < D - 1; u++) ar[u] = a_read(u);
 #pragma unroll
-            for (int n = 0; n < 2; n++) bq[(step + PF) % (PF + 1)][n] = wq4[((size_t)n * 27 + step + PF) * 64];
-        }
+    for (int step = 0; step < 27; step++) {
 #pragma unroll
         for (int t = 0; t < 9; t++) {
-            const int ty = t / 3, tx = t % 3;
-            const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
-                &lds[((i & 1) ? a_odd : a_even) + (4 * ty + i) * C34_T4_RS + (4 * tx + j) * C34_T4_PS + 32 * cc]));
+            const int u = 9 * step + t;
+            if (u + D - 1 < NT) ar[(u + D - 1) % D] = a_read(u + D - 1);
+            if (t == 0 && step + PF < 27) {
+#pragma unroll
+                for (int n = 0; n < 2; n++) bq[(step + PF) % (PF + 1)][n] = wq4[((size_t)n * 27 + step + PF) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 a = __builtin_bit_cast(bf16x8, ar[u % D]);
 #pragma unroll
             for (int n = 0; n < 2; n++)
                 acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, bq[step % (PF + 1)][n]), acc[t][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    BF_STAMP(11);                                          // wave 0's conv4 loop
     uint16_t* o = out + (size_t)patch * 36 * 96;
 #pragma unroll
     for (int n = 0; n < 2; n++) {
@@ -354,6 +430,10 @@ __global__ __launch_bounds__(192, BF_C34_MINW) void conv34_bf16_kernel(
             o[(py * 6 + px) * 96 + co] = bf16_relu(v);       // channels 90 .. 95: zero weights, zero bias
         }
     }
+    BF_STAMP(12);
+#if BF_DBG_TIME
+    if (threadIdx.x == 0) atomicAdd(&g_bf_prof[15], 1ull);
+#endif
 }
 
 }  // namespace
@@ -392,5 +472,19 @@ int k_cnn_bf16_convs(ck_ctx* ctx, const uint8_t* gob, int np, uint16_t* p2, uint
                            (const float*)W.c3b.p, (const uint16_t*)W.c4w_bf.p, (const float*)W.c4b.p, q4);
     }
     CK_HIP(ctx, hipGetLastError());
+#if BF_DBG_TIME
+    {
+        unsigned long long hp[16];
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_bf_prof), sizeof hp);
+        if (hp[7] && hp[15])
+            fprintf(stderr, "[bf16 phases, us per workgroup] conv12 (%llu): stage %.2f  conv1 %.2f  wait %.2f  k-loop %.2f  epilogue %.2f | "
+                            "conv34 (%llu): stage %.2f  conv3 %.2f  relayout %.2f  conv4 %.2f  epilogue %.2f\n",
+                    hp[7], hp[0] * 0.01 / hp[7], hp[1] * 0.01 / hp[7], hp[2] * 0.01 / hp[7], hp[3] * 0.01 / hp[7], hp[4] * 0.01 / hp[7],
+                    hp[15], hp[8] * 0.01 / hp[15], hp[9] * 0.01 / hp[15], hp[10] * 0.01 / hp[15], hp[11] * 0.01 / hp[15], hp[12] * 0.01 / hp[15]);
+        memset(hp, 0, sizeof hp);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bf_prof), hp, sizeof hp);
+    }
+#endif
     return CK_OK;
 }
