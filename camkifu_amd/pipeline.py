@@ -244,6 +244,45 @@ class BoardFold:
             k += 1
         return self.mtx
 
+    def state(self):
+        """what the next batch's first request depends on (plan_request / first_request): running frame count, frames of
+        hold-off left, frames looked at in the window in progress, the count that window opened on"""
+        return (int(self.finder.total_f_processed), int(self.hold), int(self._run), int(self._opened))
+
+    @staticmethod
+    def plan_request(n, H, k, c, run, opened):
+        """The frames of a batch of n a plan-ahead request covers when the fold stands at frame k with running count c and
+        the record of k is missing (run_lazy's docstring): a pure function of the fold's state, so that every rank of a
+        multi-GPU run can work out the FIRST request of a batch by itself (first_request) and start K1-K6 on the planned
+        frames it owns without being told.  H: frames of hold-off after a hit; run / opened: frames looked at in the
+        window in progress and the count it opened on (run == 0: a window opens at k)."""
+        def chain(k_, c_, j):
+            """frames looked at from frame k_ on count c_ if the window in progress hits on its j-th upcoming opportunity
+            and every later window of the batch on its first"""
+            out = []
+            span = (-c_) % 4 + 1 + 4 * j
+            while k_ < n:
+                out.extend(range(k_, min(n, k_ + span)))
+                k_, c_ = k_ + span + H, c_ + span + H
+                span = (-c_) % 4 + 1
+            return out
+        if run == 0:
+            return chain(k, c, 0)
+        # opportunities this window has had: its first after (-opened) % 4 + 1 frames, then one every four
+        first = (-opened) % 4 + 1
+        had = 0 if run < first else 1 + (run - first) // 4
+        # hit in round 3 or 4 of the window; a window already past that: two or four opportunities from here
+        ahead = [3 - had, 4 - had] if had <= 2 else [1, 3]
+        return sorted(set().union(*[chain(k, c, j) for j in ahead]))
+
+    @staticmethod
+    def first_request(state, n, H):
+        """the first request run_lazy(plan_ahead=True) makes for a batch of n frames that starts in `state` ([] when the
+        whole batch lies inside the hold-off)"""
+        c, hold, run, opened = state
+        k = min(hold, n)
+        return [] if k >= n else BoardFold.plan_request(n, H, k, c + k, run, opened)
+
     def run_lazy(self, n, fetch, chunk=8, plan_ahead=True):
         """The same fold over a batch of n frames whose board records do not exist yet: `fetch(indices)` computes the
         records of those frames (-> BOARD_DTYPE array, lines (len(indices), cap, 2)) and is only asked for frames this
@@ -268,7 +307,6 @@ class BoardFold:
         Without it: one request per window up to its probable end (the typical r of the last detections plus `generosity`
         rounds), further requests of `chunk` frames for a later hit."""
         cache = {}
-        H = self.refresh_frames
 
         def load(want):
             want = [f for f in want if 0 <= f < n and f not in cache]
@@ -279,17 +317,6 @@ class BoardFold:
             self.calls += 1
             for j, f in enumerate(want):
                 cache[f] = (int(res["status"][j]), int(res["n_lines"][j]), lines[j])
-
-        def chain(k, c, j):
-            """frames looked at from frame k on running count c if the window in progress hits on its j-th upcoming
-            opportunity and every later window of the batch on its first"""
-            out = []
-            span = (-c) % 4 + 1 + 4 * j
-            while k < n:
-                out.extend(range(k, min(n, k + span)))
-                k, c = k + span + H, c + span + H
-                span = (-c) % 4 + 1
-            return out
         k = 0
         while k < n:
             if self.hold > 0:
@@ -307,15 +334,8 @@ class BoardFold:
                         load(range(k, k + (-c) % 4 + 1 + 4 * rounds))
                     else:
                         load(range(k, k + chunk))
-                elif self._run == 0:
-                    load(chain(k, c, 0))
                 else:
-                    # opportunities this window has had: its first after (-opened) % 4 + 1 frames, then one every four
-                    first = (-self._opened) % 4 + 1
-                    had = 0 if self._run < first else 1 + (self._run - first) // 4
-                    # hit in round 3 or 4 of the window; a window already past that: two or four opportunities from here
-                    ahead = [3 - had, 4 - had] if had <= 2 else [1, 3]
-                    load(sorted(set().union(*[chain(k, c, j) for j in ahead])))
+                    load(self.plan_request(n, self.refresh_frames, k, c, self._run, self._opened))
             status, n_lines, lines = cache[k]
             if self._run == 0:
                 self._opened = self.finder.total_f_processed  # the count this window opens on (it may span two batches)
@@ -582,12 +602,12 @@ class FastFilePipeline:
         self.errors = []
         self.host_seconds = dict(pack=0.0, collectives=0.0, band_model=0.0, fold=0.0, fold_board=0.0, fold_stones=0.0,
                                  gather=0.0, bcast=0.0, band_exchange=0.0, counts_gather=0.0)
-        # hold-off-aware mode (one rank): the GPU core leaves the board path out and the board fold computes, through the
-        # lanes' board contexts (on their own threads), only the records it looks at.  With frames dealt across ranks
-        # the fold would have to ask other ranks for theirs: not built, the full records are computed then.
-        if board_lazy and self.exchange:
-            raise ValueError("board_lazy (hold-off-aware board path) is a one-rank mode: with the frames dealt across ranks the "
-                             "board fold would have to ask other ranks for their records")
+        # hold-off-aware mode: the GPU core leaves the board path out and the board fold computes, through the lanes' board
+        # contexts (on their own threads), only the records it looks at.  One rank: the fold runs on a thread of its own and
+        # asks as it goes (_lazy_fold).  Frames dealt across ranks: every rank works out the batch's first request from the
+        # fold's state, which travels with the transform broadcast, and computes the planned frames it owns; the records are
+        # gathered, rank 0 folds, and every deviation costs one more (broadcast, gather) round (_lazy_board_exchange).
+        self._board_state = (0, 0, 0, 0)                      # BoardFold.state() at the start of the next batch, on every rank
         if board_lazy and not hasattr(self.compute, "lanes"):
             raise ValueError("board_lazy needs a GPU core with lanes (their board contexts compute the requested records)")
         self.board_lazy = bool(board_lazy)
@@ -684,7 +704,7 @@ class FastFilePipeline:
         rates_for_core = rates if not self.exchange else rates[mine]
         seq = self.compute.ticket() if hasattr(self.compute, "ticket") else None
         t = _Ticket(self._runner.submit(self._guarded, my_frames, mtx, rates_for_core, len(mine), seq), mtx, rates, n_total, my_frames)
-        if self.board_lazy and self.rank == 0:
+        if self.board_lazy and self.rank == 0 and not self.exchange:
             # hold-off-aware mode: the board fold needs nothing of the GPU core's results -- it asks the lanes' BOARD contexts
             # (idle in this mode) for the few records it looks at, a chain of small round trips that depends only on the
             # fold before it.  It runs on a thread of its own, batch after batch, as far ahead of the cores as the batches
@@ -730,8 +750,17 @@ class FastFilePipeline:
         """-> (records of the whole batch, counts or None, transform after this batch, failure seen by any rank)"""
         import time
         hs = self.host_seconds
+        lazy_x = None
+        if self.board_lazy and self.exchange:
+            # hold-off-aware board path across ranks: its rounds and the transform broadcast come FIRST -- they need nothing
+            # of this batch's GPU core (the board contexts are idle in this mode), so they run under the stones path
+            lazy_x = self._lazy_board_exchange(t)
         (board, rl, rc, fg, gobans), failure = t.core.result()
         lazy_fold = t.lazy_fold.result() if t.lazy_fold is not None else None
+        if lazy_x is not None and lazy_x[1]:                   # the board path failed somewhere: every rank leaves here,
+            if failure is not None:                            # before the records gather
+                self.errors.append(failure)
+            return np.zeros(t.n_total, REC), None, self.mtx, True
         if failure is not None:
             self.errors.append(failure)
         n_total = t.n_total
@@ -763,7 +792,9 @@ class FastFilePipeline:
         # other ranks -- before the background model's exchange starts
         t3 = time.perf_counter()
         new, fold_error = None, None
-        if lazy_fold is not None:
+        if lazy_x is not None:
+            new = lazy_x[0]                                    # folded and broadcast already
+        elif lazy_fold is not None:
             new, fold_error = lazy_fold
             if fold_error is not None:
                 raise fold_error
@@ -778,18 +809,19 @@ class FastFilePipeline:
         t4 = time.perf_counter()
         hs["fold_board"] += t4 - t3
         if self.exchange:
-            wire = np.zeros(10)
-            if self.rank == 0 and fold_error is not None:
-                wire[0] = -1.0
-            elif self.rank == 0 and new is not None:
-                wire[0], wire[1:] = 1.0, np.asarray(new, np.float64).reshape(9)
-            wire = self.group.broadcast_array(wire, 0)
-            if wire[0] < 0:                                    # every rank leaves the batch here, before the band exchange
-                self.errors.append(fold_error if fold_error is not None else RuntimeError("the board fold failed on rank 0"))
-                return full, None, self.mtx, True
-            new = wire[1:].reshape(3, 3).copy() if wire[0] else None
-            t5 = time.perf_counter()
-            hs["bcast"] += t5 - t4
+            if lazy_x is None:
+                wire = np.zeros(10)
+                if self.rank == 0 and fold_error is not None:
+                    wire[0] = -1.0
+                elif self.rank == 0 and new is not None:
+                    wire[0], wire[1:] = 1.0, np.asarray(new, np.float64).reshape(9)
+                wire = self.group.broadcast_array(wire, 0)
+                if wire[0] < 0:                                # every rank leaves the batch here, before the band exchange
+                    self.errors.append(fold_error if fold_error is not None else RuntimeError("the board fold failed on rank 0"))
+                    return full, None, self.mtx, True
+                new = wire[1:].reshape(3, 3).copy() if wire[0] else None
+                t5 = time.perf_counter()
+                hs["bcast"] += t5 - t4
             if t.have_mtx:
                 # A rank whose band model fails (a library error, out of memory for the band tensor ...) must not leave
                 # the others waiting: it still joins the counts gather, with a header row that says so, and every rank
@@ -815,6 +847,125 @@ class FastFilePipeline:
                     return full, None, self.mtx, True
                 counts = np.concatenate([allc[r, 1:, :b - a] for r, (a, b) in enumerate(band_rows(self.world))], 1)
         return full, counts, new, False
+
+    # ---- hold-off-aware board path with the frames dealt across ranks ------------------------------------------------
+    WIRE = 16                                                 # doubles in front of a request's frame list: kind, 9 transform / count, 4 state
+
+    def _detect_frames(self, frames, idx):
+        """K1-K6 of frames[idx] on the lanes' board contexts, each driven from its own lane thread (a context is
+        single-threaded) -> (BOARD_DTYPE array, lines (len(idx), LMAX, 2)) in idx order"""
+        import time
+        lanes, pools = self.compute.lanes, self.compute.pools
+
+        def timed_detect(ctx, part):
+            t0 = time.perf_counter()
+            out = ctx.board_detect(part, -1, LMAX, True)
+            return out, time.perf_counter() - t0
+        t0 = time.perf_counter()
+        idx = list(idx)
+        k = len(lanes) if len(idx) >= 8 * len(lanes) else 1
+        cuts = [round(i * len(idx) / k) for i in range(k + 1)]
+        futs = [pools[i][0].submit(timed_detect, lanes[i][0], _take(frames, idx[cuts[i]:cuts[i + 1]])) for i in range(k)]
+        got = [f.result() for f in futs]
+        hs = self.host_seconds                               # diagnostics: the requests' wall time and the library calls inside
+        hs["lazy_fetch"] = hs.get("lazy_fetch", 0.0) + time.perf_counter() - t0
+        hs["lazy_detect"] = hs.get("lazy_detect", 0.0) + max(g[1] for g in got)
+        got = [g[0] for g in got]
+        return np.concatenate([g[0] for g in got]), np.concatenate([g[1] for g in got])
+
+    def _board_round(self, t, idx):
+        """One round of the hold-off-aware board path across ranks: frame f of the batch lives on rank f mod world (at
+        index f // world of its shard); this rank computes K1-K6 of the requested frames it owns, ONE all-gather brings the
+        records together -> on rank 0 (rows in idx order, their lines), None elsewhere.  A rank whose board path raises
+        still joins the gather, with a header row that says so: rank 0 then raises, i.e. ends the fold and tells everyone."""
+        W, r = self.world, self.rank
+        per = max(sum(1 for f in idx if f % W == q) for q in range(W))
+        mine = [f // W for f in idx if f % W == r]
+        rows = np.zeros(per + 1, REC)
+        try:
+            if mine:
+                blank = np.zeros((len(mine), 10, 10))
+                rows[1:1 + len(mine)] = pack_records(self._detect_frames(t.frames, mine), blank.astype(np.uint8), blank)
+        except Exception as why:                               # the peers are about to wait in the gather: join it
+            rows[0]["flags"] = FLAG_FAILED
+            self.errors.append(why)
+        got = self.group.all_gather_rows(rows, per + 1)
+        bad = [int(q) for q in np.nonzero(got[:, 0]["flags"] & FLAG_FAILED)[0]]
+        if r != 0:
+            return None
+        if bad:
+            raise RuntimeError("the board path (K1-K6) failed on rank(s) %s: %s" % (bad, self.errors[-1:] if 0 in bad else "see their logs"))
+        out, at = np.zeros(len(idx), REC), [1] * W
+        for j, f in enumerate(idx):
+            out[j] = got[f % W, at[f % W]]
+            at[f % W] += 1
+        return out, out["lines"]
+
+    def _lazy_board_exchange(self, t):
+        """The board fold of one batch in hold-off-aware mode with an exchange stage (reference: no K1-K6 during the hold-off
+        after a hit, board/bf_auto.py:43-49).  Every rank knows the fold's state at the start of the batch (it came with
+        the previous batch's transform) and therefore the batch's FIRST request -- the frames the fold looks at if every
+        window hits on its first opportunity (BoardFold.first_request): each rank computes the ones it owns, one all-gather.
+        Rank 0 folds; whenever the fold needs a frame outside what it has, it broadcasts the next request (a hypothesis for
+        the rest of the batch again) and another round follows.  The closing broadcast carries the transform and the state
+        the next batch starts from.  Every rank issues the same collectives in the same order: round 0 (unless the whole
+        batch lies in the hold-off), then (broadcast, gather) until a broadcast is not a request.
+        -> (transform after this batch or None, failed)"""
+        import time
+        t0 = time.perf_counter()
+        n, H, WIRE = t.n_total, self.board.refresh_frames, self.WIRE
+        first = BoardFold.first_request(self._board_state, n, H)
+        wire = np.zeros(WIRE + n)
+        if self.rank == 0:
+            rounds, err, new = [0], None, None
+
+            def fetch(idx):
+                idx = [int(f) for f in idx]
+                if rounds[0] == 0:
+                    if idx != first:                           # (the same pure function on the same state: cannot happen)
+                        raise RuntimeError("the fold's first request differs from the plan every rank made from its state")
+                else:
+                    req = np.zeros(WIRE + n)
+                    req[0], req[1], req[WIRE:WIRE + len(idx)] = 2.0, len(idx), idx
+                    self.group.broadcast_array(req, 0)
+                rounds[0] += 1
+                return self._board_round(t, idx)
+            try:
+                if self.board.state() != self._board_state:
+                    raise RuntimeError("the board fold's state %s is not the one this batch was planned from %s" % (self.board.state(), self._board_state))
+                self.board.run_lazy(n, fetch, plan_ahead=True)
+                new = self.board.mtx
+            except Exception as why:
+                err = why
+            if first and rounds[0] == 0:                       # the fold ended before its first request: the other ranks are
+                try:                                           # in round 0's gather already
+                    self._board_round(t, first)
+                except Exception:
+                    pass
+            if err is not None:
+                self.errors.append(err)
+                wire[0] = -1.0
+            else:
+                wire[0] = 1.0 if new is not None else 0.0
+                if new is not None:
+                    wire[1:10] = np.asarray(new, np.float64).reshape(9)
+            wire[10:14] = self.board.state()                   # also after a failure: the next batch is planned from where the fold stands
+            wire = self.group.broadcast_array(wire, 0)
+        else:
+            if first:
+                self._board_round(t, first)
+            while True:
+                wire = self.group.broadcast_array(np.zeros(WIRE + n), 0)
+                if wire[0] != 2.0:
+                    break
+                self._board_round(t, [int(f) for f in wire[WIRE:WIRE + int(wire[1])]])
+        self.host_seconds["fold_board"] += time.perf_counter() - t0
+        self._board_state = tuple(int(v) for v in wire[10:14])
+        if wire[0] < 0:
+            if self.rank != 0:
+                self.errors.append(RuntimeError("the board fold failed (rank 0, or the board path of a rank it asked)"))
+            return None, True
+        return (wire[1:10].reshape(3, 3).copy() if wire[0] == 1.0 else None), False
 
     def finish(self, ticket):
         """wait for the batch's exchange, publish the transform, stones fold (rank 0) -> the fold's per-frame request
@@ -861,27 +1012,8 @@ class FastFilePipeline:
         driven from its own lane thread (a context is single-threaded)"""
         if frames is None:
             return self.board.run(full)
-        lanes, pools = self.compute.lanes, self.compute.pools
-
-        def timed_detect(ctx, part):
-            import time
-            t0 = time.perf_counter()
-            out = ctx.board_detect(part, -1, LMAX, True)
-            return out, time.perf_counter() - t0
-
         def fetch(idx):
-            import time
-            t0 = time.perf_counter()
-            idx = list(idx)
-            k = len(lanes) if len(idx) >= 8 * len(lanes) else 1
-            cuts = [round(i * len(idx) / k) for i in range(k + 1)]
-            futs = [pools[i][0].submit(timed_detect, lanes[i][0], _take(frames, idx[cuts[i]:cuts[i + 1]])) for i in range(k)]
-            got = [f.result() for f in futs]
-            hs = self.host_seconds                           # diagnostics: the requests' wall time and the library calls inside
-            hs["lazy_fetch"] = hs.get("lazy_fetch", 0.0) + time.perf_counter() - t0
-            hs["lazy_detect"] = hs.get("lazy_detect", 0.0) + max(g[1] for g in got)
-            got = [g[0] for g in got]
-            return np.concatenate([g[0] for g in got]), np.concatenate([g[1] for g in got])
+            return self._detect_frames(frames, idx)
         return self.board.run_lazy(len(full), fetch, plan_ahead=os.environ.get("CK_LAZY_PLAN") != "0")      # (developer A/B knob)
 
     def fold(self, full, counts, have_mtx=True, frames=None):

