@@ -22,7 +22,7 @@ CK_BOARD_LINES, CK_BOARD_NO_CONTOUR, CK_BOARD_TOO_SMALL = 0, 1, 2
 ZONE_LINES = 32        # CK_ZONE_LINES
 
 EXPORTS = [
-    "ck_ctx_create", "ck_ctx_create_prio", "ck_ctx_destroy", "ck_last_error", "ck_backend", "ck_version", "ck_stream",
+    "ck_ctx_create", "ck_ctx_create_prio", "ck_ctx_destroy", "ck_ctx_destroy2", "ck_stream_wait", "ck_last_error", "ck_backend", "ck_version", "ck_stream",
     "ck_timing_enable", "ck_timing_reset", "ck_timing_get",
     "ck_median15", "ck_median", "ck_canny", "ck_goban_canny", "ck_board_edges", "ck_board_lines", "ck_board_detect",
     "ck_i420_to_bgr", "ck_get_perspective_transform", "ck_warp_perspective",
@@ -86,6 +86,8 @@ def lib():
         L.ck_stream.argtypes = [C.c_void_p]
         L.ck_ctx_destroy.argtypes = [C.c_void_p]
         L.ck_ctx_destroy.restype = None
+        L.ck_ctx_destroy2.argtypes = [C.c_void_p]
+        L.ck_stream_wait.argtypes = [C.c_void_p, C.c_void_p]
         for fn in (L.ck_boardfold_destroy, L.ck_policy_destroy):
             fn.argtypes = [C.c_void_p]
             fn.restype = None
@@ -104,15 +106,12 @@ def _is_torch(a):
 
 
 def _in(a, dtype=np.uint8):
-    """-> (pointer, space, keepalive) for a numpy array or a torch tensor."""
+    """-> (pointer, space, keepalive) for a numpy array or a torch tensor.  A DEVICE tensor must go through Context._in /
+    Context._out instead (they order the context's stream behind torch's): this function refuses it."""
     if _is_torch(a):
         assert a.is_contiguous()
         if a.is_cuda:
-            # the library works on its own HIP stream: whatever torch still has queued that produces
-            # this tensor must have finished before the pointer is handed over
-            import torch
-            torch.cuda.current_stream(a.device).synchronize()
-            return C.c_void_p(a.data_ptr()), CK_DEVICE, a
+            raise CkError("a device tensor is handed to the library through Context._in / Context._out (stream-ordered hand-over)")
         a = a.numpy()
     a = np.ascontiguousarray(a, dtype)
     return a.ctypes.data_as(C.c_void_p), CK_HOST, a
@@ -130,8 +129,12 @@ class Context:
         self.device = device
 
     def close(self):
+        """free the context.  A context another thread is still inside (for more than 5 s) is NOT freed and keeps its
+        handle: CkError says so, and a later close() -- or the finaliser -- tries again (the handle used to be
+        dropped regardless, the stream and all scratch HBM leaked with no way to retry)."""
         if self._h:
-            lib().ck_ctx_destroy(self._h)
+            if lib().ck_ctx_destroy2(self._h) != 0:
+                raise CkError("the context is still inside a call on another thread: not freed, close() it again later")
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -167,24 +170,43 @@ class Context:
             assert shp[3] == cn, shp
         return n, h, w
 
+    # Hand-over of DEVICE memory (torch tensors) -- the ONE place where it happens.  The library launches on the context's
+    # own HIP stream; torch queues its kernels on the calling thread's current stream and reuses a freed block at once for
+    # the next allocation on that stream, from any thread.  So before a pointer crosses the C-ABI the context's stream is
+    # ordered behind torch's current stream (ck_stream_wait: an event recorded there, waited for here -- no host wait):
+    # an input's producer has run, and so has the last kernel torch queued on a recycled output block (round 4: a memory
+    # fault in a gather whose index tensor had been recycled into an output buffer).  Results need nothing in the other
+    # direction: every entry point returns with its work complete.
+    def _order_behind_torch(self, device):
+        import torch
+        self._chk(lib().ck_stream_wait(self._h, C.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+
+    def _in(self, a, dtype=np.uint8):
+        """-> (pointer, space, keepalive) for a numpy array or a torch tensor"""
+        if _is_torch(a) and a.is_cuda:
+            assert a.is_contiguous()
+            self._order_behind_torch(a.device)
+            return C.c_void_p(a.data_ptr()), CK_DEVICE, a
+        return _in(a, dtype)
+
     def _out(self, like, shape, dtype):
         """allocate an output in the same memory space as `like`"""
         if _is_torch(like) and like.is_cuda:
-            import torch
-            t = torch.empty(shape, dtype=getattr(torch, np.dtype(dtype).name), device=like.device)
-            # The block may have been freed a moment ago by ANOTHER thread whose last kernel on it is still queued on torch's
-            # stream (torch reuses a block within a stream at once); the library writes on its own stream, which that
-            # kernel is not ordered with.  Whatever torch has queued runs first (round 4: a memory fault in a gather whose
-            # index tensor was recycled this way).
-            torch.cuda.current_stream(like.device).synchronize()
-            return t, C.c_void_p(t.data_ptr()), CK_DEVICE
+            return self._out_on(like.device, shape, dtype)
         a = np.empty(shape, dtype)
         return a, a.ctypes.data_as(C.c_void_p), CK_HOST
+
+    def _out_on(self, device, shape, dtype):
+        """a fresh device tensor the library may write: allocated, THEN the context's stream ordered behind torch's"""
+        import torch
+        t = torch.empty(shape, dtype=getattr(torch, np.dtype(dtype).name), device=device)
+        self._order_behind_torch(t.device)
+        return t, C.c_void_p(t.data_ptr()), CK_DEVICE
 
     # ---- K1 ---------------------------------------------------------------------------------
     def median15(self, bgr):
         n, h, w = self._shape(bgr, 3)
-        p, sp, keep = _in(bgr)
+        p, sp, keep = self._in(bgr)
         out, op, osp = self._out(bgr, tuple(bgr.shape), np.uint8)
         self._chk(lib().ck_median15(self._h, p, n, h, w, sp, op, osp))
         return out
@@ -192,7 +214,7 @@ class Context:
     def median(self, bgr, ksize):
         """cv2.medianBlur(bgr, ksize) for odd ksize in 3..17 (same matrix-core kernel, other window)"""
         n, h, w = self._shape(bgr, 3)
-        p, sp, keep = _in(bgr)
+        p, sp, keep = self._in(bgr)
         out, op, osp = self._out(bgr, tuple(bgr.shape), np.uint8)
         self._chk(lib().ck_median(self._h, p, n, h, w, int(ksize), sp, op, osp))
         return out
@@ -201,7 +223,7 @@ class Context:
         """SfContours.get_canny (stone/sf_contours.py:332-340): medianBlur 13 then 7, Otsu level of the grey image,
         Canny(median, otsu / 2, otsu) -> edges (and the Otsu levels)"""
         n, h, w = self._shape(bgr, 3)
-        p, sp, keep = _in(bgr)
+        p, sp, keep = self._in(bgr)
         edges, ep, osp = self._out(bgr, tuple(bgr.shape[:-1]), np.uint8)
         otsu = np.zeros(n, np.float64)
         self._chk(lib().ck_goban_canny(self._h, p, n, h, w, sp, ep, osp, otsu.ctypes.data_as(C.c_void_p)))
@@ -210,7 +232,7 @@ class Context:
     # ---- K2 ---------------------------------------------------------------------------------
     def canny(self, img3, low=25, high=75, want_map=False):
         n, h, w = self._shape(img3, 3)
-        p, sp, keep = _in(img3)
+        p, sp, keep = self._in(img3)
         oshape = tuple(img3.shape[:-1])
         edges, ep, osp = self._out(img3, oshape, np.uint8)
         m, mp = None, None
@@ -221,7 +243,7 @@ class Context:
 
     def board_edges(self, bgr):
         n, h, w = self._shape(bgr, 3)
-        p, sp, keep = _in(bgr)
+        p, sp, keep = self._in(bgr)
         edges, ep, osp = self._out(bgr, tuple(bgr.shape[:-1]), np.uint8)
         self._chk(lib().ck_board_edges(self._h, p, n, h, w, sp, ep, osp))
         return edges
@@ -237,7 +259,7 @@ class Context:
 
     def board_lines(self, edges, hough_thresh=-1, cap=1024, want_ghost=False):
         n, h, w = self._shape(edges, 1)
-        p, sp, keep = _in(edges)
+        p, sp, keep = self._in(edges)
         lines = np.zeros((n, cap, 2), np.float32)
         res = (BoardResult * n)()
         ghost, gp, gsp = (None, None, CK_HOST)
@@ -251,7 +273,7 @@ class Context:
     def board_detect(self, bgr, hough_thresh=-1, cap=1024, raw=False):
         """raw=True: (structured array of BOARD_DTYPE, lines (n, cap, 2)) without per-frame python objects"""
         n, h, w = self._shape(bgr, 3)
-        p, sp, keep = _in(bgr)
+        p, sp, keep = self._in(bgr)
         lines = np.zeros((n, cap, 2), np.float32)
         res = np.zeros(n, BOARD_DTYPE)
         self._chk(lib().ck_board_detect(self._h, p, n, h, w, sp, int(hough_thresh),
@@ -271,15 +293,13 @@ class Context:
         single = len(i420.shape) == 1
         n = 1 if single else int(i420.shape[0])
         assert int(i420.shape[-1]) == fsz, (tuple(i420.shape), fsz)
-        p, sp, keep = _in(i420)
+        p, sp, keep = self._in(i420)
         oshape = (h, w, 3) if single else (n, h, w, 3)
         if out is not None:
             assert tuple(out.shape) == oshape
-            op, osp, _ = _in(out)
+            op, osp, _ = self._in(out)
         elif to_device is not None and sp == CK_HOST:
-            import torch
-            out = torch.empty(oshape, dtype=torch.uint8, device=to_device)
-            op, osp, _ = _in(out)                          # (and whatever torch has queued on a recycled block runs first: see _out)
+            out, op, osp = self._out_on(to_device, oshape, np.uint8)
         else:
             out, op, osp = self._out(i420, oshape, np.uint8)
         self._chk(lib().ck_i420_to_bgr(self._h, p, n, int(h), int(w), sp, op, osp))
@@ -289,14 +309,14 @@ class Context:
     def warp_perspective(self, bgr, M, dsize=380, out=None):
         """`out`: an (n, dsize, dsize, 3) uint8 array / tensor in the same memory space as `bgr` to write into"""
         n, h, w = self._shape(bgr, 3)
-        p, sp, keep = _in(bgr)
+        p, sp, keep = self._in(bgr)
         M = np.ascontiguousarray(M, np.float64).reshape(-1, 9)
         oshape = (dsize, dsize, 3) if len(bgr.shape) == 3 else (n, dsize, dsize, 3)
         if out is None:
             out, op, osp = self._out(bgr, oshape, np.uint8)
         else:
             assert tuple(out.shape) == oshape and (out.is_contiguous() if _is_torch(out) else out.flags.c_contiguous)
-            op, osp, _ = _in(out)
+            op, osp, _ = self._in(out)
             assert osp == sp, "out must live where the frames live"
         self._chk(lib().ck_warp_perspective(self._h, p, n, h, w, sp, M.ctypes.data_as(C.c_void_p), len(M),
                                             int(dsize), op, osp))
@@ -309,7 +329,7 @@ class Context:
         return hd.value
 
     def mog2_apply(self, handle, img3, learning_rate):
-        p, sp, keep = _in(img3)
+        p, sp, keep = self._in(img3)
         fg, fp_, osp = self._out(img3, tuple(img3.shape[:-1]), np.uint8)
         self._chk(lib().ck_mog2_apply(self._h, int(handle), p, sp, C.c_double(learning_rate), fp_, osp))
         return fg
@@ -328,7 +348,7 @@ class Context:
             if _is_torch(a):
                 import torch
                 assert a.dtype == torch.float32
-            p, sp, ka = _in(a, np.float32)
+            p, sp, ka = self._in(a, np.float32)
             assert space in (None, sp), "weights must live in one memory space"
             space = sp
             ptrs[i] = p
@@ -341,7 +361,7 @@ class Context:
     def cnn_predict(self, goban, want_y=True):
         shp = tuple(goban.shape)
         n = 1 if len(shp) == 3 else shp[0]
-        p, sp, keep = _in(goban)
+        p, sp, keep = self._in(goban)
         y, yp = None, None
         if want_y:
             y, yp, _ = self._out(goban, (n, 100, 81), np.float32)
@@ -356,7 +376,7 @@ class Context:
         create_net (stone/nn_manager.py:280-292); n <= 128"""
         shp = tuple(goban.shape)
         n = 1 if len(shp) == 3 else shp[0]
-        p, sp, keep = _in(goban)
+        p, sp, keep = self._in(goban)
         p2 = np.empty((n, 100, 16, 16, 32), np.float32)
         p4 = np.empty((n, 100, 6, 6, 90), np.float32)
         self._chk(lib().ck_cnn_maps(self._h, p, n, sp, p2.ctypes.data_as(C.c_void_p), p4.ctypes.data_as(C.c_void_p)))
@@ -364,7 +384,7 @@ class Context:
 
     def stones_detect(self, bgr, M):
         n, h, w = self._shape(bgr, 3)
-        p, sp, keep = _in(bgr)
+        p, sp, keep = self._in(bgr)
         M = np.ascontiguousarray(M, np.float64).reshape(-1, 9)
         labels, lp, osp = self._out(bgr, (n, 19, 19), np.uint8)
         conf, cp, _ = self._out(bgr, (n, 19, 19), np.float64)
@@ -376,7 +396,7 @@ class Context:
         """-> (region_label (n, 10, 10) uint8, region_conf (n, 10, 10) float64)"""
         shp = tuple(goban.shape)
         n = 1 if len(shp) == 3 else shp[0]
-        p, sp, keep = _in(goban)
+        p, sp, keep = self._in(goban)
         rl, rlp, osp = self._out(goban, (n, 10, 10), np.uint8)
         rc, rcp, _ = self._out(goban, (n, 10, 10), np.float64)
         self._chk(lib().ck_cnn_regions(self._h, p, n, sp, rlp, rcp, osp))
@@ -386,7 +406,7 @@ class Context:
         """ordered run of n consecutive frames of one stream -> dict(region_label, region_conf, fgcount[, labels, conf]);
         fgcount is None without a background model"""
         n, h, w = self._shape(bgr, 3)
-        p, sp, keep = _in(bgr)
+        p, sp, keep = self._in(bgr)
         M = np.ascontiguousarray(M, np.float64).reshape(-1, 9)
         rl, rlp, osp = self._out(bgr, (n, 10, 10), np.uint8)
         rc, rcp, _ = self._out(bgr, (n, 10, 10), np.float64)
@@ -406,7 +426,7 @@ class Context:
     def mog2_band_run(self, handle, band, learning_rates, last_band):
         """band (n, band_h, 380, 3) of consecutive goban images -> int32 (n, zone rows, 19) foreground counts"""
         n, bh = int(band.shape[0]), int(band.shape[1])
-        p, sp, keep = _in(band)
+        p, sp, keep = self._in(band)
         lr = np.ascontiguousarray(learning_rates, np.float64).reshape(n)
         out, op, osp = self._out(band, (n, (bh + 19) // 20, 19), np.int32)
         self._chk(lib().ck_mog2_band_run(self._h, int(handle), p, n, sp, lr.ctypes.data_as(C.c_void_p), int(bool(last_band)),
@@ -417,7 +437,7 @@ class Context:
         """(n, 380, 380) or (380, 380) mask -> int32 (n, 19, 19) / (19, 19) foreground pixels per intersection zone"""
         single = len(mask.shape) == 2
         n = 1 if single else int(mask.shape[0])
-        p, sp, keep = _in(mask)
+        p, sp, keep = self._in(mask)
         out, op, osp = self._out(mask, (19, 19) if single else (n, 19, 19), np.int32)
         self._chk(lib().ck_zone_counts(self._h, p, n, sp, op, osp))
         return out
@@ -434,8 +454,8 @@ class Context:
         if tuple(goban.shape[-3:]) != (side, side, 3) or tuple(fg.shape[-2:]) != (side, side) or len(fg.shape) != len(goban.shape) - 1:
             raise ValueError("goban %r / foreground %r: expected (.., s, s, 3) and (.., s, s)" % (tuple(goban.shape), tuple(fg.shape)))
         rects = np.ascontiguousarray(rects, np.int32).reshape(19, 19, 4)
-        p, sp, keep = _in(goban)
-        q, sq, keep2 = _in(fg)
+        p, sp, keep = self._in(goban)
+        q, sq, keep2 = self._in(fg)
         if sp != sq:
             raise ValueError("goban image and foreground mask must live in the same space (both host or both device)")
         stones = np.zeros((n, 19, 19), np.uint8)
@@ -459,7 +479,7 @@ class Context:
         single = len(edges.shape) == 2
         n = 1 if single else int(edges.shape[0])
         h, w = int(edges.shape[-2]), int(edges.shape[-1])
-        p, sp, keep = _in(edges)
+        p, sp, keep = self._in(edges)
         cap = n * (h * w // 4 + 1)
         counts = np.zeros(n, np.int32)
         table = np.zeros((cap, 4), np.int32)
@@ -490,7 +510,7 @@ class Context:
             raise ValueError("goban %r: expected (.., s, s, 3)" % (tuple(goban.shape),))
         mtx = np.ascontiguousarray(mtx, np.int16).reshape(19, 19, 2)
         rects = np.ascontiguousarray(rects, np.int32).reshape(19, 19, 4)
-        p, sp, keep = _in(goban)
+        p, sp, keep = self._in(goban)
         grid = np.zeros((n, 19, 19, 2), np.int16)
         lines = counts = edges = None
         lp = cp = ep = None

@@ -206,17 +206,30 @@ int ck_ctx_create_prio(int device, int priority, ck_ctx** out)
 
 void ck_ctx_destroy(ck_ctx* ctx)
 {
-    if (!ctx) return;
+    if (ck_ctx_destroy2(ctx) == CK_ERR_STATE)
+        fprintf(stderr, "ck_ctx_destroy: context %p is still in use by another thread after 5 s; not freed\n", (void*)ctx);
+}
+
+int ck_stream_wait(ck_ctx* ctx, void* stream)
+{
+    CK_API_BEGIN(ctx)
+    if (!ctx->handover) CK_HIP(ctx, hipEventCreateWithFlags(&ctx->handover, hipEventDisableTiming));
+    CK_HIP(ctx, hipEventRecord(ctx->handover, (hipStream_t)stream));
+    CK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->handover, 0));
+    return CK_OK;
+    CK_API_END(ctx)
+}
+
+int ck_ctx_destroy2(ck_ctx* ctx)
+{
+    if (!ctx) return CK_OK;
     // A thread still inside an entry point owns the stream and the scratch buffers: freeing them under it would be a
     // use-after-free.  Wait for it to leave (a call is milliseconds); a context that stays busy is leaked, and said so.
     unsigned long long nobody = 0;
     const unsigned long long me = ck_thread_token();
     for (int spin = 0; !ctx->owner.compare_exchange_strong(nobody, me, std::memory_order_acq_rel); spin++) {
         if (nobody == me) break;                     // destroyed from inside one of its own calls: nothing to wait for
-        if (spin >= 5000) {
-            fprintf(stderr, "ck_ctx_destroy: context %p is still in use by another thread after 5 s; not freed\n", (void*)ctx);
-            return;
-        }
+        if (spin >= 5000) return CK_ERR_STATE;          // still busy: not freed, the handle stays valid
         nobody = 0;
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
@@ -229,7 +242,7 @@ void ck_ctx_destroy(ck_ctx* ctx)
                        &ctx->out_stage, &ctx->mats,
                        &ctx->cnn.c1w, &ctx->cnn.c1b, &ctx->cnn.c2w, &ctx->cnn.c2b, &ctx->cnn.c3w, &ctx->cnn.c3b,
                        &ctx->cnn.c4w, &ctx->cnn.c4b, &ctx->cnn.d1w, &ctx->cnn.d1b, &ctx->cnn.d2w, &ctx->cnn.d2b,
-                       &ctx->cnn.c2w_bf, &ctx->cnn.c3w_bf, &ctx->cnn.c4w_bf, &ctx->cnn.d1w_bf, &ctx->cnn.c1w_f16, &ctx->cnn.d1w_h2,
+                       &ctx->cnn.c2w_bf, &ctx->cnn.c3w_bf, &ctx->cnn.c4w_bf, &ctx->cnn.d1w_bf, &ctx->cnn.c1w_f16, &ctx->cnn.d1w_bfp, &ctx->cnn.d1w_h2,
                        &ctx->cnn.c1w_h2, &ctx->cnn.c2w_h2, &ctx->cnn.c3w_h2, &ctx->cnn.c4w_h2 };
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (ctx->cnn_flag_host) (void)hipHostFree(ctx->cnn_flag_host);
@@ -242,10 +255,12 @@ void ck_ctx_destroy(ck_ctx* ctx)
     }
     for (auto& pe : ctx->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->handover) (void)hipEventDestroy(ctx->handover);
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
     if (ctx->host_pinned2) (void)hipHostFree(ctx->host_pinned2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return CK_OK;
 }
 
 const char* ck_last_error(const ck_ctx* ctx)

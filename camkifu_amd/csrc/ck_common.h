@@ -52,6 +52,7 @@ struct CnnWeights {
     // bf16 packs for the MFMA path
     DevBuf c2w_bf, c3w_bf, c4w_bf, d1w_bf;
     DevBuf c1w_f16;      // conv1 for the fused bf16 kernels: fp16 fragments (k_cnn_bf16.hip)
+    DevBuf d1w_bfp;      // dense 1 for fc1_bf16_kernel: bf16 fragments over the padded maps
     // hi / lo fp16 planes for the split-precision mode
     DevBuf c1w_h2, c2w_h2, c3w_h2, c4w_h2, d1w_h2;
 };
@@ -68,6 +69,7 @@ struct ck_ctx {
     std::map<std::string, TimingSlot> slots;
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
+    hipEvent_t handover = nullptr;   // ck_stream_wait: recorded on the host framework's stream, waited for on ours
 
     // scratch (grown on demand, never shrunk)
     DevBuf in_stage;     // staged host input
@@ -238,6 +240,8 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space);
 // CK_CNN_BF16 (k_cnn_bf16.hip): conv1 + conv2 and conv3 + conv4 of np patches, pooled maps out as bf16
 int k_cnn_bf16_pack_conv1(ck_ctx* ctx, const float* k1, DevBuf& dst);
 int k_cnn_bf16_convs(ck_ctx* ctx, const uint8_t* gob, int np, uint16_t* p2, uint16_t* q4);
+int k_cnn_bf16_pack_fc1(ck_ctx* ctx, const float* w, DevBuf& dst);
+int k_cnn_bf16_fc1(ck_ctx* ctx, const uint16_t* q4, int np, float* h1);
 int k_mog2_apply(ck_ctx* ctx, Mog2State& st, const uint8_t* d_img, double lr, uint8_t* d_fg);
 int k_mog2_run(ck_ctx* ctx, Mog2State& st, const uint8_t* d_gobans, int n, const double* learning_rates,
                int32_t* d_fgcount, uint8_t* d_last_fg, int skip_row, int skip_col);

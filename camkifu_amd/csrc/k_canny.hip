@@ -13,9 +13,8 @@
 #include "ck_common.h"
 #include "ck_uf.h"
 
-#ifndef NMS_MFMA
-#define NMS_MFMA 0         // 1: gradient phase on the fp16 matrix pipe (canny_nms_mfma_kernel) -- built and measured in round 4:
-#endif                     // 8.1 us per 1080p frame against the packed kernel's 5.5 (profiles/r04_nms_phases.txt)
+// (The gradient phase on the fp16 matrix pipe -- canny_nms_mfma_kernel, built and measured in round 4: 8.1 us per 1080p frame
+// against this file's 5.5 -- is archived in tools/variants/canny_nms_mfma.hip.txt.)
 
 #ifndef NMS_LOCAL_UF
 #define NMS_LOCAL_UF 1     // tile-local union-find of the candidates inside the NMS kernel
@@ -27,7 +26,7 @@ constexpr int TW = 64;
 
 
 // ------------------------------------------------------------------------------------------
-// Packed variant (the one launched; -DNMS_MFMA=1 builds the matrix-pipe variant below instead).  The
+// Packed kernel.  The
 // kernel is VALU-bound, so what counts is instructions per pixel (round 2: ~105 lane-ops per pixel, 60 of them in the
 // gradient phase; this version: see DESIGN.md 4):
 //   * gradient phase in packed 16-bit math (v_pk_*): a thread owns 4 adjacent columns as two u16 pairs and walks PK
@@ -414,6 +413,10 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
             }
     }
     __syncthreads();
+    // (round 5: one list segment and counter per TILE ROW instead of this returning atomic on one word per frame -- ~1 000 per
+    // 1080p frame, the pattern that had cost prep_runs 1 us -- measured level here, 4.42 -> 4.44 us, and the three list kernels
+    // behind it lost their even split over the workgroups, 1.15 -> 1.26 us: the kernel is bound by vector issue and the
+    // atomic sits at its very end, behind nothing that waits for it.  Dropped.)
     if (tid == 0) cbase = ccount ? atomicAdd(cand_count + f, ccount) : 0;
     __syncthreads();
     int32_t* clist = cand + (size_t)f * h * w + cbase;
@@ -421,419 +424,9 @@ __global__ __launch_bounds__(256) void canny_nms_packed_kernel(const uint8_t* __
 }
 
 
-// ------------------------------------------------------------------------------------------
-// Matrix-pipe variant (-DNMS_MFMA=1; NOT the one launched: measured slower, see the end of this comment).  Same results
-// as the packed kernel; the gradient phase -- 54 % of that kernel's vector instructions -- becomes two chained band-matrix
-// products per channel on v_mfma_f32_16x16x32_f16:
-//
-//   stage 1 (horizontal):  T = P . Bh      P  = 16 pixel rows x 32 pixel columns as the A operand: a lane holds 8
-//                                          consecutive bytes of one row, each byte b as the exact half 0x6400 | b =
-//                                          1024 + b (one v_perm per two pixels); Bh = constant band matrices, (-1, 0, 1)
-//                                          for the difference (the 1024s cancel) and (1, 2, 1) for the smooth (the
-//                                          accumulator starts at -4096); 30 of the 32 columns are complete.
-//   stage 2 (vertical):    G^T = T^T . Bv  the f32 result tile of stage 1 has its column on the lane and 4 rows in its
-//                                          registers, so two row halves packed to halves ARE the A operand of a product
-//                                          that sums over rows (k order permuted, baked into Bv) -- no LDS, no lane
-//                                          movement.  Bv carries the factor 4 of the key, so a lane ends up with
-//                                          4 dx and 4 dy of FOUR HORIZONTALLY ADJACENT pixels of one gradient row.
-//   key:                   4 (|dx| + |dy|) + (3 - channel) + 2^23: one v_add_f32 with |.| source modifiers, one add of the
-//                          constant, v_max3 over the channels; the low 16 bits of the float ARE the 16-bit key
-//                          (0x4B000000 | key): straight to LDS with ds_write_b16.
-//
-// Everything is exact: pixel halves <= 1279, differences <= 255 and smooths <= 1020 are integers below 2048 (exact halves),
-// products and sums are integers below 2^24 in f32.  A wave owns a 32 x 32 pixel block = 30 x 30 gradients, three
-// channels: 48 MFMAs + ~220 vector instructions per 900 gradients, against 47 vector lane-operations per gradient in the
-// packed kernel.  Tile: 80 x 28 output pixels per 192-thread workgroup = three blocks at pixel columns 0, 28, 56 of
-// the tile's LDS image (4-byte aligned rows; neighbouring blocks overlap by four columns and compute gradient columns
-// 29, 30 / 1, 2 twice, identically).
-//
-// Measured (MI355X, 1080p, 64-frame launches, cumulative time of builds that leave after each phase, us per frame):
-//                  staging   + gradient   + NMS   + tile union-find   whole kernel
-//   packed           2.04      3.58        4.42        5.05              5.55
-//   matrix pipe      1.79      3.98        5.35        6.80              8.10
-// The gradient phase itself is slower on the matrix pipe (2.19 against 1.54 us): 48 MFMAs of 16 cycles per 900 gradients
-// are 0.8 us of matrix-pipe time per frame, the conversions and keys around them (perm, cvt_pk, |dx| + |dy|, tag, max3:
-// ~190 vector instructions per block) another 0.9 us, and the two ADD UP -- inside one wave they are one dependent
-// chain, and with 122 registers per lane (32 of them the constant band operands) only 4 waves per SIMD are there to fill
-// the other pipe.  The same register footprint halves the occupancy of the latency-bound phases behind it (NMS, LDS
-// union-find, list output: 4.1 us against 2.0).
-constexpr int MTW = 80;                      // output columns per tile
-constexpr int MPLD = 28;                     // pixel tile dwords per row: 22 used (x = ox - 4 .. ox + 83), pitch 28 keeps the
-                                             // 16 rows x 4 lane groups of an A-fragment read on 64 different banks
-constexpr int MGW = 88;                      // key tile pitch (u16): column a  <->  x = ox - 4 + a
-constexpr int MNT = 192;                     // threads per workgroup
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-// the eight constant B operands, in fragment order: [matrix][lane][4 dwords = 8 halves]
-//   0, 1: stage-1 difference, column tiles 0 / 1      2, 3: stage-1 smooth, column tiles 0 / 1
-//   4, 5: stage-2 smooth x 4 (-> 4 dx), row tiles 0 / 1      6, 7: stage-2 difference x 4 (-> 4 dy), row tiles 0 / 1
-struct BandTable { uint32_t v[8][64][4]; };
-constexpr uint32_t half_bits(int c)
-{
-    return c == 0 ? 0u : c == 1 ? 0x3C00u : c == -1 ? 0xBC00u : c == 2 ? 0x4000u : c == 4 ? 0x4400u : c == -4 ? 0xC400u : 0x4800u /* 8 */;
-}
-constexpr BandTable make_bands()
-{
-    BandTable t{};
-    for (int id = 0; id < 8; id++)
-        for (int l = 0; l < 64; l++) {
-            const int n = l & 15, g = l >> 4;
-            for (int j = 0; j < 8; j++) {
-                int c = 0;
-                if (id < 4) {
-                    const int k = 8 * g + j, lc = 16 * (id & 1) + n;          // input column, output column (valid 1 .. 30)
-                    if (lc >= 1 && lc <= 30) {
-                        if (id < 2) c = k == lc + 1 ? 1 : (k == lc - 1 ? -1 : 0);
-                        else c = k == lc ? 2 : ((k == lc - 1 || k == lc + 1) ? 1 : 0);
-                    }
-                } else {
-                    const int R = j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4);   // input row of k-slot (g, j): stage 1's register order
-                    const int lr = 16 * (id & 1) + n;                          // output row (valid 1 .. 30)
-                    if (lr >= 1 && lr <= 30) {
-                        if (id < 6) c = R == lr ? 8 : ((R == lr - 1 || R == lr + 1) ? 4 : 0);
-                        else c = R == lr + 1 ? 4 : (R == lr - 1 ? -4 : 0);
-                    }
-                }
-                t.v[id][l][j >> 1] |= half_bits(c) << (16 * (j & 1));
-            }
-        }
-    return t;
-}
-__device__ const BandTable g_bands = make_bands();
-
-// waves_per_eu(4): a register budget of 128 (below 256) makes the compiler pick the MFMA forms that write VGPRs; with
-// the default budget the 48 result tiles land in AGPRs and come back one v_accvgpr_read at a time (174 of them)
-__attribute__((amdgpu_waves_per_eu(4))) __global__ __launch_bounds__(MNT) void canny_nms_mfma_kernel(const uint8_t* __restrict__ planes, int h, int w, int pitch,
-                                                             int low, int high, uint8_t* __restrict__ map,
-                                                             int32_t* __restrict__ labels, int32_t* __restrict__ cand,
-                                                             int* __restrict__ cand_count, uint8_t* __restrict__ edges_zero,
-    const int* __restrict__ thr /* nullable: per-frame (low, high) pairs */)
-{
-    // XCD-aware tile order, as in the packed kernel
-    int bxi = blockIdx.x, byi = blockIdx.y, f = blockIdx.z;
-    {
-        const unsigned G = gridDim.x * gridDim.y * gridDim.z;
-        if ((G & 7u) == 0) {
-            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-            const unsigned t = (lin & 7u) * (G >> 3) + (lin >> 3);
-            bxi = (int)(t % gridDim.x);
-            byi = (int)((t / gridDim.x) % gridDim.y);
-            f = (int)(t / (gridDim.x * gridDim.y));
-        }
-    }
-    if (thr) { low = thr[2 * f]; high = thr[2 * f + 1]; }
-    // pixel tile: columns ox-4 .. ox+83, rows oy-2 .. oy+29, border replicated; the candidate buffer reuses its space
-    constexpr int PXW = 3 * PLH * MPLD, CBUF = PTH * MTW;
-    static_assert(PLH == 32 && PGR == 30 && PTH == 28, "the matrix-pipe gradient works on 32-row pixel blocks");
-    __shared__ uint32_t smem[PXW > CBUF ? PXW : CBUF];
-    uint32_t (*pxw)[PLH][MPLD] = reinterpret_cast<uint32_t (*)[PLH][MPLD]>(smem);
-    int32_t* cbuf = reinterpret_cast<int32_t*>(smem);
-    __shared__ __attribute__((aligned(8))) uint16_t mag[PGR + 1][MGW];      // keys: magnitude * 4 + (3 - channel); + a spare row
-    __shared__ __attribute__((aligned(16))) int lab[PTH * MTW];             // tile-local union-find parents
-    __shared__ int ccount, cbase;
-    const int ox = bxi * MTW, oy = byi * PTH;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, blk = tid >> 6;
-    const uint8_t* base = planes + (size_t)f * 3 * h * pitch;
-    if (tid == 0) ccount = 0;
-
-    // the constant operands: 8 x 16 bytes per lane from a 8 KB table every workgroup shares (L2); in flight during staging
-    uint4 bandv[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) bandv[i] = *reinterpret_cast<const uint4*>(g_bands.v[i][lane]);
-
-    const uint32_t plane = (uint32_t)h * pitch;
-    const bool interior = ox >= 4 && ox + MTW + 4 <= w && oy >= 2 && oy + PTH + 2 <= h;
-    if (interior) {
-        const uint8_t* org = base + (uint32_t)((oy - 2) * pitch) + (ox - 4);
-        for (int i = tid; i < PLH * 22; i += MNT) {
-            const int r = i / 22, cd = i - r * 22;
-            const uint8_t* q = org + (uint32_t)(r * pitch) + 4 * cd;
-#pragma unroll
-            for (int c = 0; c < 3; c++) pxw[c][r][cd] = *reinterpret_cast<const uint32_t*>(q + c * plane);
-        }
-    } else {
-        for (int i = tid; i < PLH * 22; i += MNT) {
-            const int r = i / 22, cd = i % 22;
-            int y = oy - 2 + r;
-            y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-            const int x = ox - 4 + 4 * cd;                 // pitch is a multiple of 64 and ox of 4: aligned
-            const uint8_t* row = base + (uint32_t)(y * pitch);
-            if (x >= 0 && x + 3 < w) {
-#pragma unroll
-                for (int c = 0; c < 3; c++) pxw[c][r][cd] = *reinterpret_cast<const uint32_t*>(row + c * plane + x);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    uint32_t v = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        int xc = x + k;
-                        xc = xc < 0 ? 0 : (xc > w - 1 ? w - 1 : xc);
-                        v |= (uint32_t)row[c * plane + xc] << (8 * k);
-                    }
-                    pxw[c][r][cd] = v;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (NMS_STOP == 1) { map[((size_t)f * h + (oy < h ? oy : 0)) * w + (tid % w)] = (uint8_t)smem[tid]; return; }
-
-    {
-        // wave `blk` owns the pixel block at LDS columns 28 blk .. 28 blk + 31 (all 32 rows)
-        const int m16 = lane & 15, g = lane >> 4;
-        const f4 zero4 = {0.f, 0.f, 0.f, 0.f}, off4 = {-4096.f, -4096.f, -4096.f, -4096.f};
-        h8 B[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) B[i] = __builtin_bit_cast(h8, bandv[i]);
-        f4 best[2][2];                                   // [column tile][row tile]: keys of 4 adjacent columns of one row
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            h8 A[2];
-#pragma unroll
-            for (int hh = 0; hh < 2; hh++) {
-                const uint32_t* src = &pxw[c][16 * hh + m16][7 * blk + 2 * g];
-                const uint32_t d0 = src[0], d1 = src[1];
-                uint4 a;
-                a.x = __builtin_amdgcn_perm(d0, 0x64646464u, 0x00050004u);        // halves 1024 + p0, 1024 + p1
-                a.y = __builtin_amdgcn_perm(d0, 0x64646464u, 0x00070006u);
-                a.z = __builtin_amdgcn_perm(d1, 0x64646464u, 0x00050004u);
-                a.w = __builtin_amdgcn_perm(d1, 0x64646464u, 0x00070006u);
-                A[hh] = __builtin_bit_cast(h8, a);
-            }
-            h8 Td[2], Ts[2];                             // stage-1 results as stage-2 A operands, per column tile
-#pragma unroll
-            for (int tc = 0; tc < 2; tc++) {
-                const f4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], B[tc], zero4, 0, 0, 0);
-                const f4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1], B[tc], zero4, 0, 0, 0);
-                const f4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[0], B[2 + tc], off4, 0, 0, 0);
-                const f4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[1], B[2 + tc], off4, 0, 0, 0);
-                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                auto pk = [](float a, float b) { return __builtin_bit_cast(uint32_t, (h2)__builtin_amdgcn_cvt_pkrtz(a, b)); };
-                uint4 u;
-                u.x = pk(d0[0], d0[1]); u.y = pk(d0[2], d0[3]); u.z = pk(d1[0], d1[1]); u.w = pk(d1[2], d1[3]);
-                Td[tc] = __builtin_bit_cast(h8, u);
-                u.x = pk(s0[0], s0[1]); u.y = pk(s0[2], s0[3]); u.z = pk(s1[0], s1[1]); u.w = pk(s1[2], s1[3]);
-                Ts[tc] = __builtin_bit_cast(h8, u);
-            }
-            const float tagmagic = 8388608.f + (float)(3 - c);       // 2^23 + tag: the float's low 16 bits are the key
-#pragma unroll
-            for (int tc = 0; tc < 2; tc++)
-#pragma unroll
-                for (int mt = 0; mt < 2; mt++) {
-                    const f4 dx = __builtin_amdgcn_mfma_f32_16x16x32_f16(Td[tc], B[4 + mt], zero4, 0, 0, 0);
-                    const f4 dy = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ts[tc], B[6 + mt], zero4, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float k = (__builtin_fabsf(dx[r]) + __builtin_fabsf(dy[r])) + tagmagic;
-                        best[tc][mt][r] = c == 0 ? k : __builtin_fmaxf(best[tc][mt][r], k);
-                    }
-                }
-            __builtin_amdgcn_sched_barrier(0);           // one channel's 16 result tiles live at a time (128-register budget)
-        }
-        // keys to the LDS tile: gradient row lr - 1 of the tile, column a = 28 blk + lc.  Rows / columns 0 and 31 of the
-        // block are incomplete: those stores go to a spare row behind the tile instead of around a branch.  Outside the
-        // image a key is 0 (only tiles on the rim can hold such positions).
-        uint16_t* magf = &mag[0][0];
-        constexpr int SPARE = PGR * MGW;
-        int rowbase[2], yrow[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++) {
-            const int lr = 16 * mt + m16;
-            yrow[mt] = oy - 2 + lr;
-            rowbase[mt] = (lr >= 1 && lr <= 30) ? (lr - 1) * MGW + 28 * blk + 4 * g : SPARE;
-        }
-        if (interior) {
-#pragma unroll
-            for (int tc = 0; tc < 2; tc++)
-#pragma unroll
-                for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        int at = rowbase[mt] + 16 * tc + r;
-                        if (tc == 0 && r == 0) at = g == 0 ? SPARE : at;               // block column 0
-                        if (tc == 1 && r == 3) at = g == 3 ? SPARE : at;               // block column 31
-                        const float kf = best[tc][mt][r];      // (__builtin_bit_cast of a vector ELEMENT reads element 0: clang 22)
-                        magf[at] = (uint16_t)__float_as_uint(kf);
-                    }
-        } else {
-#pragma unroll
-            for (int tc = 0; tc < 2; tc++)
-#pragma unroll
-                for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int lc = 16 * tc + 4 * g + r;
-                        const int x = ox - 4 + 28 * blk + lc;
-                        const bool in = x >= 0 && x < w && yrow[mt] >= 0 && yrow[mt] < h;
-                        const int at = (lc >= 1 && lc <= 30) ? rowbase[mt] + 16 * tc + r : SPARE;
-                        const float kf = best[tc][mt][r];
-                        magf[at] = in ? (uint16_t)__float_as_uint(kf) : (uint16_t)0;
-                    }
-        }
-    }
-    __syncthreads();
-    if (NMS_STOP == 2) { map[((size_t)f * h + (oy < h ? oy : 0)) * w + (tid % w)] = (uint8_t)mag[tid % PGR][tid % MGW]; return; }   // (keeps the phases alive)
-
-    // NMS: one thread = 4 consecutive pixels of one row (one dword of the map)
-    const int TG22 = 13573;   // (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
-    const uint16_t* magr = &mag[0][0];
-    const uint8_t* pxb = reinterpret_cast<const uint8_t*>(smem);
-    const unsigned lowkey = (unsigned)(low < 0 ? 0 : (low > 8191 ? 8191 : low)) * 4u + 3u;     // m > low  <=>  key > 4 low + 3
-    constexpr int QPR = MTW / 4;                                   // quads per row
-    constexpr int NQT = PTH * QPR;                                 // quads per tile (560)
-    constexpr int NQ = (NQT + MNT - 1) / MNT;
-    int km[NQ];
-#pragma unroll
-    for (int it = 0; it < NQ; it++) {
-        const int q = tid + MNT * it;
-        km[it] = 0;
-        if (q >= NQT) continue;
-        const int r = q / QPR, col0 = (q - r * QPR) * 4;
-        const int y = oy + r;
-        uint32_t mapw = 0x01010101u;
-        int keepmask = 0;
-        if (y < h && ox + col0 < w) {
-            const int i0 = (r + 1) * MGW + col0 + 4;   // output pixel (r, col)  <->  gradient row r + 1, key column col + 4
-            const uint2 m4 = *reinterpret_cast<const uint2*>(magr + i0);
-            const uint32_t m01 = m4.x, m23 = m4.y;
-            const uint32_t top = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, m01), __builtin_bit_cast(u16x2, m23)));
-            const bool any = (low < 0) || (top & 0xFFFFu) > lowkey || (top >> 16) > lowkey;      // keys beyond the image are 0
-            if (__builtin_amdgcn_ballot_w64(any) != 0 && any) {
-                const unsigned kk[4] = {m01 & 0xFFFFu, m01 >> 16, m23 & 0xFFFFu, m23 >> 16};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int m = (int)(kk[k] >> 2);
-                    if (m > low && ox + col0 + k < w) {
-                        const int i = i0 + k;
-                        // dx, dy of the chosen channel from its 8 taps: pixel (r, col) = LDS row r + 2, byte col + 4
-                        const int c = 3 - (int)(kk[k] & 3u);
-                        const uint8_t* t0 = pxb + ((c * PLH + r + 1) * MPLD) * 4 + col0 + k + 3;
-                        const uint8_t* t1 = t0 + MPLD * 4;
-                        const uint8_t* t2 = t1 + MPLD * 4;
-                        const int a00 = t0[0], a01 = t0[1], a02 = t0[2], a10 = t1[0], a12 = t1[2], a20 = t2[0], a21 = t2[1], a22 = t2[2];
-                        const int bdx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
-                        const int bdy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
-                        const int ax = abs(bdx), ay = abs(bdy) << 15;
-                        const int tg22x = ax * TG22;
-                        int o, m2 = m;
-                        if (ay < tg22x) { o = 1; m2 = m + 1; }                             // sector 0: left, right (>=)
-                        else if (ay > tg22x + (ax << 16)) { o = MGW; m2 = m + 1; }         // sector 1: up, down (>=)
-                        else o = ((bdx ^ bdy) < 0) ? MGW - 1 : MGW + 1;                    // diagonals
-                        if (m > (int)(magr[i - o] >> 2) && m2 > (int)(magr[i + o] >> 2)) {
-                            const uint32_t v = m > high ? 2u : 0u;
-                            mapw = (mapw & ~(0xFFu << (8 * k))) | (v << (8 * k));
-                            keepmask |= 1 << k;
-                        }
-                    }
-                }
-            }
-            const int x0 = ox + col0;
-            const size_t idx = ((size_t)f * h + y) * w + x0;
-            // the edge image of the hysteresis pass starts out all zero: cleared here, next to the map store
-            if (x0 + 3 < w && ((idx & 3) == 0)) {
-                *reinterpret_cast<uint32_t*>(map + idx) = mapw;
-                *reinterpret_cast<uint32_t*>(edges_zero + idx) = 0u;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (x0 + k < w) { map[idx + k] = (uint8_t)(mapw >> (8 * k)); edges_zero[idx + k] = 0; }
-            }
-        }
-        km[it] = keepmask;
-    }
-    if (NMS_STOP == 3) return;
-    // tile-local part of the hysteresis union-find in LDS (see the packed kernel): local index = r * 80 + col = 4 q + k
-#pragma unroll
-    for (int it = 0; it < NQ; it++) {
-        const int q = tid + MNT * it;
-        if (q >= NQT) continue;
-        int4 v = make_int4(-1, -1, -1, -1);
-        if (__builtin_amdgcn_ballot_w64(km[it] != 0) != 0) {      // most waves hold no kept pixel at all
-            v.x = (km[it] & 1) ? 4 * q : -1;
-            v.y = (km[it] & 2) ? ((km[it] & 1) ? v.x : 4 * q + 1) : -1;
-            v.z = (km[it] & 4) ? ((km[it] & 2) ? v.y : 4 * q + 2) : -1;
-            v.w = (km[it] & 8) ? ((km[it] & 4) ? v.z : 4 * q + 3) : -1;
-        }
-        *reinterpret_cast<int4*>(lab + 4 * q) = v;
-    }
-    {
-        int mine = 0;
-#pragma unroll
-        for (int it = 0; it < NQ; it++) mine |= km[it];
-        // a tile without a single kept pixel has nothing to link and nothing to list; the pixel tile is dead from here on
-        if (!__syncthreads_or(mine)) return;
-    }
-    auto lfind = [&](int a) {
-        int p = __hip_atomic_load(lab + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (p != a) { a = p; p = __hip_atomic_load(lab + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-        return a;
-    };
-    auto lunion = [&](int a, int b) {
-        for (;;) {
-            a = lfind(a); b = lfind(b);
-            if (a == b) return;
-            if (a < b) { const int t = a; a = b; b = t; }
-            const int old = atomicMin(lab + a, b);
-            if (old == a) return;
-            a = old;
-        }
-    };
-#pragma unroll
-    for (int it = 0; it < NQ; it++) {
-        const int q = tid + MNT * it;
-        if (q >= NQT || !km[it]) continue;
-        const int r = q / QPR, col0 = (q - r * QPR) * 4;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (!(km[it] & (1 << k))) continue;
-            const int i = 4 * q + k, col = col0 + k;
-            if (k == 0 && col > 0 && lab[i - 1] >= 0) lunion(i, i - 1);       // k > 0: linked at initialisation
-            if (r > 0) {
-                if (lab[i - MTW] >= 0) lunion(i, i - MTW);
-                else {
-                    if (col > 0 && lab[i - MTW - 1] >= 0) lunion(i, i - MTW - 1);
-                    if (col < MTW - 1 && lab[i - MTW + 1] >= 0) lunion(i, i - MTW + 1);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (NMS_STOP == 4) return;
-#pragma unroll
-    for (int it = 0; it < NQ; it++) {
-        const int q = tid + MNT * it;
-        const int nk = __builtin_popcount(km[it]);
-        if (q >= NQT || !nk) continue;
-        const int r = q / QPR, col0 = (q - r * QPR) * 4;
-        const int y = oy + r;
-        int slot = atomicAdd(&ccount, nk);
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (km[it] & (1 << k)) {
-                const int p = y * w + ox + col0 + k;
-                const int root = lfind(4 * q + k);
-                const int rr = root / MTW;
-                labels[(size_t)f * h * w + p] = (oy + rr) * w + ox + (root - rr * MTW);
-                cbuf[slot++] = p;
-            }
-    }
-    __syncthreads();
-    if (tid == 0) cbase = ccount ? atomicAdd(cand_count + f, ccount) : 0;
-    __syncthreads();
-    int32_t* clist = cand + (size_t)f * h * w + cbase;
-    for (int i = tid; i < ccount; i += MNT) clist[i] = cbuf[i];
-}
-
 // geometry of the NMS kernel that is launched: its tile-local union-find links everything inside a tile, the global
 // pass (canny_link_kernel) only visits the candidates on a tile's left / right / top edge
-#if NMS_MFMA
-constexpr int NTW = MTW, NTH = PTH;
-#else
 constexpr int NTW = TW, NTH = PTH;
-#endif
 
 // The three hysteresis kernels walk the per-frame candidate list (a few % of the pixels)
 // with a fixed grid and a grid-stride loop; the count is read from device memory.
@@ -841,7 +434,6 @@ constexpr int NTW = TW, NTH = PTH;
 #define CANNY_LIST_BLOCKS 64
 #endif
 constexpr int LIST_BLOCKS = CANNY_LIST_BLOCKS;
-
 // link every candidate with its already-scanned 8-neighbours (W, N, and NW / NE only when
 // N is not itself a candidate -- otherwise the link is implied)
 __global__ __launch_bounds__(256) void canny_link_kernel(const uint8_t* __restrict__ map, int h, int w,
@@ -931,16 +523,10 @@ int k_canny_planar(ck_ctx* ctx, const uint8_t* d_planes, int n, int h, int w, in
     {
         TimeScope ts(ctx, "canny_nms");
         CK_HIP(ctx, hipMemsetAsync(d_count, 0, (size_t)n * 4, ctx->stream));
-#if NMS_MFMA
-        dim3 grid((w + MTW - 1) / MTW, (h + PTH - 1) / PTH, n);
-        hipLaunchKernelGGL(canny_nms_mfma_kernel, grid, dim3(MNT), 0, ctx->stream, d_planes, h, w, pitch, low, high, d_map,
-                           d_labels, d_cand, d_count, d_edges, d_thr);
-#else
         dim3 grid((w + TW - 1) / TW, (h + PTH - 1) / PTH, n);
         hipLaunchKernelGGL(canny_nms_packed_kernel, grid, dim3(256), 0, ctx->stream, d_planes, h, w, pitch, low, high, d_map,
                            d_labels, d_cand, d_count, d_edges, d_thr, d_range, (w + RANGE_TILE - 1) / RANGE_TILE,
                            (h + RANGE_TILE - 1) / RANGE_TILE);
-#endif
         CK_HIP(ctx, hipGetLastError());
     }
     if (d_map_out) CK_HIP(ctx, hipMemcpyAsync(d_map_out, d_map, npx, hipMemcpyDeviceToDevice, ctx->stream));

@@ -116,15 +116,6 @@ __device__ unsigned long long g_h2_log[3 * H2_LOG_CAP];
 #define H2_STAMP(K) do { } while (0)
 #define H34_STAMP(K) do { } while (0)
 #endif
-#ifndef H2_PIPE_PPRIO
-#define H2_PIPE_PPRIO 0   // conv12_pipe_kernel: wave priority of the producer group ...
-#endif
-#ifndef H2_PIPE_KPRIO
-#define H2_PIPE_KPRIO 2   // ... and of the consumer group's k-loop
-#endif
-#ifndef H2_PIPE
-#define H2_PIPE 0         // default of CK_CONV2_PIPE
-#endif
 #ifndef H2_REBALANCE
 #define H2_REBALANCE 1    // conv2: the tiles of a patch's short last block dealt out evenly over its waves
 #endif
@@ -547,21 +538,14 @@ constexpr int h2_tile_halves()
 //             NXT_CINP channels per plane, channels COUT..NXT_CINP-1 zeroed) -- after a barrier, because that tile
 //             overlays this layer's input.
 template <int H, int W, int CIN, int KH, int KW, int COUT, int TB, int YB, int WAVES_M, int RN, bool POOL, int PF, bool SB, bool SWZ = false,
-          bool FUSE1 = false, bool IN_LDS = false, int NXT_W = 0, int NXT_PS = 0, int NXT_RS = 0, int NXT_CINP = 0, int ROLE = 0>
+          bool FUSE1 = false, bool IN_LDS = false, int NXT_W = 0, int NXT_PS = 0, int NXT_RS = 0, int NXT_CINP = 0>
 __device__ __forceinline__ void conv_h2_body(
     _Float16* __restrict__ lds, const int patch, const int blk_y,
     const float* __restrict__ in, const uint16_t* __restrict__ wt, const float* __restrict__ bias,
     float* __restrict__ out, float wscale_inv, int* __restrict__ overflow,
-    const uint8_t* __restrict__ goban1 = nullptr, const uint16_t* __restrict__ wf1 = nullptr, const float* __restrict__ bias1 = nullptr,
-    _Float16* __restrict__ in1_src = nullptr, _Float16* __restrict__ in1_dst = nullptr, const int patch_next = -1, const int blk_y_next = 0)
+    const uint8_t* __restrict__ goban1 = nullptr, const uint16_t* __restrict__ wf1 = nullptr, const float* __restrict__ bias1 = nullptr)
 {
 #pragma clang fp contract(off)
-    // ROLE (conv12_pipe_kernel: one workgroup of two wave groups per CU, the groups a barrier apart per item):
-    //   0  the whole layer by one workgroup, as everywhere else;
-    //   1  PRODUCER group: conv1 of (patch, blk_y) from the staged pixels in1_src into the tile `lds` (patch < 0: none), then the
-    //      pixels of (patch_next, blk_y_next) staged into in1_dst (patch_next < 0: none); no barrier inside;
-    //   2  CONSUMER group: k-loop and epilogue of (patch, blk_y) over the tile `lds`, which a producer call filled.
-    static_assert(ROLE == 0 || FUSE1, "the two-group form exists for the fused conv1 + conv2 only");
     constexpr int OH = H - KH + 1, OW = W - KW + 1, M = OH * OW;
     constexpr int NT = cdiv(COUT, 16), WAVES_N = NT / RN;
     constexpr int CINP = cdiv(CIN, 32) * 32;
@@ -589,7 +573,7 @@ __device__ __forceinline__ void conv_h2_body(
     constexpr int ROWS = ROWS_RAW < H ? ROWS_RAW : H;
     static_assert(ROWS * RS == h2_tile_halves<H, W, CIN, KH, KW, TB, POOL, SWZ>(), "tile size helper out of step");
 
-    const int tid = ROLE == 0 ? (int)threadIdx.x : (int)(threadIdx.x % NTHREADS), lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WAVES_N, wm = wave / WAVES_N;
     const int l15 = lane & 15, kq = lane >> 4;
 #if H2_DBG_TIME
@@ -602,12 +586,12 @@ __device__ __forceinline__ void conv_h2_body(
     // (measured per workgroup: 7.8 us of staging + conv1 next to 8.4 us of k-loop, for 6 % of the flops).  They run
     // at wave priority 3, the k-loop at 0: the issue arbiter serves the short phase first, the matrix pipe stays fed
     // by the other workgroup.
-    if constexpr (H2_PRIO != 0) { if constexpr (ROLE == 1) __builtin_amdgcn_s_setprio(H2_PIPE_PPRIO); else __builtin_amdgcn_s_setprio(3); }
+    if constexpr (H2_PRIO != 0) __builtin_amdgcn_s_setprio(3);
     const int tile_blk = blk_y * TB;
     const int oy_min = POOL ? 4 * (tile_blk / (OW / 4)) : (tile_blk * 16) / OW;
     int row_cnt = H - oy_min;
     if (row_cnt > ROWS) row_cnt = ROWS;
-    if constexpr (FUSE1 && ROLE != 2) {
+    if constexpr (FUSE1) {
         // conv1 (5x5x3 -> 32, relu) of the 40x40 u8 patch computed HERE for the rows this block needs: its output goes
         // straight into the swizzled tile as hi/lo halves and never exists in HBM.  Same arithmetic as conv1_h2_kernel
         // (K = 6 kernel rows x 16 slots in three k-steps, weights as the A operand, two MFMAs per product), so the
@@ -617,12 +601,7 @@ __device__ __forceinline__ void conv_h2_body(
         constexpr int IRS = 128;                              // halves per staged input row: 120 used, 8 zero
         constexpr int IROWS = ROWS + 4;
         static_assert((IROWS + 1) * IRS == H2_IN1_HALVES, "staged pixel rows: helper out of step");
-        _Float16* in1;                                        // (IROWS + 1) * IRS halves: + one zero row under kernel row 5
-        if constexpr (ROLE == 0) {
-            __shared__ __attribute__((aligned(16))) _Float16 in1_own[(IROWS + 1) * IRS];
-            in1 = in1_own;
-        } else
-            in1 = in1_src;
+        __shared__ __attribute__((aligned(16))) _Float16 in1[(IROWS + 1) * IRS];       // + one zero row under kernel row 5
         // the pixels of block by_ of patch p_ as halves into `dst`
         auto stage_pixels = [&](int p_, int by_, _Float16* dst) {
             const int oy_s = 4 * ((by_ * TB) / (OW / 4));
@@ -641,7 +620,7 @@ __device__ __forceinline__ void conv_h2_body(
                                                            (_Float16)(float)((raw >> 16) & 0xFFu), (_Float16)(float)(raw >> 24)};
             }
         };
-        if constexpr (ROLE == 0) stage_pixels(patch, blk_y, in1);
+        stage_pixels(patch, blk_y, in1);
         h8 w1[3][2][2];
 #pragma unroll
         for (int sx = 0; sx < 3; sx++)
@@ -653,7 +632,7 @@ __device__ __forceinline__ void conv_h2_body(
         float4 bv1[2];
 #pragma unroll
         for (int n = 0; n < 2; n++) bv1[n] = *reinterpret_cast<const float4*>(bias1 + n * 16 + 4 * kq);
-        if constexpr (ROLE == 0) __syncthreads();
+        __syncthreads();
         H2_STAMP(0);                                          // pixels staged, conv1 weights loaded
         const int ntile1 = row_cnt * W / 16;                 // 36 or 27 tiles of 16 conv1 pixels
         constexpr int NW = NTHREADS / 64, R1 = cdiv(ROWS * W / 16, NW);
@@ -721,7 +700,7 @@ __device__ __forceinline__ void conv_h2_body(
                     *reinterpret_cast<h4v*>(px + ((c ^ sw ^ 4) << 3)) = lo;
                 }
         };
-        if (ROLE == 0 || patch >= 0) {
+        {
             constexpr int U = H2_C1_U;
             int r = 0;
             if (H2_DBG_SKIP != 2) {
@@ -731,11 +710,7 @@ __device__ __forceinline__ void conv_h2_body(
         }
         if (overflow && !(big <= 65000.f)) *overflow = 1;
         H2_STAMP(4);                                          // wave 0's conv1 tiles
-        if constexpr (ROLE == 1) {
-            if (patch_next >= 0) stage_pixels(patch_next, blk_y_next, in1_dst);
-            return;
-        }
-    } else if constexpr (!IN_LDS && ROLE == 0) {
+    } else if constexpr (!IN_LDS) {
         const float2* g = reinterpret_cast<const float2*>(in + ((size_t)patch * H + oy_min) * W * CIN);
         float big = 0.f;
         // H2_STAGE_UNROLL loads in flight per thread, then their splits (written out: the inline asm of the split keeps
@@ -780,7 +755,7 @@ __device__ __forceinline__ void conv_h2_body(
                 d[CINP] = (_Float16)0.f;
             }
     }
-    if constexpr (!IN_LDS && ROLE == 0) __syncthreads();
+    if constexpr (!IN_LDS) __syncthreads();
     H2_STAMP(1);                                              // conv1 tiles done (all waves)
     H34_STAMP(4);                                             // conv3: input staged
 
@@ -973,7 +948,7 @@ __device__ __forceinline__ void conv_h2_body(
         }
     };
     const bool idle = tile0 >= RT;             // the last block of a patch may hold fewer tiles than waves x R
-    if constexpr (H2_PRIO != 0) { if constexpr (ROLE == 2) __builtin_amdgcn_s_setprio(H2_PIPE_KPRIO); else __builtin_amdgcn_s_setprio(0); }
+    if constexpr (H2_PRIO != 0) __builtin_amdgcn_s_setprio(0);
     if (!idle && H2_DBG_SKIP != 1) {
         if (nv == R) k_loop(std::integral_constant<int, R>{});
         else if constexpr (R * WAVES_M > TB || (H2_REBALANCE && FUSE1)) {
@@ -1080,68 +1055,6 @@ __global__ __launch_bounds__(64 * WAVES_M * (cdiv(COUT, 16) / RN), (64 * WAVES_M
     __shared__ __attribute__((aligned(16))) _Float16 lds[h2_tile_halves<H, W, CIN, KH, KW, TB, POOL, SWZ>()];
     conv_h2_body<H, W, CIN, KH, KW, COUT, TB, YB, WAVES_M, RN, POOL, PF, SB, SWZ, FUSE1>(lds, blockIdx.x, blockIdx.y, in, wt, bias, out,
                                                                                         wscale_inv, overflow, goban1, wf1, bias1);
-}
-
-// The fused conv1 + conv2 layer as ONE workgroup per CU made of two wave groups (round 4, -DH2_PIPE=1 / CK_CONV2_PIPE):
-// the PRODUCER group (waves 8..15) runs conv1 of item k + 1 into one of two LDS tiles and stages the pixels of item k + 2
-// while the CONSUMER group (waves 0..7) runs the k-loop and the epilogue of item k over the other tile; one workgroup
-// barrier per item.  Same device code as conv_mfma16_h2_kernel (conv_h2_body with ROLE 1 / 2), same arithmetic in the same
-// order: bit-identical results.  Why: with two independent workgroups per CU the matrix pipe idles whenever both are in
-// their prologue and is shared when both are in their k-loop (workgroup lifetime 24.5 us for 7.8 us of matrix-pipe time,
-// `[conv2 residency]` in the -DH2_DBG_TIME build); here a prologue always runs beside a k-loop.
-//   items = (patch, block) pairs in the order of the plain kernel's grid (patch fastest); a workgroup takes every
-//   gridDim.x-th.  LDS (dynamic): 2 tiles + 2 staged-pixel buffers = 158 208 B.
-template <int TB, int YB, int WAVES_M, int PF, bool SB>
-__global__ __launch_bounds__(2 * 64 * WAVES_M) void conv12_pipe_kernel(
-    const uint16_t* __restrict__ wt, const float* __restrict__ bias, float* __restrict__ out, float wscale_inv,
-    int* __restrict__ overflow, const uint8_t* __restrict__ goban1, const uint16_t* __restrict__ wf1,
-    const float* __restrict__ bias1, int np)
-{
-    extern __shared__ __attribute__((aligned(16))) _Float16 pipe_lds[];
-    constexpr int T = h2_tile_halves<36, 36, 32, 5, 5, TB, true, true>();
-    constexpr int NTH = 64 * WAVES_M;
-    auto tile = [&](int b) { return pipe_lds + (b & 1) * T; };
-    auto pix = [&](int b) { return pipe_lds + 2 * T + (b & 1) * H2_IN1_HALVES; };
-    const bool producer = threadIdx.x >= NTH;
-    const int n_items = np * YB;
-    const int n_mine = (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // blockIdx.x < n_items (host)
-    auto item = [&](int k) { return (int)blockIdx.x + k * (int)gridDim.x; };
-    // (opaque copies of the weight / bias pointers per call: what a call loads first -- conv1's weights, the first weight
-    // fragments of the k-loop, the biases -- does not depend on the item and would otherwise be hoisted out of the loop and
-    // kept in registers across it; the k-loop sits at the kernel's 128-register budget)
-#define CK_PIPE_BODY(ROLE_, TILE_, P_, BY_, SRC_, DST_, PN_, BYN_)                                                                  \
-    do {                                                                                                                            \
-        const uint16_t* wt_i = wt; const uint16_t* wf1_i = wf1; const float* bias_i = bias; const float* bias1_i = bias1;           \
-        asm volatile("" : "+s"(wt_i), "+s"(wf1_i), "+s"(bias_i), "+s"(bias1_i));                                                    \
-        conv_h2_body<36, 36, 32, 5, 5, 32, TB, YB, WAVES_M, 2, true, PF, SB, true, true, false, 0, 0, 0, 0, ROLE_>(                   \
-            TILE_, P_, BY_, nullptr, wt_i, bias_i, out, wscale_inv, overflow, goban1, wf1_i, bias1_i, SRC_, DST_, PN_, BYN_);       \
-    } while (0)
-    // two loops, one per group, with the same number of barriers: what one group keeps in registers across its items is not
-    // live anywhere in the other's code (one loop with a branch per item cost 836 bytes of scratch)
-    if (producer) {
-        CK_PIPE_BODY(1, tile(0), -1, 0, pix(0), pix(0), item(0) % np, item(0) / np);
-        __syncthreads();
-        {
-            const bool more = n_mine > 1;
-            CK_PIPE_BODY(1, tile(0), item(0) % np, item(0) / np, pix(0), pix(1), more ? item(1) % np : -1, more ? item(1) / np : 0);
-        }
-        __syncthreads();
-        for (int k = 0; k < n_mine; k++) {
-            const bool next = k + 1 < n_mine, next2 = k + 2 < n_mine;
-            if (next || next2)
-                CK_PIPE_BODY(1, tile(k + 1), next ? item(k + 1) % np : -1, next ? item(k + 1) / np : 0, pix(k + 1), pix(k),
-                             next2 ? item(k + 2) % np : -1, next2 ? item(k + 2) / np : 0);
-            __syncthreads();
-        }
-    } else {
-        __syncthreads();
-        __syncthreads();
-        for (int k = 0; k < n_mine; k++) {
-            CK_PIPE_BODY(2, tile(k), item(k) % np, item(k) / np, nullptr, nullptr, -1, 0);
-            __syncthreads();
-        }
-    }
-#undef CK_PIPE_BODY
 }
 
 // conv3 (3x3x32 -> 90, relu) and conv4 (3x3x90 -> 90, relu, 2x2 max-pool) of one patch in one workgroup: conv3's
@@ -1284,37 +1197,6 @@ __global__ __launch_bounds__(64 * (27 / R)) void conv1_h2_kernel(
                 *reinterpret_cast<float4*>(out + m * 32 + n * 16 + 4 * kq) = v;
             }
         }
-    }
-}
-
-// dense 3456(=36 px x 96 padded channels) -> 160 + relu, bf16 operands: one wave = 32 patches x 32 outputs
-__global__ __launch_bounds__(64) void fc1_mfma_bf16_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
-                                                           const float* __restrict__ bias, float* __restrict__ out, int npatch)
-{
-    constexpr int KIN = 3456, NOUT = 160;
-    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
-    const int p0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-    int p = p0 + l31;
-    if (p > npatch - 1) p = npatch - 1;
-    const uint16_t* xa = x + (size_t)p * KIN + 8 * hi;
-    const uint16_t* wb = wt + (size_t)(n0 + l31) * KIN + 8 * hi;
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; e++) acc[e] = 0.f;
-#pragma unroll 8
-    for (int s = 0; s < KIN / 16; s++) {
-        const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + 16 * s));
-        const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wb + 16 * s));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-    }
-    const int co = n0 + l31;
-    const float bv = bias[co];
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const int pp = p0 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-        float v = acc[e] + bv;
-        v = v > 0.f ? v : 0.f;
-        if (pp < npatch) out[(size_t)pp * NOUT + co] = v;
     }
 }
 
@@ -1667,6 +1549,7 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
         return CK_OK;
     };
     CK_TRY(k_cnn_bf16_pack_conv1(ctx, host[0].data(), ctx->cnn.c1w_f16));
+    CK_TRY(k_cnn_bf16_pack_fc1(ctx, host[8].data(), ctx->cnn.d1w_bfp));
     CK_TRY(pack_bf(host[2].data(), 5, 5, 32, 32, 32, 32, ctx->cnn.c2w_bf));
     CK_TRY(pack_bf(host[4].data(), 3, 3, 32, 32, 90, 96, ctx->cnn.c3w_bf));
     CK_TRY(pack_bf(host[6].data(), 3, 3, 90, 96, 90, 96, ctx->cnn.c4w_bf));
@@ -1735,15 +1618,6 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
         CK_TRY(ck_ensure(ctx, ctx->cnn.d1w_h2, v.size() * 2));
         CK_HIP(ctx, hipMemcpy(ctx->cnn.d1w_h2.p, v.data(), v.size() * 2, hipMemcpyHostToDevice));
     }
-    {
-        std::vector<uint16_t> v((size_t)160 * 3456, 0);
-        for (int o = 0; o < 160; o++)
-            for (int px = 0; px < 36; px++)
-                for (int c = 0; c < 90; c++)
-                    v[(size_t)o * 3456 + px * 96 + c] = f2bf(host[8][(size_t)(px * 90 + c) * 160 + o]);
-        CK_TRY(ck_ensure(ctx, ctx->cnn.d1w_bf, v.size() * 2));
-        CK_HIP(ctx, hipMemcpy(ctx->cnn.d1w_bf.p, v.data(), v.size() * 2, hipMemcpyHostToDevice));
-    }
     ctx->cnn.set = true;
     return CK_OK;
 }
@@ -1751,8 +1625,6 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
 // Tuning knob (developer only): extra dynamic LDS requested by the two big classifier kernels.  Enough of it leaves ONE
 // workgroup per CU instead of two, i.e. room (registers, wave slots) for waves of the board path running on other streams.
 static int lds_pad_conv2() { static const int v = getenv("CK_CONV2_LDS_PAD") ? atoi(getenv("CK_CONV2_LDS_PAD")) : 0; return v; }
-// 1: the fused conv1 + conv2 layer as conv12_pipe_kernel (developer A/B knob while the form is being measured)
-static int conv2_pipe() { static const int v = getenv("CK_CONV2_PIPE") ? atoi(getenv("CK_CONV2_PIPE")) : H2_PIPE; return v; }
 static int lds_pad_conv34() { static const int v = getenv("CK_CONV34_LDS_PAD") ? atoi(getenv("CK_CONV34_LDS_PAD")) : 0; return v; }
 
 int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, uint8_t* d_labels, double* d_conf,
@@ -1783,8 +1655,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         }
         TimeScope ts(ctx, "cnn_tail");
         const int np = nframes * 100;
-        hipLaunchKernelGGL(fc1_mfma_bf16_kernel, dim3((np + 31) / 32, 5), dim3(64), 0, ctx->stream,
-                           (const uint16_t*)q4_all, (const uint16_t*)W.d1w_bf.p, (const float*)W.d1b.p, hb, np);
+        CK_TRY(k_cnn_bf16_fc1(ctx, q4_all, np, hb));
         hipLaunchKernelGGL(fc2_softmax_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float*)hb,
                            (const float*)W.d2w.p, (const float*)W.d2b.p, d_y, np);
         hipLaunchKernelGGL(decode_kernel, dim3(nframes), dim3(128), 0, ctx->stream, (const float*)d_y, d_labels, d_conf, nframes, d_nonfinite, d_rlabel, d_rconf);
@@ -1814,18 +1685,6 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             // 8x8 pooling tiles of 4x4 pixels: workgroups of whole tile rows, pooled output 16x16x32
             if (h2) {
 #if H2C2_SWZ
-                if (H2_FUSE1 && conv2_pipe()) {
-                    constexpr int YB2 = 64 / H2C2S_TB + (64 % H2C2S_TB != 0);
-                    constexpr size_t pipe_bytes = (2 * (size_t)h2_tile_halves<36, 36, 32, 5, 5, H2C2S_TB, true, true>() + 2 * H2_IN1_HALVES) * 2;
-                    static_assert(pipe_bytes <= 160 * 1024, "two tiles and two pixel buffers in one CU's LDS");
-                    auto kern = conv12_pipe_kernel<H2C2S_TB, YB2, H2C2S_WM, H2C2S_PF, H2C2S_SB>;
-                    CK_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_bytes));
-                    int cus = 256;
-                    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-                    hipLaunchKernelGGL(kern, dim3(std::min(np * YB2, cus)), dim3(2 * 64 * H2C2S_WM), pipe_bytes, ctx->stream,
-                                       (const uint16_t*)W.c2w_h2.p, (const float*)W.c2b.p, p2, 1.f / H2_WSCALE, d_nonfinite,
-                                       gob, (const uint16_t*)W.c1w_h2.p, (const float*)W.c1b.p, np);
-                } else
                 hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, H2C2S_TB, 64 / H2C2S_TB + (64 % H2C2S_TB != 0), H2C2S_WM, 2, true, H2C2S_PF, H2C2S_SB, true, H2_FUSE1 != 0>), dim3(np, 64 / H2C2S_TB + (64 % H2C2S_TB != 0)), dim3(64 * H2C2S_WM), (size_t)lds_pad_conv2(), ctx->stream,
                                    (const float*)a1, (const uint16_t*)W.c2w_h2.p, (const float*)W.c2b.p, p2, 1.f / H2_WSCALE, d_nonfinite,
                                    gob, (const uint16_t*)W.c1w_h2.p, (const float*)W.c1b.p);

@@ -436,6 +436,89 @@ __global__ __launch_bounds__(192, BF_C34_MINW) void conv34_bf16_kernel(
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// dense 3240 -> 160 + relu (nn_manager.py:293) on the pooled conv4 maps, bf16 operands.  One workgroup = 64 patches x all
+// 160 outputs, so the activations leave HBM once (the round-1 kernel gave a wave 32 patches x 32 outputs and read every
+// activation five times: 0.84 us per frame, all of it that traffic).  D = W x X: wave w owns the output tiles w, w + 4,
+// w + 8 (< 10) and all four patch tiles; the activations of a chunk of 128 k go through LDS (copied as they are: the maps
+// are bf16 already), the weight fragments stream from L2 in fragment order, one k-step ahead.
+//   x  : [patch][36 px][96 ch] bf16 (conv34's output; channels 90 .. 95 are zero)
+//   wt : bf16 [output tile 10][k-step 108][lane][8] with k = px * 96 + ch (pack below)      out : [patch][160] f32
+__global__ __launch_bounds__(256) void fc1_bf16_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int npatch)
+{
+#pragma clang fp contract(off)
+    constexpr int KIN = 3456, NOUT = 160, KC = 128, NCH = KIN / KC, KS = KIN / 32, RSH = KC + 8;   // 272-byte LDS rows
+    constexpr int SPC = KC / 32;                     // k-steps per chunk (even: the 2-slot weight ring stays in phase)
+    constexpr int NLD = 64 * (KC / 8) / 256;         // 16-byte loads per thread and chunk
+    __shared__ __attribute__((aligned(16))) uint16_t lds[64 * RSH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int p0 = blockIdx.x * 64;
+    const int ntw = wave < 2 ? 3 : 2;
+    const uint4* wq = reinterpret_cast<const uint4*>(wt) + lane;
+    f32x4 acc[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 raw[NLD];
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int i = tid + 256 * q, row = i / (KC / 8), c8 = i % (KC / 8);
+            int p = p0 + row;
+            p = p > npatch - 1 ? npatch - 1 : p;
+            raw[q] = ch < NCH ? *reinterpret_cast<const uint4*>(x + (size_t)p * KIN + ch * KC + 8 * c8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    uint4 wf[2][3];
+    auto wload = [&](int slot, int s) {
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+            if (t < ntw) wf[slot][t] = wq[((size_t)(wave + 4 * t) * KS + s) * 64];
+    };
+    fetch(0);
+    wload(0, 0);
+    for (int ch = 0; ch < NCH; ch++) {
+        __syncthreads();                              // previous chunk fully consumed
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int i = tid + 256 * q, row = i / (KC / 8), c8 = i % (KC / 8);
+            *reinterpret_cast<uint4*>(&lds[row * RSH + 8 * c8]) = raw[q];
+        }
+        __syncthreads();
+        fetch(ch + 1);
+#pragma unroll
+        for (int ks = 0; ks < SPC; ks++) {
+            const int s = ch * SPC + ks;
+            if (s + 1 < KS) wload((ks + 1) & 1, s + 1);
+            bf16x8 xb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) xb[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&lds[(16 * j + l15) * RSH + 32 * ks + 8 * kq]));
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+                if (t < ntw) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks & 1][t]), xb[j], acc[t][j], 0, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+        if (t < ntw) {
+            const int o0 = (wave + 4 * t) * 16 + 4 * kq;
+            const float4 bv = *reinterpret_cast<const float4*>(bias + o0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int p = p0 + 16 * j + l15;
+                float4 v = make_float4(acc[t][j][0] + bv.x, acc[t][j][1] + bv.y, acc[t][j][2] + bv.z, acc[t][j][3] + bv.w);
+                v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                if (p < npatch) *reinterpret_cast<float4*>(out + (size_t)p * NOUT + o0) = v;
+            }
+        }
+}
+
 }  // namespace
 
 // conv1's weights for conv12_bf16_kernel: fp16 A fragments [channel tile][k-step][lane = kslot * 16 + channel][8] (layout at
@@ -454,6 +537,33 @@ int k_cnn_bf16_pack_conv1(ck_ctx* ctx, const float* k1, DevBuf& dst)
                 }
     CK_TRY(ck_ensure(ctx, dst, v.size() * 2));
     CK_HIP(ctx, hipMemcpy(dst.p, v.data(), v.size() * 2, hipMemcpyHostToDevice));
+    return CK_OK;
+}
+
+// dense-1 weights for fc1_bf16_kernel: bf16 A fragments [output tile][k-step][lane = kslot * 16 + output][8], k = px * 96 + ch over the
+// padded maps; `w` is the Keras matrix [3240 = px * 90 + ch][160]
+int k_cnn_bf16_pack_fc1(ck_ctx* ctx, const float* w, DevBuf& dst)
+{
+    std::vector<uint16_t> v((size_t)10 * 108 * 64 * 8, 0);
+    for (int t = 0; t < 10; t++)
+        for (int st = 0; st < 108; st++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int e = 0; e < 8; e++) {
+                    const int k = 32 * st + 8 * (lane / 16) + e, px = k / 96, c = k % 96, o = 16 * t + lane % 16;
+                    if (c >= 90) continue;
+                    const __bf16 b = (__bf16)w[(size_t)(px * 90 + c) * 160 + o];
+                    memcpy(&v[(((size_t)t * 108 + st) * 64 + lane) * 8 + e], &b, 2);
+                }
+    CK_TRY(ck_ensure(ctx, dst, v.size() * 2));
+    CK_HIP(ctx, hipMemcpy(dst.p, v.data(), v.size() * 2, hipMemcpyHostToDevice));
+    return CK_OK;
+}
+
+int k_cnn_bf16_fc1(ck_ctx* ctx, const uint16_t* q4, int np, float* h1)
+{
+    hipLaunchKernelGGL(fc1_bf16_kernel, dim3((np + 63) / 64), dim3(256), 0, ctx->stream, q4, (const uint16_t*)ctx->cnn.d1w_bfp.p,
+                       (const float*)ctx->cnn.d1b.p, h1, np);
+    CK_HIP(ctx, hipGetLastError());
     return CK_OK;
 }
 

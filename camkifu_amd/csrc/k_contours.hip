@@ -19,9 +19,9 @@
 // vertically), so the dense background costs one union per run, not per pixel.
 // The three biggest contours need float rotating calipers; that scalar, branchy search runs
 // on the host for the few components whose bounding box could still make the top three.
-// Hough voting keeps a slab of theta rows in LDS per workgroup (LDS atomics), then writes
-// the rows out coalesced -- the global accumulator is never zero-filled or atomically hit (and with HOUGH_FUSED,
-// the default, it does not exist at all: the peak test runs on the LDS slab of 16-bit counters).
+// Hough voting keeps a slab of theta rows in LDS per workgroup (LDS atomics);
+// peaks are found on the slab itself (16-bit counters): no accumulator in HBM (the two-kernel form through a global
+// accumulator is archived in tools/variants/hough_unfused.hip.txt).
 #include <math.h>
 
 #include <algorithm>
@@ -30,9 +30,6 @@
 
 #include "ck_common.h"
 
-#ifndef HOUGH_FUSED
-#define HOUGH_FUSED 1     // votes and peak test in one kernel (0: separate kernels through a global accumulator)
-#endif
 #include "ck_uf.h"
 
 #pragma clang fp contract(off)
@@ -1062,63 +1059,6 @@ __global__ __launch_bounds__(256) void ghost_list_kernel(int h, int w, const int
     }
 }
 
-// ---- H. Hough voting: one workgroup = RB theta rows of one frame, accumulators in LDS ----
-__global__ __launch_bounds__(256) void hough_vote_kernel(const uint32_t* __restrict__ hpts, const FrameTab* __restrict__ tab,
-                                                         int pcap, const float* __restrict__ trig /* cos[180], sin[180] */,
-                                                         int numrho, int rb, int32_t* __restrict__ accum)
-{
-#pragma clang fp contract(off)
-    extern __shared__ __attribute__((aligned(16))) int32_t slab[];
-    const int f = blockIdx.y;
-    const int n0 = blockIdx.x * rb;
-    const int rows = n0 + rb <= NUMANGLE ? rb : NUMANGLE - n0;
-    const int stride = numrho + 2;
-    for (int i = threadIdx.x; i < rows * stride; i += 256) slab[i] = 0;
-    __syncthreads();
-    int npts = tab[f].n_hough_pts;
-    if (npts > pcap) npts = pcap;
-    const uint32_t* P = hpts + (size_t)f * pcap;
-    const int half = (numrho - 1) / 2;
-    for (int i = threadIdx.x; i < npts; i += 256) {
-        const uint32_t pk = P[i];
-        const float xf = (float)(pk & 0xFFFF), yf = (float)(pk >> 16);
-        for (int k = 0; k < rows; k++) {
-            const float a = xf * trig[n0 + k];
-            const float b = yf * trig[NUMANGLE + n0 + k];
-            const float s = a + b;
-            const int r = (int)rintf(s) + half;
-            atomicAdd(&slab[k * stride + r + 1], 1);
-        }
-    }
-    __syncthreads();
-    int32_t* A = accum + ((size_t)f * (NUMANGLE + 2) + n0 + 1) * stride;
-    for (int i = threadIdx.x; i < rows * stride; i += 256) A[i] = slab[i];
-}
-
-// ---- I. peaks -----------------------------------------------------------------------------
-__global__ void hough_peaks_kernel(const int32_t* __restrict__ accum, int numrho, int threshold,
-                                   FrameTab* __restrict__ tab, int32_t* __restrict__ peaks /* f*PEAK_CAP*2 */)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = blockIdx.y;
-    const int f = blockIdx.z;
-    if (r >= numrho) return;
-    const int stride = numrho + 2;
-    const int32_t* A = accum + (size_t)f * (NUMANGLE + 2) * stride;
-    const int base = (n + 1) * stride + r + 1;
-    const int v = A[base];
-    if (v <= threshold) return;
-    const int up = n > 0 ? A[base - stride] : 0;
-    const int dn = n < NUMANGLE - 1 ? A[base + stride] : 0;
-    if (v > A[base - 1] && v >= A[base + 1] && v > up && v >= dn) {
-        const int i = atomicAdd(&tab[f].n_peaks, 1);
-        if (i < PEAK_CAP) {
-            peaks[((size_t)f * PEAK_CAP + i) * 2] = base;
-            peaks[((size_t)f * PEAK_CAP + i) * 2 + 1] = v;
-        } else tab[f].overflow = 1;
-    }
-}
-
 // ---- H + I fused: the votes of rb theta rows (plus one halo row either side) as 16-bit counters packed two per
 // LDS dword, peaks found on the slab itself: the accumulator never exists in HBM.  A cell's count is at most the
 // number of ghost pixels on one discrete line (< w + h), so the halves cannot carry into each other.
@@ -1483,13 +1423,7 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
             trig[k] = (float)(cos((double)ang) * 1.f);
         }
     }
-#if !HOUGH_FUSED
-    CK_TRY(ck_ensure(ctx, ctx->accum, (size_t)n * (NUMANGLE + 2) * stride * 4));
-#endif
     CK_TRY(ck_ensure(ctx, ctx->peaks, (size_t)n * PEAK_CAP * 8 + (size_t)n * pcap * 4));
-#if !HOUGH_FUSED
-    int32_t* d_accum = (int32_t*)ctx->accum.p;
-#endif
     int32_t* d_peaks = (int32_t*)ctx->peaks.p;
     uint32_t* d_hpts = (uint32_t*)(d_peaks + (size_t)n * PEAK_CAP * 2);
     {
@@ -1500,7 +1434,6 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
                            (const int32_t*)d_sel, d_tab, (const int32_t*)blist, pcap, d_hpts, d_ghost_out);
         CK_HIP(ctx, hipGetLastError());
     }
-#if HOUGH_FUSED
     {
         TimeScope ts(ctx, "hough_vote");
         const size_t row_bytes = (size_t)((stride + 1) / 2) * 4;           // 16-bit counters, two per dword
@@ -1523,26 +1456,6 @@ int k_board_lines(ck_ctx* ctx, const uint8_t* d_edges, int n, int h, int w, int 
                            (const uint32_t*)d_hpts, d_tab, pcap, (const float*)d_trig, numrho, rb, hough_thresh, d_peaks);
         CK_HIP(ctx, hipGetLastError());
     }
-#else
-    {
-        TimeScope ts(ctx, "hough_vote");
-        const size_t row_bytes = (size_t)stride * 4;
-        int rb = (int)((144 * 1024) / row_bytes);
-        if (rb > 6) rb = 6;
-        if (rb < 1) return ck_fail(ctx, CK_ERR_ARG, "image too large for the Hough LDS slab");
-        CK_HIP(ctx, hipFuncSetAttribute((const void*)hough_vote_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(rb * row_bytes)));
-        hipLaunchKernelGGL(hough_vote_kernel, dim3((NUMANGLE + rb - 1) / rb, n), dim3(256), rb * row_bytes, ctx->stream,
-                           (const uint32_t*)d_hpts, (const FrameTab*)d_tab, pcap, (const float*)d_trig, numrho, rb, d_accum);
-        CK_HIP(ctx, hipGetLastError());
-    }
-    {
-        TimeScope ts(ctx, "hough_peaks");
-        hipLaunchKernelGGL(hough_peaks_kernel, dim3((numrho + 255) / 256, NUMANGLE, n), dim3(256), 0, ctx->stream,
-                           (const int32_t*)d_accum, numrho, hough_thresh, d_tab, d_peaks);
-        CK_HIP(ctx, hipGetLastError());
-    }
-#endif
     lap("ghost+hough");
     CK_HIP(ctx, hipMemcpyAsync(tab.data(), d_tab, tab_bytes, hipMemcpyDeviceToHost, ctx->stream));
     CK_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -10,178 +10,14 @@
 //   in its tile (a 256-bit wave-uniform set), so a tile costs (#distinct medians-ish)
 //   box filters instead of 255 -- medians of a 15x15 window vary slowly.
 //
-// Two kernels evaluate the box sums.  median15_mfma_kernel (further down, the one launched) does them on the
-// i8 matrix cores: 20 us per 1080p frame.  median15_kernel (first below, kept as the all-VALU reference of
-// the same descent; build with -DMED_MFMA=0) does them with SWAR adds and DPP shifts: 38 us.
-//
-// median15_kernel mapping: one wave = one 48x64 output tile of one channel.  64 lanes = 16 (x) x 4 (y);
-// a lane owns 4 adjacent pixels packed in one dword (SWAR, byte lanes) and 16 output rows,
-// so the vertical pass is in-register and the horizontal pass crosses at most 4 lanes of
-// the same 16-lane DPP row.  Lanes 12..15 of each row only supply halo.
-//
-// HBM traffic: each input byte is read ~(64*78)/(48*64) = 1.6x (L2 absorbs the halo),
-// output written once, planar [n][3][h][pitch] so the next stage reads dwords.
-//
-// The SWAR kernel is VALU-issue bound (every instruction below costs one 4-cycle wave64 slot, v_mad_u64_u32
-// two: tools/micro/valu_rates.hip), so its time is (#box filters per tile) x (376 instructions).
-// Costed against the distinct-prefix counts of real median images (1080p board scenes, ~20.6 box
-// filters per 48x64 tile, lower bound ~12.7 from the distinct medians):
-//   * tile shapes 48x16 .. 48x128 and full-wave rows 240x8 .. 240x32: 48x48 / 48x64 are the minimum
-//     (smaller tiles pay the 14-row / 14-column halo, larger ones hold more distinct medians);
-//   * 8 pixels per lane (112-wide tiles, better lane use, fewer DPP shifts): the tile then holds
-//     ~23-25 prefixes and the registers drop the occupancy -- a wash;
-//   * skipping thresholds outside the tile's input value range, or a sampled-range + linear scan:
-//     no gain on board scenes (the input range of a tile is wide; flat tiles are already cheap);
-//   * a second copy of the threshold body for levels with a single prefix (the per-row prefix test
-//     drops out, -3 of 23 ops per row on ~35 % of the thresholds): 138 VGPRs -> 3 waves/SIMD, or 9
-//     spills when held to 4; measured 40.1 / 38.8 us against 38.3 us for the single body.
+// The box sums run on the i8 matrix cores (median_mfma_kernel below).  The first form of this kernel did them with SWAR byte
+// adds and DPP row shifts (38 us per 1080p frame, VALU-issue bound: ~20.6 box filters per 48x64 tile x 376 instructions); it
+// lives in tools/variants/median15_swar.hip.txt with the tile shapes and shortcuts that were costed against it.
 #include <type_traits>
 
 #include "ck_common.h"
 
-#ifndef MED_MFMA
-#define MED_MFMA 1
-#endif
 namespace {
-
-constexpr int HOUT = 16;              // output rows per lane
-constexpr int HIN = HOUT + 14;        // input rows per lane
-constexpr int TILE_W = 48;            // valid output columns per wave
-constexpr int TILE_H = 4 * HOUT;      // output rows per wave
-
-template <int K>
-__device__ __forceinline__ uint32_t lane_right(uint32_t v)
-{
-    // value held by the lane K places to the right inside the 16-lane DPP row (row_shl:K);
-    // lanes shifted in from beyond the row read 0.  A VALU move, no LDS crossbar traffic.
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + K, 0xf, 0xf, true);
-}
-
-__device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t nbytes)
-{
-    return __builtin_amdgcn_alignbyte(hi, lo, nbytes);
-}
-
-// 15-wide horizontal box sum of packed byte counters: result byte t of lane lx is
-// sum_{k=0..14} V[4*lx + t + k].  Per lane: PS = inclusive byte prefix sums of its word,
-// G = the word total in every byte; the window is (suffix of this word) + (two full words)
-// + (a 3+t pixel prefix spanning the words 3 and 4 lanes to the right): 4 row shifts.
-__device__ __forceinline__ uint32_t hsum15(uint32_t w)
-{
-    const uint32_t a = w + (w << 8);
-    const uint32_t PS = a + (a << 16);
-    const uint32_t G = __builtin_amdgcn_perm(PS, PS, 0x03030303u);
-    const uint32_t SS = G - (PS << 8);                                  // suffix sums
-    const uint32_t PS3 = lane_right<3>(PS), PS4 = lane_right<4>(PS);
-    const uint32_t tail = alignbyte(PS4, PS3, 2) + __builtin_amdgcn_perm(PS3, PS3, 0x03030C0Cu);
-    return SS + lane_right<1>(G) + lane_right<2>(G) + tail;
-}
-
-struct Set256 {
-    unsigned long long w[4];
-    __device__ __forceinline__ void clear() { w[0] = w[1] = w[2] = w[3] = 0; }
-    __device__ __forceinline__ void set(int v)
-    {
-        unsigned long long bit = 1ull << (v & 63);
-        switch (v >> 6) {
-        case 0: w[0] |= bit; break;
-        case 1: w[1] |= bit; break;
-        case 2: w[2] |= bit; break;
-        default: w[3] |= bit; break;
-        }
-    }
-};
-
-__global__ __launch_bounds__(64) void median15_kernel(const uint8_t* __restrict__ in, int h, int w,
-                                                      uint8_t* __restrict__ out, int pitch)
-{
-    const int lane = threadIdx.x;
-    const int lx = lane & 15, ly = lane >> 4;
-    const int ox = blockIdx.x * TILE_W, oy = blockIdx.y * TILE_H;
-    const int f = blockIdx.z / 3, c = blockIdx.z % 3;
-    const uint8_t* src = in + (size_t)f * h * w * 3 + c;
-
-    // ---- load the lane's 4 x HIN pixels (replicate border = clamped coordinates) --------
-    uint32_t nx[HIN];
-    int xo[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int x = ox - 7 + 4 * lx + k;
-        x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
-        xo[k] = x * 3;
-    }
-    const int ybase = oy + HOUT * ly - 7;
-#pragma unroll
-    for (int r = 0; r < HIN; r++) {
-        int y = ybase + r;
-        y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-        const uint8_t* row = src + (size_t)y * w * 3;
-        uint32_t v = (uint32_t)row[xo[0]] | ((uint32_t)row[xo[1]] << 8) |
-                     ((uint32_t)row[xo[2]] << 16) | ((uint32_t)row[xo[3]] << 24);
-        nx[r] = ~v;
-    }
-
-    uint32_t lo[HOUT];
-#pragma unroll
-    for (int j = 0; j < HOUT; j++) lo[j] = 0;
-    const uint32_t vm80 = (lx < 12) ? 0x80808080u : 0u;   // lanes 12..15 have no full window
-
-    Set256 cur, nxt;
-    cur.clear();
-    cur.set(0);
-    for (int b = 7; b >= 0; b--) {
-        nxt.clear();
-        const int half = 1 << b;
-        for (;;) {
-            int q;
-            if (cur.w[0]) { q = __builtin_ctzll(cur.w[0]); cur.w[0] &= cur.w[0] - 1; }
-            else if (cur.w[1]) { q = 64 + __builtin_ctzll(cur.w[1]); cur.w[1] &= cur.w[1] - 1; }
-            else if (cur.w[2]) { q = 128 + __builtin_ctzll(cur.w[2]); cur.w[2] &= cur.w[2] - 1; }
-            else if (cur.w[3]) { q = 192 + __builtin_ctzll(cur.w[3]); cur.w[3] &= cur.w[3] - 1; }
-            else break;
-            {
-                const uint32_t T = (uint32_t)(q + half) * 0x01010101u;   // t + 1 in every byte
-                const uint32_t Q = (uint32_t)q * 0x01010101u;
-                uint32_t B[HIN];
-#pragma unroll
-                for (int r = 0; r < HIN; r++)
-                    B[r] = (__builtin_amdgcn_lerp(nx[r], T, 0u) >> 7) & 0x01010101u;   // x <= t
-                uint32_t V = 0;
-#pragma unroll
-                for (int r = 0; r < 15; r++) V += B[r];
-                uint32_t any_hi = 0, any_lo = 0;
-#pragma unroll
-                for (int j = 0; j < HOUT; j++) {
-                    if (j > 0) V = V + B[j + 14] - B[j - 1];
-                    const uint32_t S = hsum15(V);
-                    const uint32_t nD = S + 0x0F0F0F0Fu;                          // bit7 set <=> S >= 113
-                    const uint32_t nz = __builtin_amdgcn_lerp(lo[j] ^ Q, 0xFFFFFFFFu, 0u);   // bit7 set <=> prefix != q
-                    const uint32_t eq7 = (~nz & vm80);      // ~nz & vm80
-                    const uint32_t upd7 = (~nD & eq7);      // eq & (S < 113): median above t
-                    lo[j] += upd7 >> (7 - b);
-                    any_hi |= upd7;
-                    any_lo |= eq7 & nD;
-                }
-                if (__builtin_amdgcn_ballot_w64(any_hi != 0)) nxt.set(q + half);
-                if (__builtin_amdgcn_ballot_w64(any_lo != 0)) nxt.set(q);
-            }
-        }
-        cur = nxt;
-    }
-
-    // ---- store: planar, one dword per lane-row ------------------------------------------
-    if (lx < 12) {
-        const int x = ox + 4 * lx;
-        if (x < w) {
-            uint8_t* dst = out + ((size_t)(f * 3 + c) * h) * pitch + x;
-#pragma unroll
-            for (int j = 0; j < HOUT; j++) {
-                const int y = oy + HOUT * ly + j;
-                if (y < h) *reinterpret_cast<uint32_t*>(dst + (size_t)y * pitch) = lo[j];
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // Matrix-core variant (the one launched).  Same radix descent, but the 15x15 box sum of the indicator
@@ -655,7 +491,6 @@ int k_median_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int 
 #if !CK_TILE_RANGE
     d_range = nullptr;
 #endif
-#if MED_MFMA
     dim3 grid((w + MT - 1) / MT, (h + MT - 1) / MT, n * 3);
 #define CK_MEDIAN_CASE(KS) case KS: hipLaunchKernelGGL(median_mfma_kernel<KS>, grid, dim3(64), 0, ctx->stream, d_bgr, h, w, d_planes, pitch, d_range); break;
     switch (ksize) {
@@ -674,12 +509,6 @@ int k_median_planar(ck_ctx* ctx, const uint8_t* d_bgr, int n, int h, int w, int 
         memset(c, 0, sizeof c);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_med_dbg), c, sizeof c);
     }
-#endif
-#else
-    if (ksize != 15) return ck_fail(ctx, CK_ERR_ARG, "the SWAR median kernel is 15x15 only");
-    if (d_range) CK_HIP(ctx, hipMemsetD16Async((hipDeviceptr_t)d_range, 0xFF00, ck_range_bytes(n, h, w) / 2, ctx->stream));   // no bounds: 0 .. 255
-    dim3 grid((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H, n * 3);
-    hipLaunchKernelGGL(median15_kernel, grid, dim3(64), 0, ctx->stream, d_bgr, h, w, d_planes, pitch);
 #endif
     CK_HIP(ctx, hipGetLastError());
     return CK_OK;

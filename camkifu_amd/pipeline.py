@@ -172,18 +172,20 @@ def _device_of(ctx):
 
 
 def _take(frames, indices):
-    """the frames with those indices, contiguous (a slice when they are consecutive)"""
+    """the frames with those indices, contiguous (a slice when they are consecutive), COMPLETE when this returns.
+    The gather runs on this thread's current torch stream, but its result goes to a lane thread, which hands it to the
+    library behind ITS current stream (capi.Context._in) -- another stream when this is the exchange thread -- so the
+    gather is waited for here; and its index tensor is kept until then: a freed block is reused by the next allocation on
+    the stream from any thread (round 4: an index tensor recycled into an output buffer under a queued gather)."""
     if len(indices) and indices[-1] - indices[0] + 1 == len(indices):
         return frames[indices[0]:indices[-1] + 1]
     if hasattr(frames, "index_select"):
         import torch
-        out = frames.index_select(0, torch.as_tensor(indices, device=frames.device))
+        index = torch.as_tensor(indices, device=frames.device)
+        out = frames.index_select(0, index)
         if out.is_cuda:
-            # The index tensor dies with this statement, and torch hands a freed block to the next allocation on the same
-            # stream -- from ANY thread.  A lane thread that gets it for an output buffer has the library write it on the
-            # context's own stream, i.e. possibly before the gather above has run: the gather then reads indices that are no
-            # longer indices (a memory fault, seen once in five runs).  Wait for the gather before anything is freed.
             torch.cuda.current_stream(out.device).synchronize()
+        del index                                             # only now: the gather has run
         return out
     return np.ascontiguousarray(np.asarray(frames)[list(indices)])
 
@@ -1003,8 +1005,9 @@ class FastFilePipeline:
     def __enter__(self):
         return self
 
-    def __exit__(self, *exc):
-        self.close()
+    def __exit__(self, exc_type, exc, tb):
+        # leaving on an exception: do not wait for batches in flight (with a dead peer that is the collective timeout)
+        self.close(wait=exc_type is None)
 
     def _fold_board(self, full, frames=None):
         """ordered replay of the board finder on the gathered records of one batch (rank 0); with `frames` (hold-off-aware

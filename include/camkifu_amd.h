@@ -55,6 +55,16 @@ int  ck_ctx_create(int device, ck_ctx** out);
  * waits for the answer) gets its kernels onto the CUs ahead of the long launches of other contexts. */
 int  ck_ctx_create_prio(int device, int priority, ck_ctx** out);
 void ck_ctx_destroy(ck_ctx* ctx);
+/* The same with a status: CK_OK when the context was freed; CK_ERR_STATE when another thread was still inside one of its
+ * calls after 5 s -- the context is then NOT freed (nothing is pulled from under that thread) and the handle stays valid:
+ * call again later.  ck_ctx_destroy is this call with the status dropped (it prints a line to stderr instead). */
+int  ck_ctx_destroy2(ck_ctx* ctx);
+/* Stream-ordered hand-over of device memory from a host framework (PyTorch: the caller passes torch's CURRENT stream, as a
+ * hipStream_t): everything queued on `stream` up to now runs before anything this context launches from now on
+ * (hipEventRecord on `stream`, hipStreamWaitEvent on the context's).  No host wait.  A host that allocates its outputs or
+ * produces its inputs on a stream of its own calls this before it passes their pointers to an entry point below; results
+ * need no call in the other direction: every entry point returns with its work complete. */
+int  ck_stream_wait(ck_ctx* ctx, void* stream);
 const char* ck_last_error(const ck_ctx* ctx);     /* ctx may be NULL: last create error */
 int  ck_backend(const ck_ctx* ctx);               /* CK_BACKEND_HIP                     */
 int  ck_version(void);

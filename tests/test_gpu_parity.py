@@ -917,35 +917,6 @@ def test_cnn_filter_maps_below_the_softmax(ck, ora, synth, mode):
     ck.cnn_set_weights(synth.cnn_weights())
 
 
-def test_conv12_two_group_form_is_bit_identical():
-    """CK_CONV2_PIPE=1 runs the fused conv1 + conv2 layer as one workgroup of a producer and a consumer wave group per CU
-    (conv12_pipe_kernel: built and measured in round 4, not the default -- DESIGN 4).  Same device code, same order of
-    operations: every output of the classifier, filter maps included, must equal the default form's bit for bit.  The knob
-    is read once per process, hence the two child processes."""
-    import hashlib
-    import subprocess
-    import sys
-    code = (
-        "import sys, hashlib, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
-        "from camkifu_amd import capi, synth\n"
-        "ck = capi.Context(0)\n"
-        "ck.cnn_set_weights(synth.cnn_weights())\n"
-        "g = np.random.default_rng(5).integers(0, 256, (3, 380, 380, 3), dtype=np.uint8)\n"
-        "p2, p4 = ck.cnn_maps(g[:2])\n"
-        "out = ck.cnn_regions(g)\n"
-        "h = hashlib.sha256()\n"
-        "for a in (p2, p4, np.asarray(out[0]), np.asarray(out[1])):\n"
-        "    h.update(np.ascontiguousarray(a).tobytes())\n"
-        "print('DIGEST', h.hexdigest())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    digests = []
-    for knob in ("0", "1"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CK_CONV2_PIPE=knob), capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
-    assert digests[0] == digests[1]
-
-
 @pytest.mark.parametrize("mode", ["f16x2", "fp32", "bf16"])
 def test_cnn_against_torch_fp64(ck, ora, synth, mode):
     """K11 pinned without the oracle: the HIP classifier against a float64 torch evaluation of the same network

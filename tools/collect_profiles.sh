@@ -6,7 +6,7 @@
 set -e
 export TMPDIR=/tmp
 O=gpurun_out
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 bench.py --no-cpu-baseline --no-extras > $O/bench_prof.json 2> $O/prof_bench.err
 echo "bench stats done"
@@ -28,10 +28,21 @@ find $O/pmc_fetch $O/pmc_write $O/pmc_valu -name "*.db" -delete 2>/dev/null || t
 # summarise here: at the bench's own scale the raw counter tables are too large to travel back (gpurun merges 64 MiB)
 python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write 128 $O/pmc_traffic.json $O/pmc_valu > /dev/null
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_valu
-# what FETCH_SIZE counts per load width, on a stream of known size (the file the traffic figures are read against)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_calib -- tools/micro/fetch_calib > $O/fetch_calib.log 2>&1 || true
-python3 tools/pmc_kernels.py $O/pmc_calib read_b8x3 "read_wide<unsigned int>" "read_wide<HIP_vector_type<unsigned int, 2" "read_wide<HIP_vector_type<unsigned int, 4" > $O/fetch_calib.txt 2>&1 || true
+# what FETCH_SIZE counts per load width, on a stream of known size (the file the traffic figures are read against): the
+# micro-benchmark is built here (its binary is not tracked), and a failure of the step is said, not swallowed
+if /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/micro/fetch_calib.hip -o tools/micro/fetch_calib 2> $O/fetch_calib_build.err \
+   && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_calib -- tools/micro/fetch_calib > $O/fetch_calib.log 2>&1 \
+   && python3 tools/pmc_kernels.py $O/pmc_calib read_b8x3 "read_wide<unsigned int>" "read_wide<HIP_vector_type<unsigned int, 2" "read_wide<HIP_vector_type<unsigned int, 4" > $O/fetch_calib.txt 2>&1; then
+  echo "fetch calibration done"
+else
+  echo "FETCH_SIZE CALIBRATION SKIPPED (build or run failed: $O/fetch_calib_build.err, $O/fetch_calib.log)"; rm -f $O/fetch_calib.txt
+fi
 rm -rf $O/pmc_calib
+# the bf16 classifier (BASELINE config 5): kernel stats of the classifier alone, 128 frames per call
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cnn_bf16 -- python3 tools/cnn_modes.py 128 bf16 > $O/cnn_bf16.log 2> $O/prof_cnn_bf16.err
+find $O/prof_cnn_bf16 -name "*kernel_trace.csv" -delete 2>/dev/null || true
+find $O/prof_cnn_bf16 -name "*.db" -delete 2>/dev/null || true
+echo "bf16 classifier stats done"
 du -sh $O | tail -1
 python bench.py > $O/bench_full.json 2> $O/bench_full.err
 echo "bench done"

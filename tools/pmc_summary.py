@@ -26,6 +26,7 @@ STAGE = [("median_mfma_kernel<15>", "median", None, True), ("canny_nms", "canny_
          ("hough_vote", "hough_vote", None, True), ("warp_kernel", "warp", None, True),
          ("mog2_run_kernel", "mog2", None, True),
          ("conv_mfma16_h2_kernel", "cnn_conv2", 128, True), ("conv34_h2_kernel", "cnn_conv4", 128, True),
+         ("conv12_bf16_kernel", "cnn_conv2_bf16", 128, True), ("conv34_bf16_kernel", "cnn_conv4_bf16", 128, True),
          ("fc1_h2_kernel", "cnn_fc1", None, True)]
 
 
