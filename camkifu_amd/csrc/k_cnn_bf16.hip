@@ -99,34 +99,47 @@ __global__ __launch_bounds__(256, BF_C12_MINW) void conv12_bf16_kernel(
     __shared__ __attribute__((aligned(16))) uint16_t tile[C12_TILE_ROWS * C12_TILE_RS];
     __shared__ __attribute__((aligned(16))) uint16_t pix[C12_PIX_ROWS * C12_PIX_RS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
-    const int patch = blockIdx.x >> 1, half = blockIdx.x & 1;
+    // (round 5, measured level and dropped: a workgroup that takes both halves of a patch with the second half's pixels
+    // requested before the first half's k-loop -- 5.2 against 4.9-5.1 us per frame: three independent workgroups per CU hide the
+    // staging latency already)
+    const int patch = blockIdx.x >> 1;
     const int frame = patch / 100, reg = patch % 100;
-    const int py0 = region_origin(reg / 10) + 16 * half, px0 = region_origin(reg % 10);
+    const int px0 = region_origin(reg % 10);
     BF_STAMP_BEGIN;
-
-    // ---- the 24 x 40 pixels this half needs, as halves: a thread turns 12 bytes (4 pixels) into 32.  Byte b becomes the
-    // half 0x6400 | b = 1024 + b (one v_perm_b32 per two values against a constant), minus 1024 by one packed subtraction.
-    if (tid < 240) {
-        const int r = tid / 10, g = tid % 10;
-        const uint32_t* s = reinterpret_cast<const uint32_t*>(goban + ((size_t)frame * 380 + py0 + r) * 1140 + (size_t)px0 * 3) + 3 * g;
-        const uint32_t d0 = s[0], d1 = s[1], d2 = s[2];
-        const uint32_t p1 = __builtin_amdgcn_alignbit(d1, d0, 24), p2 = __builtin_amdgcn_alignbit(d2, d1, 16);
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f};
-        auto bg = [&](uint32_t p, uint32_t sel) {       // two bytes of p as halves
-            return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, __builtin_amdgcn_perm(p, 0x64646464u, sel)) - k1024);
-        };
-        uint4 lo, hi;
-        lo.x = bg(d0, 0x00050004u); lo.y = bg(d0, 0x000C0006u);       // (B, G), (R, 0): selector 0x0C is the constant byte 0
-        lo.z = bg(p1, 0x00050004u); lo.w = bg(p1, 0x000C0006u);
-        hi.x = bg(p2, 0x00050004u); hi.y = bg(p2, 0x000C0006u);
-        hi.z = bg(d2, 0x00060005u); hi.w = bg(d2, 0x000C0007u);       // the fourth pixel is bytes 1 .. 3 of d2
-        uint4* d = reinterpret_cast<uint4*>(&pix[r * C12_PIX_RS + 16 * g]);
-        d[0] = lo; d[1] = hi;
-    } else {
-        // columns 40 and 41 (under the zero weights of the sixth tap): finite values
+    // the 24 x 40 pixels a half needs: a thread fetches 12 bytes (4 pixels) ...
+    uint32_t d0 = 0, d1 = 0, d2 = 0;
+    auto load_raw = [&](int half_) {
+        if (tid < 240) {
+            const int r = tid / 10, g = tid % 10;
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(goban + ((size_t)frame * 380 + region_origin(reg / 10) + 16 * half_ + r) * 1140 + (size_t)px0 * 3) + 3 * g;
+            d0 = sp[0]; d1 = sp[1]; d2 = sp[2];
+        }
+    };
+    // ... and turns them into 32 bytes of halves.  Byte b becomes the half 0x6400 | b = 1024 + b (one v_perm_b32 per two values
+    // against a constant), minus 1024 by one packed subtraction.
+    auto store_pix = [&]() {
+        if (tid < 240) {
+            const int r = tid / 10, g = tid % 10;
+            const uint32_t p1 = __builtin_amdgcn_alignbit(d1, d0, 24), p2 = __builtin_amdgcn_alignbit(d2, d1, 16);
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f};
+            auto bg = [&](uint32_t p, uint32_t sel) {       // two bytes of p as halves
+                return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, __builtin_amdgcn_perm(p, 0x64646464u, sel)) - k1024);
+            };
+            uint4 lo, hi;
+            lo.x = bg(d0, 0x00050004u); lo.y = bg(d0, 0x000C0006u);       // (B, G), (R, 0): selector 0x0C is the constant byte 0
+            lo.z = bg(p1, 0x00050004u); lo.w = bg(p1, 0x000C0006u);
+            hi.x = bg(p2, 0x00050004u); hi.y = bg(p2, 0x000C0006u);
+            hi.z = bg(d2, 0x00060005u); hi.w = bg(d2, 0x000C0007u);       // the fourth pixel is bytes 1 .. 3 of d2
+            uint4* d = reinterpret_cast<uint4*>(&pix[r * C12_PIX_RS + 16 * g]);
+            d[0] = lo; d[1] = hi;
+        }
+    };
+    if (tid >= 240)     // columns 40 and 41 (under the zero weights of the sixth tap): finite values, written once
         for (int r = tid - 240; r < C12_PIX_ROWS; r += 16) *reinterpret_cast<uint4*>(&pix[r * C12_PIX_RS + 160]) = make_uint4(0, 0, 0, 0);
-    }
+    const int half = blockIdx.x & 1;
+    load_raw(half);
+    store_pix();
 
     // conv1's weights (A operand) and bias while the pixels land
     h8 wa[4][2];
@@ -150,26 +163,46 @@ __global__ __launch_bounds__(256, BF_C12_MINW) void conv12_bf16_kernel(
 
     // ---- conv1: 20 rows x 36 pixels = 45 tiles of 16 raster pixels.  D = W x P: a lane ends up with four consecutive
     // channels of one pixel per channel tile -> relu, two packed conversions, one 8-byte store into the swizzled tile.
-    for (int t = wave; t < 45; t += 4) {
-        const int m = 16 * t + l15, my = m / 36, mx = m - 36 * my;
-        const uint16_t* pp = &pix[my * C12_PIX_RS + 4 * mx];
-        f32x4 c1[2];
+    // A wave's tiles are t = wave + 4 i, i = 0 .. 10 (and 44 for wave 0).  The pixel fragments of tile i + 1 are requested
+    // before the MFMAs of tile i (a tile alone is one dependent chain: LDS -> 8 MFMAs -> conversion -> store).
+    {
+        auto frags = [&](int t, uint4 (&pf)[4]) {
+            const int m = 16 * t + l15, my = m / 36, mx = m - 36 * my;
+            const uint16_t* pp = &pix[my * C12_PIX_RS + 4 * mx];
 #pragma unroll
-        for (int n = 0; n < 2; n++) { c1[n][0] = bv1[n].x; c1[n][1] = bv1[n].y; c1[n][2] = bv1[n].z; c1[n][3] = bv1[n].w; }
+            for (int s = 0; s < 4; s++) {
+                const uint2 f0 = *reinterpret_cast<const uint2*>(pp + foff[s]), f1 = *reinterpret_cast<const uint2*>(pp + foff[s] + 4);
+                pf[s] = make_uint4(f0.x, f0.y, f1.x, f1.y);
+            }
+        };
+        auto tile_of = [&](int t, const uint4 (&pf)[4]) {
+            const int m = 16 * t + l15, my = m / 36, mx = m - 36 * my;
+            f32x4 c1[2];
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const uint2 f0 = *reinterpret_cast<const uint2*>(pp + foff[s]), f1 = *reinterpret_cast<const uint2*>(pp + foff[s] + 4);
-            const h8 pf = __builtin_bit_cast(h8, make_uint4(f0.x, f0.y, f1.x, f1.y));
+            for (int n = 0; n < 2; n++) { c1[n][0] = bv1[n].x; c1[n][1] = bv1[n].y; c1[n][2] = bv1[n].z; c1[n][3] = bv1[n].w; }
 #pragma unroll
-            for (int n = 0; n < 2; n++) c1[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s][n], pf, c1[n], 0, 0, 0);
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int n = 0; n < 2; n++) c1[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s][n], __builtin_bit_cast(h8, pf[s]), c1[n], 0, 0, 0);
+            uint16_t* tp = &tile[my * C12_TILE_RS + 32 * mx + 4 * (kq & 1)];
+            const int sw = swz32(mx);
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                const uint2 v = make_uint2(pk_bf16_relu(c1[n][0], c1[n][1]), pk_bf16_relu(c1[n][2], c1[n][3]));
+                *reinterpret_cast<uint2*>(tp + (((2 * n + (kq >> 1)) ^ sw) << 3)) = v;
+            }
+        };
+        uint4 pf[2][4];
+        frags(wave, pf[0]);
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+            const int t = wave + 4 * i;
+            if (i + 1 < 11 || wave == 0) frags(t + 4, pf[(i + 1) & 1]);      // (tile 44 exists for wave 0 only)
+            __builtin_amdgcn_sched_barrier(0);
+            tile_of(t, pf[i & 1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        uint16_t* tp = &tile[my * C12_TILE_RS + 32 * mx + 4 * (kq & 1)];
-        const int sw = swz32(mx);
-#pragma unroll
-        for (int n = 0; n < 2; n++) {
-            const uint2 v = make_uint2(pk_bf16_relu(c1[n][0], c1[n][1]), pk_bf16_relu(c1[n][2], c1[n][3]));
-            *reinterpret_cast<uint2*>(tp + (((2 * n + (kq >> 1)) ^ sw) << 3)) = v;
-        }
+        if (wave == 0) tile_of(44, pf[1]);
     }
     BF_STAMP(1);                                           // wave 0's conv1 tiles
     __syncthreads();
