@@ -1383,33 +1383,77 @@ __global__ __launch_bounds__(256) void fc1_h2_kernel(const float* __restrict__ x
         }
 }
 
-// dense 160 -> 81 and softmax.  One wave per patch.
-__global__ __launch_bounds__(64) void fc2_softmax_kernel(const float* __restrict__ h1, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, float* __restrict__ y, int npatch)
+// dense 160 -> 81 and softmax (nn_manager.py:295) on v_mfma_f32_16x16x4_f32: one wave = 16 patches x all 81 outputs (six
+// 16-output tiles, the last one 1 real column), 40 k-steps of 4.  An f32 MFMA is bit for bit a k-ordered fmaf chain, i.e.
+// the very sums of the round-1 kernel, which gave a wave ONE patch and a lane one output and loaded every weight per lane
+// from L1: 0.37 us per frame for 2.6 MFLOP (a form with the weights as scalar operands of v_fmac was tried first: LDS reads
+// and scalar loads share one counter, every k waited for the scalar cache -- slower than round 1's).  A lane ends up with
+// four patches' logits of one output per tile; the softmax of a patch runs over the 16 lanes of a row group (DPP
+// butterflies) and the six tiles.
+__global__ __launch_bounds__(256) void fc2_softmax_kernel(const float* __restrict__ h1, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int npatch)
 {
 #pragma clang fp contract(off)
-    __shared__ float lg[96];
-    __shared__ float ex[96];
-    const int patch = blockIdx.x, lane = threadIdx.x;
-    if (patch >= npatch) return;
-    const float* hv = h1 + (size_t)patch * 160;
-    for (int o = lane; o < 81; o += 64) {
-        float acc = 0.f;
-        for (int i = 0; i < 160; i++) acc = fmaf(hv[i], w[(size_t)i * 81 + o], acc);
-        lg[o] = acc + bias[o];
+    constexpr int NO = 81, NT = 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int p0 = (blockIdx.x * 4 + wave) * 16;
+    if (p0 >= npatch) return;
+    int pa = p0 + l15;                                     // A operand: patch l15 of the group, k = 4 s + kq
+    pa = pa < npatch ? pa : npatch - 1;
+    const float* ha = h1 + (size_t)pa * 160 + kq;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s = 0; s < 40; s++) {
+        const float a = ha[4 * s];
+        const float* wr = w + (size_t)(4 * s + kq) * NO + l15;          // B operand: w[k][16 t + l15]
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const float bw = 16 * t + l15 < NO ? wr[16 * t] : 0.f;
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc[t], 0, 0, 0);
+        }
     }
-    __syncthreads();
-    float mx = lg[0];
-    for (int i = 1; i < 81; i++) mx = lg[i] > mx ? lg[i] : mx;
-    for (int o = lane; o < 81; o += 64) ex[o] = expf(lg[o] - mx);
-    __syncthreads();
-    float sum = 0.f;
-    for (int i = 0; i < 81; i++) sum += ex[i];
-    for (int o = lane; o < 81; o += 64) {
-        const float v = ex[o] / sum;
-        ex[o] = v;
-        y[(size_t)patch * 81 + o] = v;
+    // lane (l15, kq): logits of patches p0 + 4 kq + e (e = 0 .. 3) for the outputs 16 t + l15
+    float v[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int o = 16 * t + l15;
+        const float bo = o < NO ? bias[o] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[t][e] = o < NO ? acc[t][e] + bo : -INFINITY;
     }
+#define CK_ROW16(V, OP)                                                                                              \
+    { float t_;                                                                                                      \
+      t_ = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), 0xB1, 0xF, 0xF, false)); V = OP(V, t_);  /* quad_perm [1,0,3,2] */ \
+      t_ = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), 0x4E, 0xF, 0xF, false)); V = OP(V, t_);  /* quad_perm [2,3,0,1] */ \
+      t_ = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), 0x141, 0xF, 0xF, false)); V = OP(V, t_); /* row_half_mirror */     \
+      t_ = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), 0x140, 0xF, 0xF, false)); V = OP(V, t_); } /* row_mirror */
+#define CK_FMAX(a, b) fmaxf(a, b)
+#define CK_FADD(a, b) ((a) + (b))
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        float mx = v[0][e];
+#pragma unroll
+        for (int t = 1; t < NT; t++) mx = fmaxf(mx, v[t][e]);
+        CK_ROW16(mx, CK_FMAX)
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            v[t][e] = expf(v[t][e] - mx);                 // exp(-inf) = 0 for the padding columns
+            sum += v[t][e];
+        }
+        CK_ROW16(sum, CK_FADD)
+        const int p = p0 + 4 * kq + e;
+        if (p < npatch) {
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                if (16 * t + l15 < NO) y[(size_t)p * NO + 16 * t + l15] = v[t][e] / sum;
+        }
+    }
+#undef CK_ROW16
+#undef CK_FMAX
+#undef CK_FADD
 }
 
 }  // namespace
@@ -1656,7 +1700,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         TimeScope ts(ctx, "cnn_tail");
         const int np = nframes * 100;
         CK_TRY(k_cnn_bf16_fc1(ctx, q4_all, np, hb));
-        hipLaunchKernelGGL(fc2_softmax_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float*)hb,
+        hipLaunchKernelGGL(fc2_softmax_kernel, dim3((np + 63) / 64), dim3(256), 0, ctx->stream, (const float*)hb,
                            (const float*)W.d2w.p, (const float*)W.d2b.p, d_y, np);
         hipLaunchKernelGGL(decode_kernel, dim3(nframes), dim3(128), 0, ctx->stream, (const float*)d_y, d_labels, d_conf, nframes, d_nonfinite, d_rlabel, d_rconf);
         CK_HIP(ctx, hipGetLastError());
@@ -1804,7 +1848,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         else
         hipLaunchKernelGGL(fc1_mfma16_kernel, dim3((np + 63) / 64), dim3(256), 0, ctx->stream,
                            (const float*)p4_all, (const float*)W.d1w.p, (const float*)W.d1b.p, h1, np);
-        hipLaunchKernelGGL(fc2_softmax_kernel, dim3(np), dim3(64), 0, ctx->stream, (const float*)h1,
+        hipLaunchKernelGGL(fc2_softmax_kernel, dim3((np + 63) / 64), dim3(256), 0, ctx->stream, (const float*)h1,
                            (const float*)W.d2w.p, (const float*)W.d2b.p, d_y, np);
         hipLaunchKernelGGL(decode_kernel, dim3(nframes), dim3(128), 0, ctx->stream, (const float*)d_y, d_labels, d_conf, nframes, d_nonfinite, d_rlabel, d_rconf);
         CK_HIP(ctx, hipGetLastError());
