@@ -918,6 +918,34 @@ def test_cnn_filter_maps_below_the_softmax(ck, ora, synth, mode):
 
 
 @pytest.mark.parametrize("mode", ["f16x2", "fp32", "bf16"])
+def test_cnn_answers_do_not_depend_on_the_batch(ck, synth, mode):
+    """A region's answer is a function of its 40 x 40 pixels alone: whatever the batch -- one goban image, three, or 131
+    (more than one 128-frame chunk of the convolutions, and dense-layer workgroups that are partly empty) -- every region
+    label, confidence and softmax row is bit for bit the one the image gets when it is classified on its own.  Guards the
+    tails of every kernel's grid (partial workgroups of the dense layers, the last chunk) in every mode."""
+    from camkifu_amd import capi
+    rng = np.random.default_rng(41)
+    base = rng.integers(0, 256, (5, 380, 380, 3), dtype=np.uint8)
+    base[1] = (base[1] // 64) * 64
+    base[2, 100:300] = rng.integers(0, 256, 3, dtype=np.uint8)
+    big = base[np.arange(131) % 5]
+    ck.cnn_set_weights(synth.cnn_weights())
+    ck.cnn_set_mode({"f16x2": capi.CK_CNN_F16X2, "fp32": capi.CK_CNN_FP32, "bf16": capi.CK_CNN_BF16}[mode])
+    try:
+        alone = [ck.cnn_predict(base[k]) for k in range(5)]
+        y3, l3, c3 = ck.cnn_predict(base[:3])
+        yb, lb, cb = ck.cnn_predict(big)
+    finally:
+        ck.cnn_set_mode(capi.CK_CNN_DEFAULT)
+    for k in range(3):
+        assert np.array_equal(y3[k], alone[k][0][0]) and np.array_equal(l3[k], alone[k][1][0]) and np.array_equal(c3[k], alone[k][2][0])
+    for k in range(131):
+        ref = alone[k % 5]
+        assert np.array_equal(yb[k], ref[0][0]), (mode, k)
+        assert np.array_equal(lb[k], ref[1][0]) and np.array_equal(cb[k], ref[2][0])
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "fp32", "bf16"])
 def test_cnn_against_torch_fp64(ck, ora, synth, mode):
     """K11 pinned without the oracle: the HIP classifier against a float64 torch evaluation of the same network
     on the same gobans.  f32-accurate modes: softmax within 1e-4 and identical labels wherever float64's own
