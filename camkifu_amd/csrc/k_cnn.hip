@@ -1300,19 +1300,23 @@ __global__ __launch_bounds__(256) void fc1_h2_kernel(const float* __restrict__ x
 #pragma unroll
             for (int e = 0; e < 4; e++) acc[t][j][e] = 0.f;
 
-    float4 raw[NLD];
-    auto fetch = [&](int ch) {
+    // Few workgroups (200 per 128-frame call), each a chain of 26 chunks: what the kernel waits for is latency, so everything
+    // runs well ahead (round 5) -- the activations TWO chunks (two register sets), the weight fragments a whole chunk (a ring
+    // of SPC slots: the fragments of k-step s + SPC are requested into the slot step s has just used).  One step ahead, as
+    // first built, a call took 115 us: 104 k-steps x an L2 round trip.
+    float4 raw[2][NLD];
+    auto fetch = [&](int ch, float4 (&dst)[NLD]) {
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
             const int i = tid + 256 * q, row = i / (KC / 4), c4 = i % (KC / 4);
             int p = p0 + row;
             p = p > npatch - 1 ? npatch - 1 : p;
             const int k = ch * KC + 4 * c4;
-            raw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ch < NCH && k < KIN) raw[q] = *reinterpret_cast<const float4*>(x + (size_t)p * KIN + k);
+            dst[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ch < NCH && k < KIN) dst[q] = *reinterpret_cast<const float4*>(x + (size_t)p * KIN + k);
         }
     };
-    uint4 wf[2][3][2];                               // [ring slot][tile][hi|lo]
+    uint4 wf[SPC][3][2];                             // [ring slot][tile][hi|lo]
     auto wload = [&](int slot, int s) {
 #pragma unroll
         for (int t = 0; t < 3; t++)
@@ -1321,15 +1325,17 @@ __global__ __launch_bounds__(256) void fc1_h2_kernel(const float* __restrict__ x
                 wf[slot][t][1] = wq[(((size_t)(wave + 4 * t) * KS + s) * 2 + 1) * 64];
             }
     };
-    fetch(0);
-    wload(0, 0);
+    fetch(0, raw[0]);
+    fetch(1, raw[1]);
+#pragma unroll
+    for (int ks = 0; ks < SPC; ks++) wload(ks, ks);
     float big = 0.f;
-    for (int ch = 0; ch < NCH; ch++) {
+    auto chunk = [&](int ch, float4 (&mine)[NLD]) {
         __syncthreads();                             // previous chunk fully consumed
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
             const int i = tid + 256 * q, row = i / (KC / 4), c4 = i % (KC / 4);
-            const float v[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
+            const float v[4] = {mine[q].x, mine[q].y, mine[q].z, mine[q].w};
             typedef _Float16 h4v __attribute__((ext_vector_type(4)));
             big = fmaxf(big, fmaxf(fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))));
             h2v h01, l01, h23, l23;
@@ -1340,11 +1346,10 @@ __global__ __launch_bounds__(256) void fc1_h2_kernel(const float* __restrict__ x
             *reinterpret_cast<h4v*>(&lds[row * RSH + KC + 4 * c4]) = lo;
         }
         __syncthreads();
-        fetch(ch + 1);
+        fetch(ch + 2, mine);
 #pragma unroll
         for (int ks = 0; ks < SPC; ks++) {
             const int s = ch * SPC + ks;
-            if (s + 1 < KS) wload((ks + 1) & 1, s + 1);
             h8 xh[4], xl[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -1355,7 +1360,7 @@ __global__ __launch_bounds__(256) void fc1_h2_kernel(const float* __restrict__ x
 #pragma unroll
             for (int t = 0; t < 3; t++)
                 if (t < ntw) {
-                    const h8 wh = __builtin_bit_cast(h8, wf[ks & 1][t][0]), wl = __builtin_bit_cast(h8, wf[ks & 1][t][1]);
+                    const h8 wh = __builtin_bit_cast(h8, wf[ks][t][0]), wl = __builtin_bit_cast(h8, wf[ks][t][1]);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[j], acc[t][j], 0, 0, 0);
@@ -1363,7 +1368,13 @@ __global__ __launch_bounds__(256) void fc1_h2_kernel(const float* __restrict__ x
                         acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[j], acc[t][j], 0, 0, 0);
                     }
                 }
+            if (s + SPC < KS) wload(ks, s + SPC);
         }
+    };
+    static_assert(NCH % 2 == 0, "26 chunks: pairs");
+    for (int ch = 0; ch < NCH; ch += 2) {
+        chunk(ch, raw[0]);
+        chunk(ch + 1, raw[1]);
     }
     if (overflow && !(big <= 65000.f)) *overflow = 1;
 #pragma unroll

@@ -474,7 +474,7 @@ __global__ __launch_bounds__(192, BF_C34_MINW) void conv34_bf16_kernel(
 // 160 outputs, so the activations leave HBM once (the round-1 kernel gave a wave 32 patches x 32 outputs and read every
 // activation five times: 0.84 us per frame, all of it that traffic).  D = W x X: wave w owns the output tiles w, w + 4,
 // w + 8 (< 10) and all four patch tiles; the activations of a chunk of 128 k go through LDS (copied as they are: the maps
-// are bf16 already), the weight fragments stream from L2 in fragment order, one k-step ahead.
+// are bf16 already), the weight fragments stream from L2 in fragment order, a chunk ahead.
 //   x  : [patch][36 px][96 ch] bf16 (conv34's output; channels 90 .. 95 are zero)
 //   wt : bf16 [output tile 10][k-step 108][lane][8] with k = px * 96 + ch (pack below)      out : [patch][160] f32
 __global__ __launch_bounds__(256) void fc1_bf16_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
@@ -494,37 +494,42 @@ __global__ __launch_bounds__(256) void fc1_bf16_kernel(const uint16_t* __restric
     for (int t = 0; t < 3; t++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint4 raw[NLD];
-    auto fetch = [&](int ch) {
+    // Few workgroups (200 per 128-frame call), each a chain of 27 chunks: what it waits for is latency, so everything runs
+    // well ahead -- the activations TWO chunks (two register sets), the weight fragments a whole chunk (a ring of SPC slots:
+    // the fragment of k-step s + SPC is requested into the slot step s has just used).  One step ahead, as first built, the
+    // kernel took 63 us per call: 108 k-steps x an L2 round trip.
+    uint4 raw[2][NLD];
+    auto fetch = [&](int ch, uint4 (&dst)[NLD]) {
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
             const int i = tid + 256 * q, row = i / (KC / 8), c8 = i % (KC / 8);
             int p = p0 + row;
             p = p > npatch - 1 ? npatch - 1 : p;
-            raw[q] = ch < NCH ? *reinterpret_cast<const uint4*>(x + (size_t)p * KIN + ch * KC + 8 * c8) : make_uint4(0, 0, 0, 0);
+            dst[q] = ch < NCH ? *reinterpret_cast<const uint4*>(x + (size_t)p * KIN + ch * KC + 8 * c8) : make_uint4(0, 0, 0, 0);
         }
     };
-    uint4 wf[2][3];
+    uint4 wf[SPC][3];
     auto wload = [&](int slot, int s) {
 #pragma unroll
         for (int t = 0; t < 3; t++)
             if (t < ntw) wf[slot][t] = wq[((size_t)(wave + 4 * t) * KS + s) * 64];
     };
-    fetch(0);
-    wload(0, 0);
-    for (int ch = 0; ch < NCH; ch++) {
+    fetch(0, raw[0]);
+    fetch(1, raw[1]);
+#pragma unroll
+    for (int ks = 0; ks < SPC; ks++) wload(ks, ks);
+    auto chunk = [&](int ch, uint4 (&mine)[NLD]) {
         __syncthreads();                              // previous chunk fully consumed
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
             const int i = tid + 256 * q, row = i / (KC / 8), c8 = i % (KC / 8);
-            *reinterpret_cast<uint4*>(&lds[row * RSH + 8 * c8]) = raw[q];
+            *reinterpret_cast<uint4*>(&lds[row * RSH + 8 * c8]) = mine[q];
         }
         __syncthreads();
-        fetch(ch + 1);
+        fetch(ch + 2, mine);
 #pragma unroll
         for (int ks = 0; ks < SPC; ks++) {
             const int s = ch * SPC + ks;
-            if (s + 1 < KS) wload((ks + 1) & 1, s + 1);
             bf16x8 xb[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) xb[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&lds[(16 * j + l15) * RSH + 32 * ks + 8 * kq]));
@@ -533,10 +538,17 @@ __global__ __launch_bounds__(256) void fc1_bf16_kernel(const uint16_t* __restric
                 if (t < ntw) {
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks & 1][t]), xb[j], acc[t][j], 0, 0, 0);
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks][t]), xb[j], acc[t][j], 0, 0, 0);
                 }
+            if (s + SPC < KS) wload(ks, s + SPC);
         }
+    };
+    static_assert(NCH % 2 == 1, "27 chunks: pairs, then one");
+    for (int ch = 0; ch + 1 < NCH; ch += 2) {
+        chunk(ch, raw[0]);
+        chunk(ch + 1, raw[1]);
     }
+    chunk(NCH - 1, raw[0]);
 #pragma unroll
     for (int t = 0; t < 3; t++)
         if (t < ntw) {
