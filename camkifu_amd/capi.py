@@ -15,7 +15,7 @@ SO_PATH = os.environ.get("CK_HIP_LIB") or os.path.join(_HERE, "libck_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 CK_HOST, CK_DEVICE = 0, 1
-CK_CNN_FP32, CK_CNN_BF16, CK_CNN_F16X2 = 0, 1, 2
+CK_CNN_FP32, CK_CNN_BF16, CK_CNN_F16X2, CK_CNN_F16Q8 = 0, 1, 2, 3
 CK_CNN_DEFAULT = CK_CNN_F16X2            # what a new context computes in
 CK_BOARD_LINES, CK_BOARD_NO_CONTOUR, CK_BOARD_TOO_SMALL = 0, 1, 2
 

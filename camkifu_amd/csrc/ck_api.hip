@@ -242,7 +242,7 @@ int ck_ctx_destroy2(ck_ctx* ctx)
                        &ctx->out_stage, &ctx->mats,
                        &ctx->cnn.c1w, &ctx->cnn.c1b, &ctx->cnn.c2w, &ctx->cnn.c2b, &ctx->cnn.c3w, &ctx->cnn.c3b,
                        &ctx->cnn.c4w, &ctx->cnn.c4b, &ctx->cnn.d1w, &ctx->cnn.d1b, &ctx->cnn.d2w, &ctx->cnn.d2b,
-                       &ctx->cnn.c2w_bf, &ctx->cnn.c3w_bf, &ctx->cnn.c4w_bf, &ctx->cnn.d1w_bf, &ctx->cnn.c1w_f16, &ctx->cnn.d1w_bfp, &ctx->cnn.d1w_h2,
+                       &ctx->cnn.c2w_bf, &ctx->cnn.c3w_bf, &ctx->cnn.c4w_bf, &ctx->cnn.d1w_bf, &ctx->cnn.c1w_f16, &ctx->cnn.d1w_bfp, &ctx->cnn.c1w_q8, &ctx->cnn.c2x_q8, &ctx->cnn.c3x_q8, &ctx->cnn.c4x_q8, &ctx->cnn.d1w_h2,
                        &ctx->cnn.c1w_h2, &ctx->cnn.c2w_h2, &ctx->cnn.c3w_h2, &ctx->cnn.c4w_h2 };
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (ctx->cnn_flag_host) (void)hipHostFree(ctx->cnn_flag_host);
@@ -534,7 +534,7 @@ int ck_cnn_set_mode(ck_ctx* ctx, int mode)
 {
     CK_API_BEGIN(ctx)
     if (!ctx) return CK_ERR_ARG;
-    if (mode != CK_CNN_FP32 && mode != CK_CNN_BF16 && mode != CK_CNN_F16X2) return ck_fail(ctx, CK_ERR_ARG, "unknown cnn mode %d", mode);
+    if (mode != CK_CNN_FP32 && mode != CK_CNN_BF16 && mode != CK_CNN_F16X2 && mode != CK_CNN_F16Q8) return ck_fail(ctx, CK_ERR_ARG, "unknown cnn mode %d", mode);
     ctx->cnn_mode = mode;
     return CK_OK;
     CK_API_END(ctx)
@@ -552,7 +552,7 @@ static int cnn_predict_dev(ck_ctx* ctx, const uint8_t* d_goban, int n, float* y,
     CK_TRY(ck_ensure(ctx, ctx->confbuf, (size_t)n * 361 * sizeof(double)));
     CK_TRY(ck_ensure(ctx, ctx->rlblbuf, (size_t)n * 100));
     CK_TRY(ck_ensure(ctx, ctx->rconfbuf, (size_t)n * 100 * sizeof(double)));
-    if (ctx->cnn_mode == CK_CNN_F16X2) {
+    if (ck_cnn_split(ctx->cnn_mode)) {
         // Safety net of the split-precision mode: an activation beyond the fp16 range (|x| > 65000; never seen with
         // 8-bit images and sane weights) would turn into inf.  The kernels raise a flag in host-mapped memory, which
         // cnn_finish() looks at after the one synchronisation the call needs anyway.
@@ -581,10 +581,11 @@ static int cnn_finish(ck_ctx* ctx, const uint8_t* d_goban, int n, float* y, uint
                       RegionOut ro = RegionOut())
 {
     CK_TRY(finish(ctx));
-    if (ctx->cnn_mode == CK_CNN_F16X2 && ctx->cnn_flag_host && *(volatile int*)ctx->cnn_flag_host) {
+    if (ck_cnn_split(ctx->cnn_mode) && ctx->cnn_flag_host && *(volatile int*)ctx->cnn_flag_host) {
+        const int mode = ctx->cnn_mode;
         ctx->cnn_mode = CK_CNN_FP32;
         const int rc = cnn_predict_dev(ctx, d_goban, n, y, labels, conf, out_space, ro);
-        ctx->cnn_mode = CK_CNN_F16X2;
+        ctx->cnn_mode = mode;
         ctx->cnn_fallbacks++;
         if (rc) return rc;
         return finish(ctx);
@@ -615,7 +616,7 @@ int ck_cnn_maps(ck_ctx* ctx, const uint8_t* goban, int n, int in_space, float* p
     CK_TRY(ck_to_device(ctx, goban, (size_t)n * 380 * 380 * 3, in_space, ctx->in_stage, &d_in));
     CK_TRY(cnn_predict_dev(ctx, (const uint8_t*)d_in, n, nullptr, nullptr, nullptr, CK_HOST));
     CK_TRY(finish(ctx));
-    if (ctx->cnn_mode == CK_CNN_F16X2 && ctx->cnn_flag_host && *(volatile int*)ctx->cnn_flag_host)
+    if (ck_cnn_split(ctx->cnn_mode) && ctx->cnn_flag_host && *(volatile int*)ctx->cnn_flag_host)
         return ck_fail(ctx, CK_ERR_STATE, "an activation left the fp16 range: the maps of this batch are the f32 chain's (set CK_CNN_FP32)");
     // after one chunk the pooled conv2 output is still in act1 and the pooled conv4 output in act2 (k_cnn_predict)
     const size_t np = (size_t)n * 100;

@@ -45,6 +45,9 @@ struct Mog2State {
     bool rates_busy = false;
 };
 
+// the modes that carry f32 operands as split fp16 (and share the overflow flag and the f32 fallback)
+static inline bool ck_cnn_split(int mode) { return mode == CK_CNN_F16X2 || mode == CK_CNN_F16Q8; }
+
 struct CnnWeights {
     bool set = false;
     // repacked fp32 (correlation layout, [kh][kw][cin][cout] with the flip applied)
@@ -55,6 +58,9 @@ struct CnnWeights {
     DevBuf d1w_bfp;      // dense 1 for fc1_bf16_kernel: bf16 fragments over the padded maps
     // hi / lo fp16 planes for the split-precision mode
     DevBuf c1w_h2, c2w_h2, c3w_h2, c4w_h2, d1w_h2;
+    // CK_CNN_F16Q8 (k_cnn_q8.hip): conv1 as fp16 fragments of both planes, the cross-term weights of conv2 .. conv4 as e4m3
+    DevBuf c1w_q8, c2x_q8, c3x_q8, c4x_q8;
+    bool q8_ok = false;  // every weight inside the e4m3 range of its block scale (else the mode runs the three-MFMA kernels)
 };
 
 struct ck_ctx {
@@ -242,6 +248,9 @@ int k_cnn_bf16_pack_conv1(ck_ctx* ctx, const float* k1, DevBuf& dst);
 int k_cnn_bf16_convs(ck_ctx* ctx, const uint8_t* gob, int np, uint16_t* p2, uint16_t* q4);
 int k_cnn_bf16_pack_fc1(ck_ctx* ctx, const float* w, DevBuf& dst);
 int k_cnn_bf16_fc1(ck_ctx* ctx, const uint16_t* q4, int np, float* h1);
+// CK_CNN_F16Q8 (k_cnn_q8.hip): the same two fused kernels with f32 maps in and out (drop-ins for the split-precision pair of k_cnn.hip)
+int k_cnn_q8_pack(ck_ctx* ctx, const float* k1, const float* k2, const float* k3, const float* k4);
+int k_cnn_q8_conv12(ck_ctx* ctx, const uint8_t* gob, int np, float* p2, int* overflow);
 int k_mog2_apply(ck_ctx* ctx, Mog2State& st, const uint8_t* d_img, double lr, uint8_t* d_fg);
 int k_mog2_run(ck_ctx* ctx, Mog2State& st, const uint8_t* d_gobans, int n, const double* learning_rates,
                int32_t* d_fgcount, uint8_t* d_last_fg, int skip_row, int skip_col);

@@ -1655,6 +1655,7 @@ int k_cnn_pack_weights(ck_ctx* ctx, const float* const w[12], int space)
     CK_TRY(pack_h2(host[2].data(), 5, 5, 32, 32, ctx->cnn.c2w_h2));
     CK_TRY(pack_h2(host[4].data(), 3, 3, 32, 90, ctx->cnn.c3w_h2));
     CK_TRY(pack_h2(host[6].data(), 3, 3, 90, 90, ctx->cnn.c4w_h2));
+    CK_TRY(k_cnn_q8_pack(ctx, host[0].data(), host[2].data(), host[4].data(), host[6].data()));
     {   // dense1 for fc1_h2_kernel: [output tile][k-step][plane][lane = kslot*16 + output][8 consecutive k], weights x 2^8
         std::vector<uint16_t> v((size_t)10 * 104 * 2 * 64 * 8, 0);
         for (int t = 0; t < 10; t++)
@@ -1717,7 +1718,8 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         CK_HIP(ctx, hipGetLastError());
         return CK_OK;
     }
-    const bool h2 = ctx->cnn_mode == CK_CNN_F16X2;
+    const bool h2 = ck_cnn_split(ctx->cnn_mode);
+    const bool q8 = ctx->cnn_mode == CK_CNN_F16Q8 && W.q8_ok;      // (weights outside the e4m3 range: the three-MFMA kernels)
     for (int f0 = 0; f0 < nframes; f0 += CHUNK) {
         const int nf = nframes - f0 < CHUNK ? nframes - f0 : CHUNK;
         const int np = nf * 100;
@@ -1725,7 +1727,7 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
         float* p4 = p4_all + (size_t)f0 * 100 * 3240;
         {
             TimeScope ts(ctx, "cnn_conv1");
-            if (h2 && H2C2_SWZ && H2_FUSE1) {
+            if (q8 || (h2 && H2C2_SWZ && H2_FUSE1)) {
                 // conv1 is computed inside conv2's staging (below)
             } else if (h2)
                 hipLaunchKernelGGL((conv1_h2_kernel<C1_R>), dim3(std::min(np * 3, C1_GRID)), dim3(64 * (27 / C1_R)), 0, ctx->stream, gob,
@@ -1738,7 +1740,9 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
             TimeScope ts(ctx, "cnn_conv2");
             // 32 rows: 4 groups of (4 waves x 2 rows), pooled output 16x16x32
             // 8x8 pooling tiles of 4x4 pixels: workgroups of whole tile rows, pooled output 16x16x32
-            if (h2) {
+            if (q8) {
+                CK_TRY(k_cnn_q8_conv12(ctx, gob, np, p2, d_nonfinite));
+            } else if (h2) {
 #if H2C2_SWZ
                 hipLaunchKernelGGL((conv_mfma16_h2_kernel<36, 36, 32, 5, 5, 32, H2C2S_TB, 64 / H2C2S_TB + (64 % H2C2S_TB != 0), H2C2S_WM, 2, true, H2C2S_PF, H2C2S_SB, true, H2_FUSE1 != 0>), dim3(np, 64 / H2C2S_TB + (64 % H2C2S_TB != 0)), dim3(64 * H2C2S_WM), (size_t)lds_pad_conv2(), ctx->stream,
                                    (const float*)a1, (const uint16_t*)W.c2w_h2.p, (const float*)W.c2b.p, p2, 1.f / H2_WSCALE, d_nonfinite,

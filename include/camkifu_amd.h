@@ -30,7 +30,7 @@ extern "C" {
 enum { CK_OK = 0, CK_ERR_ARG = 1, CK_ERR_HIP = 2, CK_ERR_CAPACITY = 3, CK_ERR_STATE = 4 };
 enum { CK_HOST = 0, CK_DEVICE = 1 };
 enum { CK_BACKEND_HIP = 1 };
-enum { CK_CNN_FP32 = 0, CK_CNN_BF16 = 1, CK_CNN_F16X2 = 2 };
+enum { CK_CNN_FP32 = 0, CK_CNN_BF16 = 1, CK_CNN_F16X2 = 2, CK_CNN_F16Q8 = 3 };
 
 /* per-frame status of the board path, mirrors the early exits of
  * BoardFinderAuto._detect (board/bf_auto.py:76-82) */

@@ -12,7 +12,7 @@ from camkifu_amd.stone.nn_manager import NNManager
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 128
 modes = sys.argv[2].split(",") if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else ["bf16", "f16x2"]
-MODE = {"f16x2": capi.CK_CNN_F16X2, "fp32": capi.CK_CNN_FP32, "bf16": capi.CK_CNN_BF16}
+MODE = {"f16x2": capi.CK_CNN_F16X2, "fp32": capi.CK_CNN_FP32, "bf16": capi.CK_CNN_BF16, "f16q8": capi.CK_CNN_F16Q8}
 ctx = capi.Context(0)
 W = NNManager.init_net()
 ctx.cnn_set_weights(W)
