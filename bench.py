@@ -39,7 +39,8 @@ MFMA_F16_PEAK_TF = 2500.0        # dense fp16 / bf16 MFMA
 MACS = dict(cnn_conv1=311.04e6, cnn_conv2=2621.44e6, cnn_conv3=508.03e6, cnn_conv4=1049.76e6)
 FUSED_FILTER_BYTES = lambda h, w: 4 * h * w          # noqa: E731  read the frame once, write the edge map
 DST = [(0, 0), (380, 0), (380, 380), (0, 380)]
-DTYPE = {"fp32": "u8+f32", "bf16": "u8+bf16(f32 accumulate)", "f16x2": "u8+f16x2(f32 accumulate)"}
+DTYPE = {"fp32": "u8+f32", "bf16": "u8+bf16(f32 accumulate)", "f16x2": "u8+f16x2(f32 accumulate)",
+         "f16q8": "u8+f16 main term, e4m3 cross terms (f32 accumulate)"}
 
 
 def thresholds_per_tile(med):
@@ -269,9 +270,10 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per batch per GPU")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--cnn", choices=["fp32", "bf16", "f16x2"], default="f16x2",
+    ap.add_argument("--cnn", choices=["fp32", "bf16", "f16x2", "f16q8"], default="f16x2",
                     help="f16x2 (default): f32-accurate split-fp16 operands on the fp16 matrix pipe; fp32: k-ordered f32 "
-                         "MFMA chain; bf16: bf16 operands (BASELINE config 5)")
+                         "MFMA chain; bf16: bf16 operands (BASELINE config 5); f16q8: split fp16 with the cross terms as e4m3 on "
+                         "the block-scaled MFMA (maps within 1e-4, not f32-equivalent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip fp32_chain / pcie_inclusive / k1_content / cv2 legs")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on one GPU)")
@@ -352,7 +354,7 @@ def main():
                                                            device=dev, quiet=52, move_every=32, hand_frames=12, select=mine)
     weights = NNManager.init_net()
     torch.cuda.synchronize()
-    mode = {"fp32": capi.CK_CNN_FP32, "bf16": capi.CK_CNN_BF16, "f16x2": capi.CK_CNN_F16X2}[args.cnn]
+    mode = {"fp32": capi.CK_CNN_FP32, "bf16": capi.CK_CNN_BF16, "f16x2": capi.CK_CNN_F16X2, "f16q8": capi.CK_CNN_F16Q8}[args.cnn]
     for _, c in lanes:
         c.cnn_set_weights({k: torch.from_numpy(v).to(dev) for k, v in weights.items()})
         c.cnn_set_mode(mode)
@@ -443,6 +445,19 @@ def main():
                 r["executed_mfma_frac"] = round(mult * ach / peak, 5)
                 r["note"] = ("split precision: every f32-equivalent product is three fp16 MFMAs (two in conv1); `frac` prices "
                              "the ALGORITHMIC flops against the fp16 peak, executed_mfma_frac the instructions executed")
+            if cnn == "f16q8":
+                # matrix-pipe cycles per product in units of one fp16 MFMA: main term 1, cross terms 32 cycles per scaled instruction
+                # (= 2 units) over the taps it covers -- conv2 (400 + 480) / 400, conv3 (144 + 192) / 144, conv4 (432 + 448) / 432;
+                # conv1 two fp16 MFMAs per product at 75 of 128 k used
+                if stage == "cnn_conv2":
+                    mult = (2.2 * MACS["cnn_conv2"] + (2.0 * 128 / 75 * MACS["cnn_conv1"] if fused1 else 0.0)) / macs
+                elif stage == "cnn_conv4":
+                    mult = (880.0 / 432 * MACS["cnn_conv4"] + (336.0 / 144 * MACS["cnn_conv3"] if fused34 else 0.0)) / macs
+                else:
+                    mult = 2.2
+                r["executed_mfma_frac"] = round(mult * ach / peak, 5)
+                r["note"] = ("split precision, cross terms as e4m3 on the block-scaled MFMA: executed_mfma_frac prices the pipe cycles "
+                             "issued (fp16 MFMA 16, scaled MFMA 32 per two taps) against the fp16 peak, `frac` the ALGORITHMIC flops")
             return r
         per_frame = {"median": 2 * 3 * ww * hh, "canny_nms": 4 * ww * hh, "warp": 433200 + 3 * ww * hh, "ccl": 6 * ww * hh,
                      "canny_hyst": 2 * ww * hh, "mog2": 433200 + 1444}.get(stage, 4 * ww * hh)
@@ -547,12 +562,13 @@ def main():
                                         note="same timed region with CK_CNN_FP32 (k-ordered f32 MFMA chain)")
             for _, c in lanes:
                 c.cnn_set_mode(mode)
-        # (1a) BASELINE config 5's classifier at this rank count: the same timed region with the stone classifier in bf16
-        # (k_cnn_bf16.hip: one bf16 MFMA per product, conv1 + conv2 and conv3 + conv4 fused).  With --streams every rank
-        # runs exactly this on its own film; at one rank the two coincide.  Same game record as the default mode required.
-        if args.cnn != "bf16":
+        # (1a) the same timed region with the stone classifier in another mode; same game record as the default mode required.
+        #   bf16_streams: BASELINE config 5's classifier at this rank count (k_cnn_bf16.hip: one bf16 MFMA per product, conv1 + conv2
+        #     and conv3 + conv4 fused).  With --streams every rank runs exactly this on its own film; at one rank the two coincide.
+        #   f16q8: split precision with the two cross terms of a product as e4m3 on the block-scaled MFMA (k_cnn_q8.hip).
+        def classifier_leg(name, cmode, note):
             for _, c in lanes:
-                c.cnn_set_mode(capi.CK_CNN_BF16)
+                c.cnn_set_mode(cmode)
             pb = new_pipe()
             pb.process_batch(frames, n_total)
             if pb.mtx is None:
@@ -561,11 +577,8 @@ def main():
             k = max(6, args.steps // 2)
             db = timed(pb, k, 2, frames)
             pb.close()
-            leg = dict(value=round((world if args.streams else 1) * n_total * k / db, 2), unit="frames/s", steps=k, dtype=DTYPE["bf16"],
-                       same_game_record=bool(req_b == requests),
-                       note="BASELINE config 5 (one 1080p stream per GPU, stone-CNN in bf16 on MFMA) at this run's rank count: the "
-                            "headline's timed region with CK_CNN_BF16; labels are held to the oracle's by "
-                            "tests/test_gpu_fullsize.py::test_config5_bf16_labels_against_the_oracle, the filter maps to 3e-2")
+            leg = dict(value=round((world if args.streams else 1) * n_total * k / db, 2), unit="frames/s", steps=k, dtype=DTYPE[name],
+                       same_game_record=bool(req_b == requests), note=note)
             if rank == 0:
                 st_b = stage_pass(frames, M, F, board=False)
                 conv_b = {x: st_b[x] for x in st_b if x.startswith("cnn_")}
@@ -575,11 +588,25 @@ def main():
                 leg["stone_grid_match_pct"] = round(100.0 * float((gb[calm[:64]] == truth[mine[:64]][calm[:64]]).mean()), 3)
                 leg["stages"] = conv_b
                 leg["classifier_us_per_frame"] = round(sum(v["us_per_frame"] for v in conv_b.values()), 3)
-                leg["mfma_kernel"] = roofline_of(max((x for x in conv_b if x in MACS), key=lambda x: conv_b[x]["ms_total"]), st_b, "bf16", F, H, W,
+                leg["mfma_kernel"] = roofline_of(max((x for x in conv_b if x in MACS), key=lambda x: conv_b[x]["ms_total"]), st_b, name, F, H, W,
                                                  with_traffic=False)
             for _, c in lanes:
                 c.cnn_set_mode(mode)
-            extras["bf16_streams"] = leg
+            return leg
+        if args.cnn != "bf16":
+            extras["bf16_streams"] = classifier_leg(
+                "bf16", capi.CK_CNN_BF16,
+                "BASELINE config 5 (one 1080p stream per GPU, stone-CNN in bf16 on MFMA) at this run's rank count: the headline's timed "
+                "region with CK_CNN_BF16; labels are held to the oracle's by tests/test_gpu_fullsize.py::"
+                "test_config5_bf16_labels_against_the_oracle, the filter maps to 3e-2")
+        if args.cnn != "f16q8":
+            extras["f16q8"] = classifier_leg(
+                "f16q8", capi.CK_CNN_F16Q8,
+                "NOT the headline: the headline's timed region with CK_CNN_F16Q8 -- the split-precision classifier with the two cross "
+                "terms of every product (2^-11 of the main term) rounded to e4m3 and issued as ONE block-scaled MFMA per two taps "
+                "(k_cnn_q8.hip): two thirds of the matrix-pipe cycles.  Pooled maps within 5e-5 of their scale against a float64 "
+                "evaluation (bar 1e-4: tests/test_gpu_parity.py::test_cnn_filter_maps_below_the_softmax[f16q8]); the default mode "
+                "stays the f32-equivalent f16x2 (1e-6)")
         # (1b) hold-off-aware scheduling (one rank): the reference does not run K1..K6 during the hold-off after a hit
         # (bf_auto.py:43-49); here the fold computes only the board records it looks at.  NOT the headline workload
         # (that one is the per-frame hot path on every frame); same game record required.

@@ -251,6 +251,7 @@ int k_cnn_bf16_fc1(ck_ctx* ctx, const uint16_t* q4, int np, float* h1);
 // CK_CNN_F16Q8 (k_cnn_q8.hip): the same two fused kernels with f32 maps in and out (drop-ins for the split-precision pair of k_cnn.hip)
 int k_cnn_q8_pack(ck_ctx* ctx, const float* k1, const float* k2, const float* k3, const float* k4);
 int k_cnn_q8_conv12(ck_ctx* ctx, const uint8_t* gob, int np, float* p2, int* overflow);
+int k_cnn_q8_conv34(ck_ctx* ctx, const float* p2, int np, float* p4, int* overflow);
 int k_mog2_apply(ck_ctx* ctx, Mog2State& st, const uint8_t* d_img, double lr, uint8_t* d_fg);
 int k_mog2_run(ck_ctx* ctx, Mog2State& st, const uint8_t* d_gobans, int n, const double* learning_rates,
                int32_t* d_fgcount, uint8_t* d_last_fg, int skip_row, int skip_col);

@@ -1813,7 +1813,10 @@ int k_cnn_predict(ck_ctx* ctx, const uint8_t* d_goban, int nframes, float* d_y, 
                                (const float*)W.c2b.p, p2);
         }
         float* a3 = a1;
-        if (h2 && H2_FUSE34) {
+        if (q8) {
+            TimeScope ts(ctx, "cnn_conv4");
+            CK_TRY(k_cnn_q8_conv34(ctx, p2, np, p4, d_nonfinite));
+        } else if (h2 && H2_FUSE34) {
             TimeScope ts(ctx, "cnn_conv4");
             // conv3 + conv4 of a patch in one workgroup; pooled 6x6x90 written directly
             hipLaunchKernelGGL(conv34_h2_kernel, dim3(np), dim3(64 * 2 * (6 / H2C34_RN)), (size_t)lds_pad_conv34(), ctx->stream, (const float*)p2, (const uint16_t*)W.c3w_h2.p,

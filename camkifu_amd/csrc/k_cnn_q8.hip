@@ -22,12 +22,31 @@
 // A value beyond the e4m3 range (|x| >= 1792 with the block scale 4; the conversion then gives NaN) raises the same flag
 // as an fp16 overflow in k_cnn.hip and the batch is recomputed by the f32 chain (ck_api.hip: cnn_finish).
 #include <algorithm>
+#include <map>
+#include <type_traits>
+#include <utility>
 
 #include "ck_common.h"
 
 #ifndef Q8_C2_D
 #define Q8_C2_D 4            // conv2: depth of the fragment ring (reads in flight + the one in use)
 #endif
+#ifndef Q8_C4_D
+#define Q8_C4_D 3            // conv4: depth of the fragment ring
+#endif
+#ifndef Q8_C4_PF
+#define Q8_C4_PF 1           // conv4: sweeps the weight fragments run ahead
+#endif
+#ifndef Q8_C3_D
+#define Q8_C3_D 3            // conv3: depth of the fragment ring
+#endif
+#ifndef Q8_C34_WAVES
+#define Q8_C34_WAVES 4       // 128 registers, four waves per SIMD: two workgroups of six waves fit a CU however their waves fall on its SIMDs
+#endif                       // (at 168 registers, three per SIMD, the second workgroup of a CU did not start: ONE was resident, measured).  The
+                             // tile is dynamic LDS because the compiler, seeing 75 KB, settles for three waves per SIMD whatever it is asked.
+#ifndef Q8_PRIO
+#define Q8_PRIO 1            // wave priority 3 outside the k-loops (staging, conv1, relayout, epilogue): these short phases of loads, LDS traffic
+#endif                       // and vector arithmetic otherwise wait behind the other workgroup's matrix instructions for every issue slot
 #ifndef Q8_DBG_TIME
 #define Q8_DBG_TIME 0        // profiling aid: phase times per workgroup (thread 0, 100 MHz wall clock) summed into g_q8_prof
 #endif
@@ -36,8 +55,21 @@ namespace {
 
 #if Q8_DBG_TIME
 __device__ unsigned long long g_q8_prof[16];
+constexpr int Q8_LOG_CAP = 1 << 16;
+__device__ unsigned long long g_q8_log[2][3 * Q8_LOG_CAP];           // per kernel and workgroup: CU key, first and last stamp of thread 0
+__device__ __forceinline__ void q8_log(int which, unsigned long long t_born)
+{
+    if (threadIdx.x == 0 && blockIdx.x < Q8_LOG_CAP) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_q8_log[which][3 * blockIdx.x] = 1ull | ((unsigned long long)((xcc & 0xFu) << 8 | ((hwid >> 8) & 0xFFu)) << 8);
+        g_q8_log[which][3 * blockIdx.x + 1] = t_born;
+        g_q8_log[which][3 * blockIdx.x + 2] = wall_clock64();
+    }
+}
 #define Q8_STAMP(K) do { if (threadIdx.x == 0) { const unsigned long long now__ = wall_clock64(); atomicAdd(&g_q8_prof[K], now__ - t_prev__); t_prev__ = now__; } } while (0)
-#define Q8_STAMP_BEGIN unsigned long long t_prev__ = wall_clock64()
+#define Q8_STAMP_BEGIN unsigned long long t_prev__ = wall_clock64(); const unsigned long long t_born__ = t_prev__
 #else
 #define Q8_STAMP(K) do { } while (0)
 #define Q8_STAMP_BEGIN do { } while (0)
@@ -86,6 +118,13 @@ __device__ __forceinline__ Split4 split4(float v0, float v1, float v2, float v3)
 __device__ __forceinline__ int scale_act(int kq) { return (kq & 1) ? 127 + Q8_SA - 11 : 127 + Q8_SA; }
 __device__ __forceinline__ int scale_wgt(int kq) { return (kq & 1) ? 127 + Q8_SW : 127 + Q8_SW - 11; }
 
+// straight-line expansion of a loop body over 0 .. N - 1 with the index a compile-time constant (a `#pragma unroll` nest of a
+// few hundred steps runs into the unroller's budget, silently, and the register arrays indexed by it go to scratch)
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 __device__ __forceinline__ i32x8 pair8(const uint4& a, const uint4& b)
 {
     return i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w};
@@ -122,6 +161,7 @@ __device__ __forceinline__ void conv12_q8_body(
     const int frame = patch / 100, reg = patch % 100;
     const int px0 = region_origin(reg % 10);
     Q8_STAMP_BEGIN;
+    if (Q8_PRIO) __builtin_amdgcn_s_setprio(3);
     // the PROWS x 40 pixels of the item: a thread fetches 12 bytes (4 pixels) and turns them into 32 bytes of halves (byte b
     // becomes the half 0x6400 | b = 1024 + b by one v_perm_b32 per two values, minus 1024 by one packed subtraction)
     if (tid < PROWS * 10) {
@@ -221,6 +261,7 @@ __device__ __forceinline__ void conv12_q8_body(
     Q8_STAMP(1);                                           // wave 0's conv1 tiles
     __syncthreads();
     Q8_STAMP(2);                                           // ... the other waves'
+    if (Q8_PRIO) __builtin_amdgcn_s_setprio(0);
 
     // ---- conv2: wave = (channel tile n, 16-column strip s), T output rows.  Eight sweeps over the strip's ROWS input rows:
     // M0 M1 X01 M2 M3 X23 M4 X4 (M j: main term of tap column j; X: cross terms of a pair of columns).  The five weight
@@ -293,6 +334,7 @@ __device__ __forceinline__ void conv12_q8_body(
         }
     }
     Q8_STAMP(3);                                           // wave 0's k-loop
+    if (Q8_PRIO) __builtin_amdgcn_s_setprio(3);
 
     // ---- 2x2 max-pool in the lane (bias in the sums already; max commutes with the relu), x 2^-8, f32 out
     float* o = out + (size_t)patch * 256 * 32 + 16 * n + l15;
@@ -311,6 +353,7 @@ __device__ __forceinline__ void conv12_q8_body(
     Q8_STAMP(4);                                           // epilogue issued
 #if Q8_DBG_TIME
     if (threadIdx.x == 0) atomicAdd(&g_q8_prof[7], 1ull);
+    q8_log(0, t_born__);
 #endif
 }
 
@@ -325,6 +368,263 @@ __global__ __launch_bounds__(256, 2) void conv12_q8_kernel(
     const int patch = blockIdx.x / 3, third = blockIdx.x % 3;
     if (third < 2) conv12_q8_body<12>(thi, tq, pix, patch, 12 * third, goban, w1, b1, w2m, w2x, b2, out, overflow);
     else conv12_q8_body<8>(thi, tq, pix, patch, 24, goban, w1, b1, w2m, w2x, b2, out, overflow);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv3 + conv4 of one patch per workgroup of six waves.
+//   in   : [patch][16 * 16][32] f32 (conv12's pooled output)      out : [patch][6 * 6][90] f32
+//   w3m  : the c3w_h2 pack [channel tile 6][tap 9][plane][lane][8]          w3x : e4m3 [channel tile 6][kernel row 3][pair 2][lane][32 B]
+//   w4m  : the c4w_h2 pack [channel tile 6][step 27 = tap * 3 + cc][plane][lane][8]      w4x : e4m3 [channel tile 6][pair 14 of steps][lane][32 B]
+// conv3 (wave = channel tile, D = W x P on row tiles, two passes of seven rows, as conv34_bf16_kernel): sweeps M0 M1 X01 M2 X2
+// over the nine input rows of a pass; a lane ends up with four consecutive channels of a pixel -> split, into conv4's tile.
+// conv4 (wave = (row of three pooling tiles, three channel tiles), D = P x W, pool in the lane): per pair of k-steps two main
+// sweeps and one cross sweep over the wave's tiles.
+// LDS (bytes): conv4's tile [14][14][96 channels] in two planes of 192 bytes per pixel (hi at 0, q at 37 632), chunk (cc, kq) of
+// the pixel in row y at slot 4 cc + (kq ^ 2 (y & 1)).  conv3's input (a hi plane [256 px][64] and a q plane [256 px][64],
+// swizzled by swz32) lies where rows 0 .. 6 of the two planes will be (16 384 < 7 x 2 688): the first pass's rows 7 .. 13 are
+// stored at once, rows 0 .. 6 after a barrier.  75 264 B: two workgroups per CU.
+constexpr int C34_PS = 192, C34_RS = 14 * 192, C34_PLANE = 14 * C34_RS;      // bytes
+
+// conv4's sweeps: k = 3 u + {0, 1, 2} = M(2u), M(2u + 1), X(u); the last pair has one step: M(26), X(13)
+constexpr int C4_NSW = 27 + 14;
+constexpr int c4_kind(int k) { return k % 3 == 2 || k == C4_NSW - 1 ? 1 : 0; }
+constexpr int c4_step(int k) { return 2 * (k / 3) + (k % 3 == 1 ? 1 : 0); }
+
+__device__ __forceinline__ int c34_row_base(int y, int plane) { return plane * C34_PLANE + y * C34_RS; }
+
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVES, Q8_C34_WAVES))) void conv34_q8_kernel(
+    const float* __restrict__ in, const uint16_t* __restrict__ w3m, const uint8_t* __restrict__ w3x, const float* __restrict__ b3,
+    const uint16_t* __restrict__ w4m, const uint8_t* __restrict__ w4x, const float* __restrict__ b4,
+    float* __restrict__ out, int* __restrict__ overflow)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // 2 * C34_PLANE bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kq = lane >> 4;
+    const int patch = blockIdx.x;
+    Q8_STAMP_BEGIN;
+    const int s_act = scale_act(kq), s_wgt = scale_wgt(kq);
+    if (Q8_PRIO) __builtin_amdgcn_s_setprio(3);
+
+    {   // stage: four consecutive channels of a pixel per step -> hi plane at 0, q plane at C34_PLANE.  All six loads of a thread
+        // first (left as a loop the compiler keeps one in flight: 3.9 us per workgroup, measured)
+        const float4* g = reinterpret_cast<const float4*>(in + (size_t)patch * 256 * 32);
+        float4 v[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) v[k] = tid + 384 * k < 2048 ? g[tid + 384 * k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        __builtin_amdgcn_sched_barrier(0);
+        float big = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int c = tid + 384 * k;
+            big = fmaxf(big, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
+            const Split4 sp = split4(v[k].x, v[k].y, v[k].z, v[k].w);
+            const int px = c >> 3, c4 = c & 7, sw = swz32(px & 15);
+            if (c < 2048) {
+                *reinterpret_cast<uint2*>(&lds[64 * px + (((c4 >> 1) ^ sw) << 4) + 8 * (c4 & 1)]) = sp.hi;
+                *reinterpret_cast<uint32_t*>(&lds[C34_PLANE + 64 * px + (((c4 >> 2) ^ sw) << 4) + 4 * (c4 & 3)]) = sp.qh;
+                *reinterpret_cast<uint32_t*>(&lds[C34_PLANE + 64 * px + (((2 + (c4 >> 2)) ^ sw) << 4) + 4 * (c4 & 3)]) = sp.ql;
+            }
+        }
+        if (overflow && !(big <= Q8_LIMIT)) *overflow = 1;
+    }
+    __syncthreads();
+    Q8_STAMP(8);                                           // input staged
+    if (Q8_PRIO) __builtin_amdgcn_s_setprio(0);
+
+    // ---- conv3: channel tile n = wave
+    auto store_px = [&](int oy, const Split4& sp) {
+        const int n = wave;
+        const int c8 = 2 * n + (kq >> 1);                   // 16-byte chunk of the hi plane: 0 .. 11
+        const int cq = 4 * (n >> 1) + (n & 1);              // chunk of the q plane holding the hi bytes (lo bytes: + 2)
+        const int f = (oy & 1) << 1;
+        if (l15 < 14) {
+            uint8_t* p = &lds[c34_row_base(oy, 0) + l15 * C34_PS];
+            *reinterpret_cast<uint2*>(p + (((c8 & ~3) | ((c8 & 3) ^ f)) << 4) + 8 * (kq & 1)) = sp.hi;
+            uint8_t* q = &lds[c34_row_base(oy, 1) + l15 * C34_PS + 4 * kq];
+            *reinterpret_cast<uint32_t*>(q + (((cq & ~3) | ((cq & 3) ^ f)) << 4)) = sp.qh;
+            *reinterpret_cast<uint32_t*>(q + ((((cq + 2) & ~3) | (((cq + 2) & 3) ^ f)) << 4)) = sp.ql;
+        }
+    };
+    Split4 c3[7];                                          // rows 0 .. 6, split, until the input may be overwritten
+    float big3 = 0.f;
+    {
+        float4 bv;
+        {
+            const int c0 = 16 * wave + 4 * kq;              // 90 real channels: 88 .. 91 straddles the end
+            bv.x = c0 < 90 ? b3[c0] * Q8_WSCALE : 0.f; bv.y = c0 + 1 < 90 ? b3[c0 + 1] * Q8_WSCALE : 0.f;
+            bv.z = c0 + 2 < 90 ? b3[c0 + 2] * Q8_WSCALE : 0.f; bv.w = c0 + 3 < 90 ? b3[c0 + 3] * Q8_WSCALE : 0.f;
+        }
+        constexpr int NSW = 5;
+        constexpr int SW_KIND[NSW] = {0, 0, 1, 0, 1};
+        constexpr int SW_COL[NSW] = {0, 1, 0, 2, 2};
+        constexpr int SW_PAIR[NSW] = {0, 0, 0, 0, 1};
+        int ab[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = l15 + (j < 3 ? j : 2);            // (column 3 exists only as the empty half of the pair (2, -): any finite bytes)
+            ab[j] = 64 * x + ((kq ^ swz32(x)) << 4);
+        }
+#pragma unroll
+        for (int pass = 1; pass >= 0; pass--) {
+            const uint4* wm = reinterpret_cast<const uint4*>(w3m) + (size_t)wave * 9 * 2 * 64 + lane;
+            const uint4* wx = reinterpret_cast<const uint4*>(w3x) + ((size_t)wave * 6 * 64 + lane) * 2;
+            asm volatile("" : "+v"(wm), "+v"(wx));            // (an opaque copy per pass: the same loads, kept live across both otherwise)
+            f32x4 acc[7];
+#pragma unroll
+            for (int r = 0; r < 7; r++) { acc[r][0] = bv.x; acc[r][1] = bv.y; acc[r][2] = bv.z; acc[r][3] = bv.w; }
+            uint4 wb[2][3][2];
+            auto wload = [&](int k, uint4 (&dst)[3][2]) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    if (SW_KIND[k] == 0) dst[i][0] = wm[(size_t)((i * 3 + SW_COL[k]) * 2) * 64];
+                    else { dst[i][0] = wx[(size_t)((i * 2 + SW_PAIR[k]) * 64) * 2]; dst[i][1] = wx[(size_t)((i * 2 + SW_PAIR[k]) * 64) * 2 + 1]; }
+                }
+            };
+            wload(0, wb[0]);
+            constexpr int D = Q8_C3_D, ROWS = 9, NT = NSW * ROWS;
+            uint4 ar[D][2];
+            auto p_read = [&](int t, uint4 (&dst)[2]) {
+                const int k = t / ROWS, y = t % ROWS, row = 7 * pass + y;
+                if (SW_KIND[k] == 0) dst[0] = *reinterpret_cast<const uint4*>(&lds[1024 * row + ab[SW_COL[k]]]);
+                else {
+                    dst[0] = *reinterpret_cast<const uint4*>(&lds[C34_PLANE + 1024 * row + ab[SW_COL[k]]]);
+                    dst[1] = *reinterpret_cast<const uint4*>(&lds[C34_PLANE + 1024 * row + ab[SW_COL[k] + 1]]);
+                }
+            };
+#pragma unroll
+            for (int t = 0; t < D - 1; t++) p_read(t, ar[t]);
+#pragma unroll
+            for (int k = 0; k < NSW; k++) {
+#pragma unroll
+                for (int y = 0; y < ROWS; y++) {
+                    const int t = k * ROWS + y;
+                    if (t + D - 1 < NT) p_read(t + D - 1, ar[(t + D - 1) % D]);
+                    if (y == 0 && k + 1 < NSW) wload(k + 1, wb[(k + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        const int r = y - i;
+                        if (r >= 0 && r < 7) {
+                            if (SW_KIND[k] == 0)
+                                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, wb[k & 1][i][0]), __builtin_bit_cast(h8, ar[t % D][0]), acc[r], 0, 0, 0);
+                            else
+                                acc[r] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pair8(wb[k & 1][i][0], wb[k & 1][i][1]), pair8(ar[t % D][0], ar[t % D][1]),
+                                                                                          acc[r], 0, 0, 0, s_wgt, 0, s_act);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 7; r++) {
+                const float v0 = fmaxf(acc[r][0], 0.f) * (1.f / Q8_WSCALE), v1 = fmaxf(acc[r][1], 0.f) * (1.f / Q8_WSCALE);
+                const float v2 = fmaxf(acc[r][2], 0.f) * (1.f / Q8_WSCALE), v3 = fmaxf(acc[r][3], 0.f) * (1.f / Q8_WSCALE);
+                if (l15 < 14 && !(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)) <= Q8_LIMIT)) big3 = 1e30f;
+                const Split4 sp = split4(v0, v1, v2, v3);
+                if (pass == 1) store_px(7 + r, sp);
+                else c3[r] = sp;
+            }
+        }
+    }
+    Q8_STAMP(9);                                           // wave 0's conv3
+    if (Q8_PRIO) __builtin_amdgcn_s_setprio(3);
+    __syncthreads();                                       // every wave is done with conv3's input, which rows 0 .. 6 overlay
+#pragma unroll
+    for (int oy = 0; oy < 7; oy++) store_px(oy, c3[oy]);
+    if (overflow && big3 != 0.f) *overflow = 1;
+    __syncthreads();
+    Q8_STAMP(10);                                          // barrier, rows 0 .. 6 stored, barrier
+    if (Q8_PRIO) __builtin_amdgcn_s_setprio(0);
+
+    // ---- conv4: wave = (mh, nh): the pooling tiles of tile row mh (3 of the 9), channel tiles 3 nh .. 3 nh + 2: a fragment
+    // read feeds three MFMAs (with two channel tiles per wave the LDS, at 1 650 reads of 1 KB per patch, took as long as the
+    // matrix pipe)
+    constexpr int MT = 3, NN = 3;
+    const int mh = wave >> 1, nh = wave & 1;
+    f32x4 acc[MT][NN];
+#pragma unroll
+    for (int n = 0; n < NN; n++) {
+        const int co = 16 * (NN * nh + n) + l15;
+        const float bb = co < 90 ? b4[co] * Q8_WSCALE : 0.f;
+#pragma unroll
+        for (int t = 0; t < MT; t++) { acc[t][n][0] = bb; acc[t][n][1] = bb; acc[t][n][2] = bb; acc[t][n][3] = bb; }
+    }
+    const int q = l15 >> 2, sub = l15 & 3, dy = 2 * (q >> 1) + (sub >> 1), dx = 2 * (q & 1) + (sub & 1);
+    // the lane's pixel inside pooling tile (mh, tl), for taps in rows of either parity (the parity flips bit 1 of the slot);
+    // everything else of a fragment's address (tile column, tap, channel block, plane) is an immediate offset of the read
+    int ta[2];
+    {
+        const int base = (4 * mh + dy) * C34_RS + dx * C34_PS;
+        ta[0] = base + ((kq ^ ((dy & 1) << 1)) << 4);
+        ta[1] = base + ((kq ^ (((dy + 1) & 1) << 1)) << 4);
+    }
+    const uint4* wm4 = reinterpret_cast<const uint4*>(w4m) + (size_t)(NN * nh) * 27 * 2 * 64 + lane;
+    const uint4* wx4 = reinterpret_cast<const uint4*>(w4x) + ((size_t)(NN * nh) * 14 * 64 + lane) * 2;
+    // sweeps: per pair u of k-steps: M(2u), M(2u + 1), X(u); the last pair has one step
+    constexpr int PF = Q8_C4_PF, D4 = Q8_C4_D, NT4 = C4_NSW * MT;
+    uint4 wb4[PF + 1][NN][2], ar4[D4][2];
+    auto wload4 = [&](auto kc, uint4 (&dst)[NN][2]) {
+        constexpr int k = decltype(kc)::value;
+#pragma unroll
+        for (int n = 0; n < NN; n++) {
+            if constexpr (c4_kind(k) == 0) dst[n][0] = wm4[((size_t)n * 27 + c4_step(k)) * 2 * 64];
+            else { dst[n][0] = wx4[((size_t)n * 14 + k / 3) * 64 * 2]; dst[n][1] = wx4[((size_t)n * 14 + k / 3) * 64 * 2 + 1]; }
+        }
+    };
+    auto unit_addr = [&](int step, int tl, int plane) {
+        const int tap = step / 3, cc = step % 3, i = tap / 3, j = tap % 3;
+        return ta[i & 1] + (i * C34_RS + (4 * tl + j) * C34_PS + 64 * cc + plane * C34_PLANE);
+    };
+    auto a_read4 = [&](auto uc, uint4 (&dst)[2]) {
+        constexpr int u = decltype(uc)::value, k = u / MT, tl = u % MT;
+        if constexpr (c4_kind(k) == 0) dst[0] = *reinterpret_cast<const uint4*>(&lds[unit_addr(c4_step(k), tl, 0)]);
+        else {
+            constexpr int s0 = 2 * (k / 3), s1 = s0 + 1 < 27 ? s0 + 1 : s0;       // (the empty half of the last pair: any finite bytes)
+            dst[0] = *reinterpret_cast<const uint4*>(&lds[unit_addr(s0, tl, 1)]);
+            dst[1] = *reinterpret_cast<const uint4*>(&lds[unit_addr(s1, tl, 1)]);
+        }
+    };
+    static_for<PF>([&](auto kc) { wload4(kc, wb4[decltype(kc)::value]); });
+    static_for<D4 - 1>([&](auto uc) { a_read4(uc, ar4[decltype(uc)::value]); });
+    static_for<NT4>([&](auto uc) {
+        constexpr int u = decltype(uc)::value, k = u / MT, tl = u % MT;
+        if constexpr (u + D4 - 1 < NT4) a_read4(std::integral_constant<int, u + D4 - 1>{}, ar4[(u + D4 - 1) % D4]);
+        if constexpr (tl == 0 && k + PF < C4_NSW) wload4(std::integral_constant<int, k + PF>{}, wb4[(k + PF) % (PF + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NN; n++) {
+            if constexpr (c4_kind(k) == 0)
+                acc[tl][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ar4[u % D4][0]), __builtin_bit_cast(h8, wb4[k % (PF + 1)][n][0]), acc[tl][n], 0, 0, 0);
+            else
+                acc[tl][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pair8(ar4[u % D4][0], ar4[u % D4][1]), pair8(wb4[k % (PF + 1)][n][0], wb4[k % (PF + 1)][n][1]),
+                                                                               acc[tl][n], 0, 0, 0, s_act, 0, s_wgt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    Q8_STAMP(11);                                          // wave 0's conv4 loop
+    if (Q8_PRIO) __builtin_amdgcn_s_setprio(3);
+    float* o = out + (size_t)patch * 3240;
+    float big4 = 0.f;
+#pragma unroll
+    for (int n = 0; n < NN; n++) {
+        const int co = 16 * (NN * nh + n) + l15;
+#pragma unroll
+        for (int tl = 0; tl < MT; tl++) {
+            float v = fmaxf(fmaxf(acc[tl][n][0], acc[tl][n][1]), fmaxf(acc[tl][n][2], acc[tl][n][3]));
+            v = fmaxf(v, 0.f) * (1.f / Q8_WSCALE);
+            const int py = 2 * mh + (kq >> 1), px = 2 * tl + (kq & 1);
+            if (co < 90) {
+                if (!(v <= 65000.f)) big4 = 1e30f;
+                o[(py * 6 + px) * 90 + co] = v;
+            }
+        }
+    }
+    if (overflow && big4 != 0.f) *overflow = 1;
+    Q8_STAMP(12);
+#if Q8_DBG_TIME
+    if (threadIdx.x == 0) atomicAdd(&g_q8_prof[15], 1ull);
+    q8_log(1, t_born__);
+#endif
 }
 
 }  // namespace
@@ -407,10 +707,86 @@ int k_cnn_q8_pack(ck_ctx* ctx, const float* k1, const float* k2, const float* k3
         }
         CK_TRY(pack_cross(ctx, k2, 5, 5, 32, 32, 2, pr, W.c2x_q8, &wmax));
     }
-    (void)k3; (void)k4;
+    {   // conv3: per kernel row the column pairs (0, 1), (2, -)
+        std::vector<std::pair<Unit, Unit>> pr;
+        for (int i = 0; i < 3; i++) {
+            pr.push_back({Unit{i, 0, 0}, Unit{i, 1, 0}});
+            pr.push_back({Unit{i, 2, 0}, Unit{-1, 0, 0}});
+        }
+        CK_TRY(pack_cross(ctx, k3, 3, 3, 32, 90, 6, pr, W.c3x_q8, &wmax));
+    }
+    {   // conv4: pairs of consecutive k-steps (step = tap * 3 + channel block), the 27th alone
+        std::vector<std::pair<Unit, Unit>> pr;
+        for (int u = 0; u < 14; u++) {
+            const int s0 = 2 * u, s1 = 2 * u + 1;
+            pr.push_back({Unit{s0 / 9, (s0 / 3) % 3, s0 % 3}, s1 < 27 ? Unit{s1 / 9, (s1 / 3) % 3, s1 % 3} : Unit{-1, 0, 0}});
+        }
+        CK_TRY(pack_cross(ctx, k4, 3, 3, 90, 90, 6, pr, W.c4x_q8, &wmax));
+    }
     // weights beyond the e4m3 range of their block scale: the mode is not available with them (k_cnn_predict then runs the
     // three-MFMA kernels instead)
     W.q8_ok = wmax <= 448.f * (float)(1 << Q8_SW);
+    return CK_OK;
+}
+
+#if Q8_DBG_TIME
+// workgroups resident per CU over the kernel's duration, from the per-workgroup log
+static void q8_residency(const char* name, int which, int nwg)
+{
+    const int n = std::min(nwg, (int)Q8_LOG_CAP);
+    std::vector<unsigned long long> lg((size_t)3 * Q8_LOG_CAP);
+    (void)hipMemcpyFromSymbol(lg.data(), HIP_SYMBOL(g_q8_log), lg.size() * 8, (size_t)which * lg.size() * 8);
+    std::map<unsigned, std::vector<std::pair<unsigned long long, int>>> ev;      // CU key -> (time, +1 / -1)
+    unsigned long long lo = ~0ull, hi = 0;
+    double life = 0;
+    int cnt = 0;
+    for (int i = 0; i < n; i++) {
+        if (!lg[3 * i]) continue;
+        auto& e = ev[(unsigned)(lg[3 * i] >> 8)];
+        e.push_back({lg[3 * i + 1], +1}); e.push_back({lg[3 * i + 2], -1});
+        life += (double)(lg[3 * i + 2] - lg[3 * i + 1]);
+        lo = std::min(lo, lg[3 * i + 1]); hi = std::max(hi, lg[3 * i + 2]);
+        cnt++;
+    }
+    // time a CU spends with 0, 1, 2, 3+ workgroups of this kernel (between the first start and the last end on that CU)
+    double at[4] = {0, 0, 0, 0}, span = 0;
+    for (auto& cu : ev) {
+        std::sort(cu.second.begin(), cu.second.end());
+        int live = 0;
+        for (size_t k = 0; k + 1 < cu.second.size(); k++) {
+            live += cu.second[k].second;
+            at[std::min(live, 3)] += (double)(cu.second[k + 1].first - cu.second[k].first);
+        }
+        span += (double)(cu.second.back().first - cu.second.front().first);
+    }
+    if (cnt) fprintf(stderr, "[q8 residency] %s: %d workgroups on %zu CUs, lifetime %.2f us, %.2f resident per CU over %.0f us; share of a CU's time with 0 / 1 / 2 / 3+ resident: %.2f %.2f %.2f %.2f\n",
+                     name, cnt, ev.size(), 0.01 * life / cnt, life / ((double)(hi - lo) * ev.size()), 0.01 * (double)(hi - lo),
+                     at[0] / span, at[1] / span, at[2] / span, at[3] / span);
+    std::fill(lg.begin(), lg.end(), 0ull);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_q8_log), lg.data(), lg.size() * 8, (size_t)which * lg.size() * 8);
+}
+#endif
+
+// conv3 + conv4 of np patches: pooled conv2 output in, pooled conv4 output (p4, f32 [patch][36][90]) out
+int k_cnn_q8_conv34(ck_ctx* ctx, const float* p2, int np, float* p4, int* overflow)
+{
+    const CnnWeights& W = ctx->cnn;
+    hipLaunchKernelGGL(conv34_q8_kernel, dim3(np), dim3(384), (size_t)(2 * C34_PLANE), ctx->stream, p2, (const uint16_t*)W.c3w_h2.p, (const uint8_t*)W.c3x_q8.p,
+                       (const float*)W.c3b.p, (const uint16_t*)W.c4w_h2.p, (const uint8_t*)W.c4x_q8.p, (const float*)W.c4b.p, p4, overflow);
+    CK_HIP(ctx, hipGetLastError());
+#if Q8_DBG_TIME
+    {
+        unsigned long long hp[16];
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_q8_prof), sizeof hp);
+        if (hp[15])
+            fprintf(stderr, "[q8 phases, us per workgroup] conv34 (%llu): stage %.2f  conv3 %.2f  relayout %.2f  conv4 %.2f  epilogue %.2f\n",
+                    hp[15], hp[8] * 0.01 / hp[15], hp[9] * 0.01 / hp[15], hp[10] * 0.01 / hp[15], hp[11] * 0.01 / hp[15], hp[12] * 0.01 / hp[15]);
+        memset(hp, 0, sizeof hp);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_q8_prof), hp, sizeof hp);
+        q8_residency("conv34", 1, np);
+    }
+#endif
     return CK_OK;
 }
 
@@ -431,6 +807,7 @@ int k_cnn_q8_conv12(ck_ctx* ctx, const uint8_t* gob, int np, float* p2, int* ove
                     hp[7], hp[0] * 0.01 / hp[7], hp[1] * 0.01 / hp[7], hp[2] * 0.01 / hp[7], hp[3] * 0.01 / hp[7], hp[4] * 0.01 / hp[7]);
         memset(hp, 0, sizeof hp);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_q8_prof), hp, sizeof hp);
+        q8_residency("conv12", 0, 3 * np);
     }
 #endif
     return CK_OK;
