@@ -138,7 +138,7 @@ __device__ __forceinline__ i32x8 pair8(const uint4& a, const uint4& b)
 //           conv12_bf16_kernel (fragment f = 4 s + kq = kernel row f / 3, tap pair f % 3; e = (tap, channel)); the u8 pixels
 //           are exact halves: two MFMAs per product
 //   w2m   : conv2 main term: the c2w_h2 pack [channel tile 2][tap 25][plane][lane][8] (plane 0 = fp16(w x 2^8))
-//   w2x   : conv2 cross terms [channel tile 2][kernel row 5][column pair 3][lane][32 bytes]: e4m3, bytes 0..15 the first
+//   w2x   : conv2 cross terms [channel tile 2][kernel row 5 x column pair 3, then the 3 vertical pairs of column 4][lane][32 bytes]: e4m3, bytes 0..15 the first
 //           column of the pair, 16..31 the second (zero for the pair (4, -)); lane group 0 / 1: w_lo of input channels
 //           0..15 / 16..31, group 2 / 3: w_hi of the same
 //   out   : [patch][16 * 16 pooled pixels][32] f32 (as conv_mfma16_h2_kernel writes it)
@@ -274,19 +274,22 @@ __device__ __forceinline__ void conv12_q8_body(
         for (int r = 0; r < T; r++) { acc[r][0] = bb; acc[r][1] = bb; acc[r][2] = bb; acc[r][3] = bb; }
     }
     const int sa = scale_act(kq), sb = scale_wgt(kq);
-    // sweep k: kind (0 main, 1 cross), first column, pair index
+    // sweep k: kind (0 main, 1 cross terms of two columns, 2 cross terms of the last column with its taps paired VERTICALLY: the
+    // fragments of rows y and y + 1 against taps (0, 1), (2, 3), (4, -) -- three instructions per row instead of five), first
+    // column, pair index
     constexpr int NSW = 8;
-    constexpr int SW_KIND[NSW] = {0, 0, 1, 0, 0, 1, 0, 1};
+    constexpr int SW_KIND[NSW] = {0, 0, 1, 0, 0, 1, 0, 2};
     constexpr int SW_COL[NSW] = {0, 1, 0, 2, 3, 2, 4, 4};
     constexpr int SW_PAIR[NSW] = {0, 0, 0, 0, 0, 1, 0, 2};
     const uint4* wm = reinterpret_cast<const uint4*>(w2m) + (size_t)n * 25 * 2 * 64 + lane;
-    const uint4* wx = reinterpret_cast<const uint4*>(w2x) + ((size_t)n * 15 * 64 + lane) * 2;
+    const uint4* wx = reinterpret_cast<const uint4*>(w2x) + ((size_t)n * 18 * 64 + lane) * 2;
     uint4 wb[2][5][2];
     auto wload = [&](int k, uint4 (&dst)[5][2]) {
 #pragma unroll
         for (int i = 0; i < 5; i++) {
             if (SW_KIND[k] == 0) dst[i][0] = wm[(size_t)((i * 5 + SW_COL[k]) * 2) * 64];
-            else { dst[i][0] = wx[(size_t)((i * 3 + SW_PAIR[k]) * 64) * 2]; dst[i][1] = wx[(size_t)((i * 3 + SW_PAIR[k]) * 64) * 2 + 1]; }
+            else if (SW_KIND[k] == 1) { dst[i][0] = wx[(size_t)((i * 3 + SW_PAIR[k]) * 64) * 2]; dst[i][1] = wx[(size_t)((i * 3 + SW_PAIR[k]) * 64) * 2 + 1]; }
+            else if (i < 3) { dst[i][0] = wx[(size_t)((15 + i) * 64) * 2]; dst[i][1] = wx[(size_t)((15 + i) * 64) * 2 + 1]; }
         }
     };
     wload(0, wb[0]);
@@ -304,9 +307,13 @@ __device__ __forceinline__ void conv12_q8_body(
     auto a_read = [&](int t, uint4 (&dst)[2]) {
         const int k = t / ROWS, y = t % ROWS;
         if (SW_KIND[k] == 0) dst[0] = *reinterpret_cast<const uint4*>(th8 + y * (2 * C12_RS) + ab[SW_COL[k]]);
-        else {
+        else if (SW_KIND[k] == 1) {
             dst[0] = *reinterpret_cast<const uint4*>(tq + y * (2 * C12_RS) + ab[SW_COL[k]]);
             dst[1] = *reinterpret_cast<const uint4*>(tq + y * (2 * C12_RS) + ab[SW_COL[k] + 1]);
+        } else {
+            const int y1 = y + 1 < ROWS ? y + 1 : y;          // (below the last row: the empty half of (4, -), any finite bytes)
+            dst[0] = *reinterpret_cast<const uint4*>(tq + y * (2 * C12_RS) + ab[SW_COL[k]]);
+            dst[1] = *reinterpret_cast<const uint4*>(tq + y1 * (2 * C12_RS) + ab[SW_COL[k]]);
         }
     };
 #pragma unroll
@@ -321,8 +328,8 @@ __device__ __forceinline__ void conv12_q8_body(
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 5; i++) {
-                const int r = y - i;
-                if (r >= 0 && r < T) {
+                const int r = SW_KIND[k] == 2 ? y - 2 * i : y - i;      // (kind 2: instruction i covers the taps 2 i and 2 i + 1)
+                if (r >= 0 && r < T && !(SW_KIND[k] == 2 && i > 2)) {
                     if (SW_KIND[k] == 0)
                         acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ar[t % D][0]), __builtin_bit_cast(h8, wb[k & 1][i][0]), acc[r], 0, 0, 0);
                     else
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void conv12_q8_kernel(
 // ------------------------------------------------------------------------------------------------------------------
 // conv3 + conv4 of one patch per workgroup of six waves.
 //   in   : [patch][16 * 16][32] f32 (conv12's pooled output)      out : [patch][6 * 6][90] f32
-//   w3m  : the c3w_h2 pack [channel tile 6][tap 9][plane][lane][8]          w3x : e4m3 [channel tile 6][kernel row 3][pair 2][lane][32 B]
+//   w3m  : the c3w_h2 pack [channel tile 6][tap 9][plane][lane][8]          w3x : e4m3 [channel tile 6][kernel row 3 x pair 2, then the 2 vertical pairs of column 2][lane][32 B]
 //   w4m  : the c4w_h2 pack [channel tile 6][step 27 = tap * 3 + cc][plane][lane][8]      w4x : e4m3 [channel tile 6][pair 14 of steps][lane][32 B]
 // conv3 (wave = channel tile, D = W x P on row tiles, two passes of seven rows, as conv34_bf16_kernel): sweeps M0 M1 X01 M2 X2
 // over the nine input rows of a pass; a lane ends up with four consecutive channels of a pixel -> split, into conv4's tile.
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVE
             bv.z = c0 + 2 < 90 ? b3[c0 + 2] * Q8_WSCALE : 0.f; bv.w = c0 + 3 < 90 ? b3[c0 + 3] * Q8_WSCALE : 0.f;
         }
         constexpr int NSW = 5;
-        constexpr int SW_KIND[NSW] = {0, 0, 1, 0, 1};
+        constexpr int SW_KIND[NSW] = {0, 0, 1, 0, 2};       // (2: the last column's cross terms with the taps paired vertically, as in conv2)
         constexpr int SW_COL[NSW] = {0, 1, 0, 2, 2};
         constexpr int SW_PAIR[NSW] = {0, 0, 0, 0, 1};
         int ab[4];
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVE
 #pragma unroll
         for (int pass = 1; pass >= 0; pass--) {
             const uint4* wm = reinterpret_cast<const uint4*>(w3m) + (size_t)wave * 9 * 2 * 64 + lane;
-            const uint4* wx = reinterpret_cast<const uint4*>(w3x) + ((size_t)wave * 6 * 64 + lane) * 2;
+            const uint4* wx = reinterpret_cast<const uint4*>(w3x) + ((size_t)wave * 8 * 64 + lane) * 2;
             asm volatile("" : "+v"(wm), "+v"(wx));            // (an opaque copy per pass: the same loads, kept live across both otherwise)
             f32x4 acc[7];
 #pragma unroll
@@ -477,7 +484,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVE
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
                     if (SW_KIND[k] == 0) dst[i][0] = wm[(size_t)((i * 3 + SW_COL[k]) * 2) * 64];
-                    else { dst[i][0] = wx[(size_t)((i * 2 + SW_PAIR[k]) * 64) * 2]; dst[i][1] = wx[(size_t)((i * 2 + SW_PAIR[k]) * 64) * 2 + 1]; }
+                    else if (SW_KIND[k] == 1) { dst[i][0] = wx[(size_t)((i * 2 + SW_PAIR[k]) * 64) * 2]; dst[i][1] = wx[(size_t)((i * 2 + SW_PAIR[k]) * 64) * 2 + 1]; }
+                    else if (i < 2) { dst[i][0] = wx[(size_t)((6 + i) * 64) * 2]; dst[i][1] = wx[(size_t)((6 + i) * 64) * 2 + 1]; }
                 }
             };
             wload(0, wb[0]);
@@ -486,9 +494,13 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVE
             auto p_read = [&](int t, uint4 (&dst)[2]) {
                 const int k = t / ROWS, y = t % ROWS, row = 7 * pass + y;
                 if (SW_KIND[k] == 0) dst[0] = *reinterpret_cast<const uint4*>(&lds[1024 * row + ab[SW_COL[k]]]);
-                else {
+                else if (SW_KIND[k] == 1) {
                     dst[0] = *reinterpret_cast<const uint4*>(&lds[C34_PLANE + 1024 * row + ab[SW_COL[k]]]);
                     dst[1] = *reinterpret_cast<const uint4*>(&lds[C34_PLANE + 1024 * row + ab[SW_COL[k] + 1]]);
+                } else {
+                    const int row1 = y + 1 < ROWS ? row + 1 : row;
+                    dst[0] = *reinterpret_cast<const uint4*>(&lds[C34_PLANE + 1024 * row + ab[SW_COL[k]]]);
+                    dst[1] = *reinterpret_cast<const uint4*>(&lds[C34_PLANE + 1024 * row1 + ab[SW_COL[k]]]);
                 }
             };
 #pragma unroll
@@ -503,8 +515,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVE
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 3; i++) {
-                        const int r = y - i;
-                        if (r >= 0 && r < 7) {
+                        const int r = SW_KIND[k] == 2 ? y - 2 * i : y - i;
+                        if (r >= 0 && r < 7 && !(SW_KIND[k] == 2 && i > 1)) {
                             if (SW_KIND[k] == 0)
                                 acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, wb[k & 1][i][0]), __builtin_bit_cast(h8, ar[t % D][0]), acc[r], 0, 0, 0);
                             else
@@ -703,16 +715,21 @@ int k_cnn_q8_pack(ck_ctx* ctx, const float* k1, const float* k2, const float* k3
         for (int i = 0; i < 5; i++) {
             pr.push_back({Unit{i, 0, 0}, Unit{i, 1, 0}});
             pr.push_back({Unit{i, 2, 0}, Unit{i, 3, 0}});
-            pr.push_back({Unit{i, 4, 0}, Unit{-1, 0, 0}});
+            pr.push_back({Unit{i, 4, 0}, Unit{-1, 0, 0}});       // (not used since the last column's taps are paired vertically:)
         }
+        pr.push_back({Unit{0, 4, 0}, Unit{1, 4, 0}});
+        pr.push_back({Unit{2, 4, 0}, Unit{3, 4, 0}});
+        pr.push_back({Unit{4, 4, 0}, Unit{-1, 0, 0}});
         CK_TRY(pack_cross(ctx, k2, 5, 5, 32, 32, 2, pr, W.c2x_q8, &wmax));
     }
     {   // conv3: per kernel row the column pairs (0, 1), (2, -)
         std::vector<std::pair<Unit, Unit>> pr;
         for (int i = 0; i < 3; i++) {
             pr.push_back({Unit{i, 0, 0}, Unit{i, 1, 0}});
-            pr.push_back({Unit{i, 2, 0}, Unit{-1, 0, 0}});
+            pr.push_back({Unit{i, 2, 0}, Unit{-1, 0, 0}});       // (not used: the vertical pairs below)
         }
+        pr.push_back({Unit{0, 2, 0}, Unit{1, 2, 0}});
+        pr.push_back({Unit{2, 2, 0}, Unit{-1, 0, 0}});
         CK_TRY(pack_cross(ctx, k3, 3, 3, 32, 90, 6, pr, W.c3x_q8, &wmax));
     }
     {   // conv4: pairs of consecutive k-steps (step = tap * 3 + channel block), the 27th alone
