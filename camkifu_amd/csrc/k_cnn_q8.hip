@@ -40,6 +40,18 @@
 #ifndef Q8_C3_D
 #define Q8_C3_D 3            // conv3: depth of the fragment ring
 #endif
+#ifndef Q8_C3_PF
+#define Q8_C3_PF 2           // conv3, four-wave form: sweeps the weight fragments run ahead
+#endif
+#ifndef Q8_C4W4_PF
+#define Q8_C4W4_PF 3         // conv4, four-wave form: the same (a main sweep of five tiles is 240 pipe cycles)
+#endif
+#ifndef Q8_C4W4_D
+#define Q8_C4W4_D 6          // conv4, four-wave form: depth of the fragment ring
+#endif
+#ifndef Q8_C34_NW
+#define Q8_C34_NW 4          // waves per workgroup of the conv3 + conv4 kernel (6: the first form, kept for A/B)
+#endif
 #ifndef Q8_C34_WAVES
 #define Q8_C34_WAVES 4       // 128 registers, four waves per SIMD: two workgroups of six waves fit a CU however their waves fall on its SIMDs
 #endif                       // (at 168 registers, three per SIMD, the second workgroup of a CU did not start: ONE was resident, measured).  The
@@ -184,6 +196,13 @@ __device__ __forceinline__ void conv12_q8_body(
         for (int r = tid - (256 - 32); r < PROWS; r += 32) *reinterpret_cast<uint4*>(&pix[r * C12_PIX_RS + 160]) = make_uint4(0, 0, 0, 0);
     }
 
+    // conv2's first sweep of weight fragments is requested here, a whole conv1 ahead of its use (at the k-loop's start it cost an
+    // exposed L2 round trip per workgroup)
+    const int n = wave & 1, s = wave >> 1;
+    const uint4* wm = reinterpret_cast<const uint4*>(w2m) + (size_t)n * 25 * 2 * 64 + lane;
+    uint4 wb[2][5][2];
+#pragma unroll
+    for (int i = 0; i < 5; i++) wb[0][i][0] = wm[(size_t)((i * 5 + 0) * 2) * 64];
     // conv1's weights (A operand), both planes, and its bias x 2^8 while the pixels land
     h8 wa[2][4][2];
 #pragma unroll
@@ -266,7 +285,6 @@ __device__ __forceinline__ void conv12_q8_body(
     // ---- conv2: wave = (channel tile n, 16-column strip s), T output rows.  Eight sweeps over the strip's ROWS input rows:
     // M0 M1 X01 M2 M3 X23 M4 X4 (M j: main term of tap column j; X: cross terms of a pair of columns).  The five weight
     // fragments of a sweep (taps (0..4, j)) are in registers, the next sweep's in flight.
-    const int n = wave & 1, s = wave >> 1;
     f32x4 acc[T];
     {
         const float bb = b2[16 * n + l15] * Q8_WSCALE;
@@ -281,9 +299,7 @@ __device__ __forceinline__ void conv12_q8_body(
     constexpr int SW_KIND[NSW] = {0, 0, 1, 0, 0, 1, 0, 2};
     constexpr int SW_COL[NSW] = {0, 1, 0, 2, 3, 2, 4, 4};
     constexpr int SW_PAIR[NSW] = {0, 0, 0, 0, 0, 1, 0, 2};
-    const uint4* wm = reinterpret_cast<const uint4*>(w2m) + (size_t)n * 25 * 2 * 64 + lane;
     const uint4* wx = reinterpret_cast<const uint4*>(w2x) + ((size_t)n * 18 * 64 + lane) * 2;
-    uint4 wb[2][5][2];
     auto wload = [&](int k, uint4 (&dst)[5][2]) {
 #pragma unroll
         for (int i = 0; i < 5; i++) {
@@ -292,7 +308,7 @@ __device__ __forceinline__ void conv12_q8_body(
             else if (i < 3) { dst[i][0] = wx[(size_t)((15 + i) * 64) * 2]; dst[i][1] = wx[(size_t)((15 + i) * 64) * 2 + 1]; }
         }
     };
-    wload(0, wb[0]);
+    static_assert(SW_KIND[0] == 0 && SW_COL[0] == 0, "the first sweep's weights are loaded before conv1");
     // byte address of the lane's 16-byte chunk in a plane row (both planes: 64 bytes per pixel, chunk kq ^ swz32(x)) per column
     int ab[6];
 #pragma unroll
@@ -399,30 +415,38 @@ constexpr int c4_step(int k) { return 2 * (k / 3) + (k % 3 == 1 ? 1 : 0); }
 
 __device__ __forceinline__ int c34_row_base(int y, int plane) { return plane * C34_PLANE + y * C34_RS; }
 
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVES, Q8_C34_WAVES))) void conv34_q8_kernel(
-    const float* __restrict__ in, const uint16_t* __restrict__ w3m, const uint8_t* __restrict__ w3x, const float* __restrict__ b3,
+// NW waves per workgroup.  Six (round 5's first form: conv3 wave = channel tile with both passes, conv4 wave = (row of three
+// pooling tiles, three channel tiles)) fall 2-2-1-1 on a CU's four SIMDs, for both resident workgroups alike: two SIMDs carry
+// twice the work.  Four (one per SIMD and workgroup, 256 registers each): conv3 in twelve units (channel tile, pass), three per
+// wave -- (w, rows 7-13), one of the four units of tiles 4 and 5, (w, rows 0-6) --, conv4 wave = (five / four pooling tiles,
+// three channel tiles).
+template <int NW>
+__device__ __forceinline__ void conv34_q8_body(
+    uint8_t* __restrict__ lds, const float* __restrict__ in, const uint16_t* __restrict__ w3m, const uint8_t* __restrict__ w3x, const float* __restrict__ b3,
     const uint16_t* __restrict__ w4m, const uint8_t* __restrict__ w4x, const float* __restrict__ b4,
     float* __restrict__ out, int* __restrict__ overflow)
 {
 #pragma clang fp contract(off)
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // 2 * C34_PLANE bytes
+    static_assert(NW == 6 || NW == 4, "six or four waves");
+    constexpr int NTHR = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kq = lane >> 4;
     const int patch = blockIdx.x;
     Q8_STAMP_BEGIN;
     const int s_act = scale_act(kq), s_wgt = scale_wgt(kq);
     if (Q8_PRIO) __builtin_amdgcn_s_setprio(3);
 
-    {   // stage: four consecutive channels of a pixel per step -> hi plane at 0, q plane at C34_PLANE.  All six loads of a thread
+    {   // stage: four consecutive channels of a pixel per step -> hi plane at 0, q plane at C34_PLANE.  All loads of a thread
         // first (left as a loop the compiler keeps one in flight: 3.9 us per workgroup, measured)
+        constexpr int NLD = (2048 + NTHR - 1) / NTHR;
         const float4* g = reinterpret_cast<const float4*>(in + (size_t)patch * 256 * 32);
-        float4 v[6];
+        float4 v[NLD];
 #pragma unroll
-        for (int k = 0; k < 6; k++) v[k] = tid + 384 * k < 2048 ? g[tid + 384 * k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < NLD; k++) v[k] = tid + NTHR * k < 2048 ? g[tid + NTHR * k] : make_float4(0.f, 0.f, 0.f, 0.f);
         __builtin_amdgcn_sched_barrier(0);
         float big = 0.f;
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int c = tid + 384 * k;
+        for (int k = 0; k < NLD; k++) {
+            const int c = tid + NTHR * k;
             big = fmaxf(big, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
             const Split4 sp = split4(v[k].x, v[k].y, v[k].z, v[k].w);
             const int px = c >> 3, c4 = c & 7, sw = swz32(px & 15);
@@ -438,9 +462,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVE
     Q8_STAMP(8);                                           // input staged
     if (Q8_PRIO) __builtin_amdgcn_s_setprio(0);
 
-    // ---- conv3: channel tile n = wave
-    auto store_px = [&](int oy, const Split4& sp) {
-        const int n = wave;
+    // ---- conv3
+    auto store_px = [&](int n, int oy, const Split4& sp) {
         const int c8 = 2 * n + (kq >> 1);                   // 16-byte chunk of the hi plane: 0 .. 11
         const int cq = 4 * (n >> 1) + (n & 1);              // chunk of the q plane holding the hi bytes (lo bytes: + 2)
         const int f = (oy & 1) << 1;
@@ -452,75 +475,86 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVE
             *reinterpret_cast<uint32_t*>(q + ((((cq + 2) & ~3) | (((cq + 2) & 3) ^ f)) << 4)) = sp.ql;
         }
     };
-    Split4 c3[7];                                          // rows 0 .. 6, split, until the input may be overwritten
     float big3 = 0.f;
+    int ab[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int x = l15 + (j < 3 ? j : 2);                // (column 3 exists only as the empty half of the pair (2, -): any finite bytes)
+        ab[j] = 64 * x + ((kq ^ swz32(x)) << 4);
+    }
+    // The wave's units (channel tile n, output rows 7 pass .. 7 pass + 6), rows 7 .. 13 first: they lie behind conv3's input in
+    // both planes and are stored at once; rows 0 .. 6 wait, split, for the barrier.  ONE sequence of sweeps over all units: the
+    // weight fragments run WPF sweeps ahead and the fragment reads D - 1 steps ahead ACROSS the unit boundaries (unit by
+    // unit, every unit began by waiting an L2 round trip for its first weights with nothing left to overlap it).
+    constexpr int NU = NW == 4 ? 3 : 2;
+    const int nb = 4 + (wave >> 1), pb = 1 - (wave & 1);    // (four waves) the wave's middle unit: tile 4 or 5, either pass
+    int un[NU], up[NU];
+    un[0] = wave; up[0] = 1;
+    if constexpr (NW == 4) { un[1] = nb; up[1] = pb; }
+    un[NU - 1] = wave; up[NU - 1] = 0;
+    Split4 c3[NU][7];
     {
-        float4 bv;
-        {
-            const int c0 = 16 * wave + 4 * kq;              // 90 real channels: 88 .. 91 straddles the end
-            bv.x = c0 < 90 ? b3[c0] * Q8_WSCALE : 0.f; bv.y = c0 + 1 < 90 ? b3[c0 + 1] * Q8_WSCALE : 0.f;
-            bv.z = c0 + 2 < 90 ? b3[c0 + 2] * Q8_WSCALE : 0.f; bv.w = c0 + 3 < 90 ? b3[c0 + 3] * Q8_WSCALE : 0.f;
-        }
-        constexpr int NSW = 5;
+        constexpr int NSW = 5, ROWS = 9, UT = NSW * ROWS, NT = NU * UT, D = Q8_C3_D;
         constexpr int SW_KIND[NSW] = {0, 0, 1, 0, 2};       // (2: the last column's cross terms with the taps paired vertically, as in conv2)
         constexpr int SW_COL[NSW] = {0, 1, 0, 2, 2};
         constexpr int SW_PAIR[NSW] = {0, 0, 0, 0, 1};
-        int ab[4];
+        constexpr int WPF = NW == 4 ? Q8_C3_PF : 1;         // sweeps the weight fragments run ahead (a main sweep is 336 pipe cycles: one ahead
+        uint4 wb[WPF + 1][3][2];                            // does not cover an L2 round trip)
+        auto wload = [&](int K, uint4 (&dst)[3][2]) {       // K: sweep of the whole sequence
+            const int u = K / NSW, k = K % NSW;
+            const uint4* wm = reinterpret_cast<const uint4*>(w3m) + (size_t)un[u] * 9 * 2 * 64 + lane;
+            const uint4* wx = reinterpret_cast<const uint4*>(w3x) + ((size_t)un[u] * 8 * 64 + lane) * 2;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int x = l15 + (j < 3 ? j : 2);            // (column 3 exists only as the empty half of the pair (2, -): any finite bytes)
-            ab[j] = 64 * x + ((kq ^ swz32(x)) << 4);
-        }
+            for (int i = 0; i < 3; i++) {
+                if (SW_KIND[k] == 0) dst[i][0] = wm[(size_t)((i * 3 + SW_COL[k]) * 2) * 64];
+                else if (SW_KIND[k] == 1) { dst[i][0] = wx[(size_t)((i * 2 + SW_PAIR[k]) * 64) * 2]; dst[i][1] = wx[(size_t)((i * 2 + SW_PAIR[k]) * 64) * 2 + 1]; }
+                else if (i < 2) { dst[i][0] = wx[(size_t)((6 + i) * 64) * 2]; dst[i][1] = wx[(size_t)((6 + i) * 64) * 2 + 1]; }
+            }
+        };
+        uint4 ar[D][2];
+        auto p_read = [&](int t, uint4 (&dst)[2]) {
+            const int u = t / UT, k = (t % UT) / ROWS, y = t % ROWS;
+            const int rb = 7 * 1024 * up[u];                // byte offset of the unit's first input row in either plane
+            if (SW_KIND[k] == 0) dst[0] = *reinterpret_cast<const uint4*>(&lds[rb + 1024 * y + ab[SW_COL[k]]]);
+            else if (SW_KIND[k] == 1) {
+                dst[0] = *reinterpret_cast<const uint4*>(&lds[C34_PLANE + rb + 1024 * y + ab[SW_COL[k]]]);
+                dst[1] = *reinterpret_cast<const uint4*>(&lds[C34_PLANE + rb + 1024 * y + ab[SW_COL[k] + 1]]);
+            } else {
+                const int y1 = y + 1 < ROWS ? y + 1 : y;
+                dst[0] = *reinterpret_cast<const uint4*>(&lds[C34_PLANE + rb + 1024 * y + ab[SW_COL[k]]]);
+                dst[1] = *reinterpret_cast<const uint4*>(&lds[C34_PLANE + rb + 1024 * y1 + ab[SW_COL[k]]]);
+            }
+        };
 #pragma unroll
-        for (int pass = 1; pass >= 0; pass--) {
-            const uint4* wm = reinterpret_cast<const uint4*>(w3m) + (size_t)wave * 9 * 2 * 64 + lane;
-            const uint4* wx = reinterpret_cast<const uint4*>(w3x) + ((size_t)wave * 8 * 64 + lane) * 2;
-            asm volatile("" : "+v"(wm), "+v"(wx));            // (an opaque copy per pass: the same loads, kept live across both otherwise)
-            f32x4 acc[7];
+        for (int K = 0; K < WPF; K++) wload(K, wb[K]);
 #pragma unroll
-            for (int r = 0; r < 7; r++) { acc[r][0] = bv.x; acc[r][1] = bv.y; acc[r][2] = bv.z; acc[r][3] = bv.w; }
-            uint4 wb[2][3][2];
-            auto wload = [&](int k, uint4 (&dst)[3][2]) {
+        for (int t = 0; t < D - 1; t++) p_read(t, ar[t]);
+        f32x4 acc[7];
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    if (SW_KIND[k] == 0) dst[i][0] = wm[(size_t)((i * 3 + SW_COL[k]) * 2) * 64];
-                    else if (SW_KIND[k] == 1) { dst[i][0] = wx[(size_t)((i * 2 + SW_PAIR[k]) * 64) * 2]; dst[i][1] = wx[(size_t)((i * 2 + SW_PAIR[k]) * 64) * 2 + 1]; }
-                    else if (i < 2) { dst[i][0] = wx[(size_t)((6 + i) * 64) * 2]; dst[i][1] = wx[(size_t)((6 + i) * 64) * 2 + 1]; }
-                }
-            };
-            wload(0, wb[0]);
-            constexpr int D = Q8_C3_D, ROWS = 9, NT = NSW * ROWS;
-            uint4 ar[D][2];
-            auto p_read = [&](int t, uint4 (&dst)[2]) {
-                const int k = t / ROWS, y = t % ROWS, row = 7 * pass + y;
-                if (SW_KIND[k] == 0) dst[0] = *reinterpret_cast<const uint4*>(&lds[1024 * row + ab[SW_COL[k]]]);
-                else if (SW_KIND[k] == 1) {
-                    dst[0] = *reinterpret_cast<const uint4*>(&lds[C34_PLANE + 1024 * row + ab[SW_COL[k]]]);
-                    dst[1] = *reinterpret_cast<const uint4*>(&lds[C34_PLANE + 1024 * row + ab[SW_COL[k] + 1]]);
-                } else {
-                    const int row1 = y + 1 < ROWS ? row + 1 : row;
-                    dst[0] = *reinterpret_cast<const uint4*>(&lds[C34_PLANE + 1024 * row + ab[SW_COL[k]]]);
-                    dst[1] = *reinterpret_cast<const uint4*>(&lds[C34_PLANE + 1024 * row1 + ab[SW_COL[k]]]);
-                }
-            };
+        for (int u = 0; u < NU; u++) {
+            {
+                const int c0 = 16 * un[u] + 4 * kq;         // 90 real channels: 88 .. 91 straddles the end
+                const float bx = c0 < 90 ? b3[c0] * Q8_WSCALE : 0.f, by = c0 + 1 < 90 ? b3[c0 + 1] * Q8_WSCALE : 0.f;
+                const float bz = c0 + 2 < 90 ? b3[c0 + 2] * Q8_WSCALE : 0.f, bw = c0 + 3 < 90 ? b3[c0 + 3] * Q8_WSCALE : 0.f;
 #pragma unroll
-            for (int t = 0; t < D - 1; t++) p_read(t, ar[t]);
+                for (int r = 0; r < 7; r++) { acc[r][0] = bx; acc[r][1] = by; acc[r][2] = bz; acc[r][3] = bw; }
+            }
 #pragma unroll
             for (int k = 0; k < NSW; k++) {
 #pragma unroll
                 for (int y = 0; y < ROWS; y++) {
-                    const int t = k * ROWS + y;
+                    const int K = u * NSW + k, t = K * ROWS + y;
                     if (t + D - 1 < NT) p_read(t + D - 1, ar[(t + D - 1) % D]);
-                    if (y == 0 && k + 1 < NSW) wload(k + 1, wb[(k + 1) & 1]);
+                    if (y == 0 && K + WPF < NU * NSW) wload(K + WPF, wb[(K + WPF) % (WPF + 1)]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 3; i++) {
                         const int r = SW_KIND[k] == 2 ? y - 2 * i : y - i;
                         if (r >= 0 && r < 7 && !(SW_KIND[k] == 2 && i > 1)) {
                             if (SW_KIND[k] == 0)
-                                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, wb[k & 1][i][0]), __builtin_bit_cast(h8, ar[t % D][0]), acc[r], 0, 0, 0);
+                                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, wb[K % (WPF + 1)][i][0]), __builtin_bit_cast(h8, ar[t % D][0]), acc[r], 0, 0, 0);
                             else
-                                acc[r] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pair8(wb[k & 1][i][0], wb[k & 1][i][1]), pair8(ar[t % D][0], ar[t % D][1]),
+                                acc[r] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pair8(wb[K % (WPF + 1)][i][0], wb[K % (WPF + 1)][i][1]), pair8(ar[t % D][0], ar[t % D][1]),
                                                                                           acc[r], 0, 0, 0, s_wgt, 0, s_act);
                         }
                     }
@@ -532,27 +566,20 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVE
                 const float v0 = fmaxf(acc[r][0], 0.f) * (1.f / Q8_WSCALE), v1 = fmaxf(acc[r][1], 0.f) * (1.f / Q8_WSCALE);
                 const float v2 = fmaxf(acc[r][2], 0.f) * (1.f / Q8_WSCALE), v3 = fmaxf(acc[r][3], 0.f) * (1.f / Q8_WSCALE);
                 if (l15 < 14 && !(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)) <= Q8_LIMIT)) big3 = 1e30f;
-                const Split4 sp = split4(v0, v1, v2, v3);
-                if (pass == 1) store_px(7 + r, sp);
-                else c3[r] = sp;
+                c3[u][r] = split4(v0, v1, v2, v3);
+            }
+            if (u + 1 < NU) {                               // (the last unit is a pass 0 by construction)
+                if (up[u]) {
+#pragma unroll
+                    for (int r = 0; r < 7; r++) store_px(un[u], 7 + r, c3[u][r]);
+                }
             }
         }
     }
-    Q8_STAMP(9);                                           // wave 0's conv3
-    if (Q8_PRIO) __builtin_amdgcn_s_setprio(3);
-    __syncthreads();                                       // every wave is done with conv3's input, which rows 0 .. 6 overlay
-#pragma unroll
-    for (int oy = 0; oy < 7; oy++) store_px(oy, c3[oy]);
-    if (overflow && big3 != 0.f) *overflow = 1;
-    __syncthreads();
-    Q8_STAMP(10);                                          // barrier, rows 0 .. 6 stored, barrier
-    if (Q8_PRIO) __builtin_amdgcn_s_setprio(0);
-
-    // ---- conv4: wave = (mh, nh): the pooling tiles of tile row mh (3 of the 9), channel tiles 3 nh .. 3 nh + 2: a fragment
-    // read feeds three MFMAs (with two channel tiles per wave the LDS, at 1 650 reads of 1 KB per patch, took as long as the
-    // matrix pipe)
-    constexpr int MT = 3, NN = 3;
-    const int mh = wave >> 1, nh = wave & 1;
+    // ---- conv4: wave = (group of MT pooling tiles from T0 on, channel tiles 3 nh .. 3 nh + 2): a fragment read feeds three
+    // MFMAs (with two channel tiles per wave the LDS, at 1 650 reads of 1 KB per patch, took as long as the matrix pipe)
+    constexpr int MT = NW == 6 ? 3 : 5, NN = 3;
+    const int nh = wave & 1, T0 = MT * (wave >> 1);
     f32x4 acc[MT][NN];
 #pragma unroll
     for (int n = 0; n < NN; n++) {
@@ -562,18 +589,20 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVE
         for (int t = 0; t < MT; t++) { acc[t][n][0] = bb; acc[t][n][1] = bb; acc[t][n][2] = bb; acc[t][n][3] = bb; }
     }
     const int q = l15 >> 2, sub = l15 & 3, dy = 2 * (q >> 1) + (sub >> 1), dx = 2 * (q & 1) + (sub & 1);
-    // the lane's pixel inside pooling tile (mh, tl), for taps in rows of either parity (the parity flips bit 1 of the slot);
-    // everything else of a fragment's address (tile column, tap, channel block, plane) is an immediate offset of the read
-    int ta[2];
-    {
-        const int base = (4 * mh + dy) * C34_RS + dx * C34_PS;
-        ta[0] = base + ((kq ^ ((dy & 1) << 1)) << 4);
-        ta[1] = base + ((kq ^ (((dy + 1) & 1) << 1)) << 4);
+    // the lane's pixel inside pooling tile T0 + tl, for taps in rows of either parity (the parity flips bit 1 of the slot);
+    // everything else of a fragment's address (tap, channel block, plane) is an immediate offset of the read
+    int ta[MT][2];
+#pragma unroll
+    for (int tl = 0; tl < MT; tl++) {
+        const int t = T0 + tl, tt = t > 8 ? 8 : t;          // (four waves: tile 9 of the second group does not exist -- clamped, its results are dropped)
+        const int base = (4 * (tt / 3) + dy) * C34_RS + (4 * (tt % 3) + dx) * C34_PS;
+        ta[tl][0] = base + ((kq ^ ((dy & 1) << 1)) << 4);
+        ta[tl][1] = base + ((kq ^ (((dy + 1) & 1) << 1)) << 4);
     }
     const uint4* wm4 = reinterpret_cast<const uint4*>(w4m) + (size_t)(NN * nh) * 27 * 2 * 64 + lane;
     const uint4* wx4 = reinterpret_cast<const uint4*>(w4x) + ((size_t)(NN * nh) * 14 * 64 + lane) * 2;
     // sweeps: per pair u of k-steps: M(2u), M(2u + 1), X(u); the last pair has one step
-    constexpr int PF = Q8_C4_PF, D4 = Q8_C4_D, NT4 = C4_NSW * MT;
+    constexpr int PF = NW == 6 ? Q8_C4_PF : Q8_C4W4_PF, D4 = NW == 6 ? Q8_C4_D : Q8_C4W4_D, NT4 = C4_NSW * MT;
     uint4 wb4[PF + 1][NN][2], ar4[D4][2];
     auto wload4 = [&](auto kc, uint4 (&dst)[NN][2]) {
         constexpr int k = decltype(kc)::value;
@@ -585,7 +614,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVE
     };
     auto unit_addr = [&](int step, int tl, int plane) {
         const int tap = step / 3, cc = step % 3, i = tap / 3, j = tap % 3;
-        return ta[i & 1] + (i * C34_RS + (4 * tl + j) * C34_PS + 64 * cc + plane * C34_PLANE);
+        return ta[tl][i & 1] + (i * C34_RS + j * C34_PS + 64 * cc + plane * C34_PLANE);
     };
     auto a_read4 = [&](auto uc, uint4 (&dst)[2]) {
         constexpr int u = decltype(uc)::value, k = u / MT, tl = u % MT;
@@ -596,7 +625,21 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVE
             dst[1] = *reinterpret_cast<const uint4*>(&lds[unit_addr(s1, tl, 1)]);
         }
     };
-    static_for<PF>([&](auto kc) { wload4(kc, wb4[decltype(kc)::value]); });
+    static_for<PF>([&](auto kc) { wload4(kc, wb4[decltype(kc)::value]); });     // (requested before the barriers of the relayout: an L2 round trip ahead)
+    Q8_STAMP(9);                                           // wave 0's conv3
+    if (Q8_PRIO) __builtin_amdgcn_s_setprio(3);
+    __syncthreads();                                       // every wave is done with conv3's input, which rows 0 .. 6 overlay
+#pragma unroll
+    for (int u = 0; u < NU; u++)
+        if (!up[u]) {
+#pragma unroll
+            for (int oy = 0; oy < 7; oy++) store_px(un[u], oy, c3[u][oy]);
+        }
+    if (overflow && big3 != 0.f) *overflow = 1;
+    __syncthreads();
+    Q8_STAMP(10);                                          // barrier, rows 0 .. 6 stored, barrier
+    if (Q8_PRIO) __builtin_amdgcn_s_setprio(0);
+
     static_for<D4 - 1>([&](auto uc) { a_read4(uc, ar4[decltype(uc)::value]); });
     static_for<NT4>([&](auto uc) {
         constexpr int u = decltype(uc)::value, k = u / MT, tl = u % MT;
@@ -622,10 +665,11 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVE
         const int co = 16 * (NN * nh + n) + l15;
 #pragma unroll
         for (int tl = 0; tl < MT; tl++) {
+            const int t = T0 + tl;
             float v = fmaxf(fmaxf(acc[tl][n][0], acc[tl][n][1]), fmaxf(acc[tl][n][2], acc[tl][n][3]));
             v = fmaxf(v, 0.f) * (1.f / Q8_WSCALE);
-            const int py = 2 * mh + (kq >> 1), px = 2 * tl + (kq & 1);
-            if (co < 90) {
+            const int py = 2 * (t / 3) + (kq >> 1), px = 2 * (t % 3) + (kq & 1);
+            if (t < 9 && co < 90) {
                 if (!(v <= 65000.f)) big4 = 1e30f;
                 o[(py * 6 + px) * 90 + co] = v;
             }
@@ -637,6 +681,25 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVE
     if (threadIdx.x == 0) atomicAdd(&g_q8_prof[15], 1ull);
     q8_log(1, t_born__);
 #endif
+}
+
+// (the tile is dynamic LDS: seeing 75 KB of static LDS the compiler settles for three waves per SIMD whatever it is asked)
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVES, Q8_C34_WAVES))) void conv34_q8_w6_kernel(
+    const float* __restrict__ in, const uint16_t* __restrict__ w3m, const uint8_t* __restrict__ w3x, const float* __restrict__ b3,
+    const uint16_t* __restrict__ w4m, const uint8_t* __restrict__ w4x, const float* __restrict__ b4,
+    float* __restrict__ out, int* __restrict__ overflow)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];       // 2 * C34_PLANE bytes
+    conv34_q8_body<6>(lds_dyn, in, w3m, w3x, b3, w4m, w4x, b4, out, overflow);
+}
+
+__global__ __launch_bounds__(256, 2) void conv34_q8_w4_kernel(
+    const float* __restrict__ in, const uint16_t* __restrict__ w3m, const uint8_t* __restrict__ w3x, const float* __restrict__ b3,
+    const uint16_t* __restrict__ w4m, const uint8_t* __restrict__ w4x, const float* __restrict__ b4,
+    float* __restrict__ out, int* __restrict__ overflow)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];       // 2 * C34_PLANE bytes
+    conv34_q8_body<4>(lds_dyn, in, w3m, w3x, b3, w4m, w4x, b4, out, overflow);
 }
 
 }  // namespace
@@ -788,8 +851,13 @@ static void q8_residency(const char* name, int which, int nwg)
 int k_cnn_q8_conv34(ck_ctx* ctx, const float* p2, int np, float* p4, int* overflow)
 {
     const CnnWeights& W = ctx->cnn;
-    hipLaunchKernelGGL(conv34_q8_kernel, dim3(np), dim3(384), (size_t)(2 * C34_PLANE), ctx->stream, p2, (const uint16_t*)W.c3w_h2.p, (const uint8_t*)W.c3x_q8.p,
+#if Q8_C34_NW == 4
+    hipLaunchKernelGGL(conv34_q8_w4_kernel, dim3(np), dim3(256), (size_t)(2 * C34_PLANE), ctx->stream, p2, (const uint16_t*)W.c3w_h2.p, (const uint8_t*)W.c3x_q8.p,
                        (const float*)W.c3b.p, (const uint16_t*)W.c4w_h2.p, (const uint8_t*)W.c4x_q8.p, (const float*)W.c4b.p, p4, overflow);
+#else
+    hipLaunchKernelGGL(conv34_q8_w6_kernel, dim3(np), dim3(384), (size_t)(2 * C34_PLANE), ctx->stream, p2, (const uint16_t*)W.c3w_h2.p, (const uint8_t*)W.c3x_q8.p,
+                       (const float*)W.c3b.p, (const uint16_t*)W.c4w_h2.p, (const uint8_t*)W.c4x_q8.p, (const float*)W.c4b.p, p4, overflow);
+#endif
     CK_HIP(ctx, hipGetLastError());
 #if Q8_DBG_TIME
     {

@@ -147,7 +147,10 @@ int ck_mog2_destroy(ck_ctx* ctx, int handle);
 int ck_cnn_set_weights(ck_ctx* ctx, const float* const weights[12], int space);
 int ck_cnn_set_mode(ck_ctx* ctx, int mode);      /* CK_CNN_F16X2 (default): f32 operands split into hi + lo fp16, three fp16 MFMAs per product,
                                                     f32 accumulate -- as close to a float64 evaluation as the f32 chain is (profiles/r01_cnn_precision.txt);
-                                                    CK_CNN_FP32: k-ordered f32 MFMA chain; CK_CNN_BF16: bf16 operands */
+                                                    CK_CNN_FP32: k-ordered f32 MFMA chain; CK_CNN_BF16: bf16 operands;
+                                                    CK_CNN_F16Q8 (opt-in): the split of CK_CNN_F16X2 with its two cross terms (2^-11 of a product)
+                                                    rounded to e4m3 and issued as one block-scaled MFMA per two taps -- a quarter faster, the
+                                                    filter maps within 5e-5 of their scale instead of 1e-6; out-of-range values fall back */
 /* goban: n x 380 x 380 x 3.  Any of y (n*100*81 softmax), labels (n*361, 0=E 1=B 2=W),
  * conf (n*361 doubles, max(y)/sum(y)) may be NULL. */
 int ck_cnn_predict(ck_ctx* ctx, const uint8_t* goban, int n, int in_space,

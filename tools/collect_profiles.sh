@@ -43,6 +43,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cnn_bf16 -- pyth
 find $O/prof_cnn_bf16 -name "*kernel_trace.csv" -delete 2>/dev/null || true
 find $O/prof_cnn_bf16 -name "*.db" -delete 2>/dev/null || true
 echo "bf16 classifier stats done"
+# the opt-in F16Q8 classifier: the same
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cnn_q8 -- python3 tools/cnn_modes.py 128 f16q8 > $O/cnn_q8.log 2> $O/prof_cnn_q8.err
+find $O/prof_cnn_q8 -name "*kernel_trace.csv" -delete 2>/dev/null || true
+find $O/prof_cnn_q8 -name "*.db" -delete 2>/dev/null || true
+echo "f16q8 classifier stats done"
 du -sh $O | tail -1
 python bench.py > $O/bench_full.json 2> $O/bench_full.err
 echo "bench done"
