@@ -239,9 +239,10 @@ __device__ __forceinline__ void conv12_q8_body(
                 pf[s] = make_uint4(f0.x, f0.y, f1.x, f1.y);
             }
         };
-        auto tile_of = [&](int t, const uint4 (&pf)[4]) {
-            const int m = 16 * t + l15, my = m / 36, mx = m - 36 * my;
-            f32x4 c1[2];
+        // a tile in two halves: its 16 MFMAs, and -- one tile later, next to the NEXT tile's MFMAs, which do not depend on them --
+        // the relu, split and stores of its results (in one piece every tile was a chain: LDS -> 16 MFMAs -> 50 vector
+        // instructions -> stores, the matrix pipe idle under the second half)
+        auto tile_mfma = [&](const uint4 (&pf)[4], f32x4 (&c1)[2]) {
 #pragma unroll
             for (int n = 0; n < 2; n++) { c1[n][0] = bv1[n].x; c1[n][1] = bv1[n].y; c1[n][2] = bv1[n].z; c1[n][3] = bv1[n].w; }
 #pragma unroll
@@ -250,6 +251,9 @@ __device__ __forceinline__ void conv12_q8_body(
                 for (int pl = 0; pl < 2; pl++)
 #pragma unroll
                     for (int n = 0; n < 2; n++) c1[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[pl][s][n], __builtin_bit_cast(h8, pf[s]), c1[n], 0, 0, 0);
+        };
+        auto tile_out = [&](int t, const f32x4 (&c1)[2]) {
+            const int m = 16 * t + l15, my = m / 36, mx = m - 36 * my;
             const int sw = swz32(mx);
             uint16_t* hp = &thi[my * C12_RS + 32 * mx + 4 * (kq & 1)];
             uint8_t* qp = &tq[my * (2 * C12_RS) + 64 * mx + 4 * kq];
@@ -266,13 +270,15 @@ __device__ __forceinline__ void conv12_q8_body(
         };
         constexpr int NI = (NTILE + 3) / 4;
         uint4 pf[2][4];
+        f32x4 c1[2][2];
         frags(wave, pf[0]);
 #pragma unroll
-        for (int i = 0; i < NI; i++) {
+        for (int i = 0; i <= NI; i++) {
             const int t = wave + 4 * i;
             if (i + 1 < NI && t + 4 < NTILE) frags(t + 4, pf[(i + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            if (t < NTILE) tile_of(t, pf[i & 1]);
+            if (i < NI && t < NTILE) tile_mfma(pf[i & 1], c1[i & 1]);
+            if (i > 0 && t - 4 < NTILE) tile_out(t - 4, c1[(i - 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -579,7 +585,10 @@ __device__ __forceinline__ void conv34_q8_body(
     // ---- conv4: wave = (group of MT pooling tiles from T0 on, channel tiles 3 nh .. 3 nh + 2): a fragment read feeds three
     // MFMAs (with two channel tiles per wave the LDS, at 1 650 reads of 1 KB per patch, took as long as the matrix pipe)
     constexpr int MT = NW == 6 ? 3 : 5, NN = 3;
-    const int nh = wave & 1, T0 = MT * (wave >> 1);
+    // (four waves: the group of five tiles goes to waves 0, 1 of even patches and to waves 2, 3 of odd ones, so that the two
+    // workgroups of a CU do not both put their longer waves on the same SIMDs)
+    const int nh = wave & 1, T0 = MT * (NW == 4 ? ((wave >> 1) ^ (patch & 1)) : (wave >> 1));
+    const bool last_tile = T0 + MT - 1 < 9;                 // (four waves: tile 9 of the second group does not exist; uniform over the wave)
     f32x4 acc[MT][NN];
 #pragma unroll
     for (int n = 0; n < NN; n++) {
@@ -646,13 +655,15 @@ __device__ __forceinline__ void conv34_q8_body(
         if constexpr (u + D4 - 1 < NT4) a_read4(std::integral_constant<int, u + D4 - 1>{}, ar4[(u + D4 - 1) % D4]);
         if constexpr (tl == 0 && k + PF < C4_NSW) wload4(std::integral_constant<int, k + PF>{}, wb4[(k + PF) % (PF + 1)]);
         __builtin_amdgcn_sched_barrier(0);
+        if (NW == 6 || tl + 1 < MT || last_tile) {
 #pragma unroll
-        for (int n = 0; n < NN; n++) {
-            if constexpr (c4_kind(k) == 0)
-                acc[tl][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ar4[u % D4][0]), __builtin_bit_cast(h8, wb4[k % (PF + 1)][n][0]), acc[tl][n], 0, 0, 0);
-            else
-                acc[tl][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pair8(ar4[u % D4][0], ar4[u % D4][1]), pair8(wb4[k % (PF + 1)][n][0], wb4[k % (PF + 1)][n][1]),
-                                                                               acc[tl][n], 0, 0, 0, s_act, 0, s_wgt);
+            for (int n = 0; n < NN; n++) {
+                if constexpr (c4_kind(k) == 0)
+                    acc[tl][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ar4[u % D4][0]), __builtin_bit_cast(h8, wb4[k % (PF + 1)][n][0]), acc[tl][n], 0, 0, 0);
+                else
+                    acc[tl][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(pair8(ar4[u % D4][0], ar4[u % D4][1]), pair8(wb4[k % (PF + 1)][n][0], wb4[k % (PF + 1)][n][1]),
+                                                                                   acc[tl][n], 0, 0, 0, s_act, 0, s_wgt);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     });
