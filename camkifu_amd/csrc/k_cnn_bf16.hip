@@ -16,7 +16,7 @@
 #include "ck_common.h"
 
 #ifndef BF_C12_MINW
-#define BF_C12_MINW 3        // workgroups (of four waves) per CU the compiler is asked to leave room for: 3 x 54 KB of LDS
+#define BF_C12_MINW 3        // workgroups (of four waves) per CU the compiler is asked to leave room for: 3 x 53 760 B of LDS
 #endif
 #ifndef BF_C2_D
 #define BF_C2_D 5            // conv2: depth of the fragment ring (reads in flight + the one in use)
@@ -86,9 +86,15 @@ __device__ __forceinline__ int swz32(int x) { return (x >> 1) & 3; }
 //           the u8 pixels are exact halves, so conv1 runs on v_mfma_f32_16x16x32_f16 with 11-bit weights (flip applied)
 //   w2    : conv2 weights bf16 [channel tile 2][tap 25][lane][8] (pack_bf of k_cnn.hip: lane = kslot * 16 + channel)
 //   out   : [patch][16 * 16 pooled pixels][32] bf16
-// LDS: the staged pixels as halves [24 rows][42 px][B, G, R, 0] (a fragment = two neighbouring taps = 16 aligned bytes)
-// and conv1's output tile [20 rows][36 px][32 ch] bf16, swizzled (swz32).  54 144 B: three workgroups per CU.
-constexpr int C12_PIX_RS = 42 * 4, C12_PIX_ROWS = 24;          // halves
+// LDS: the staged pixels as halves [24 rows][40 px][B, G, R, 0] (a fragment = two neighbouring taps = 16 aligned bytes)
+// and conv1's output tile [20 rows][36 px][32 ch] bf16, swizzled (swz32).  53 760 B = 42 allocation units of 1 280 B: three
+// workgroups per CU.  (With two padding columns per pixel row, 54 144 B, only TWO were resident -- tools/micro/wave_placement.hip:
+// LDS is handed out in units of 1 280 B and 3 x 43 of them exceed the CU's 128.  The sixth tap of a kernel row, which the
+// padding fed, has zero weights and needs finite halves only: the last pixel tile column re-reads its fifth.)
+#ifndef BF_C12_PIXPAD
+#define BF_C12_PIXPAD 0      // developer A/B: 1 = the two padding columns back (54 144 B, two workgroups per CU)
+#endif
+constexpr int C12_PIX_RS = (40 + 2 * BF_C12_PIXPAD) * 4, C12_PIX_ROWS = 24;          // halves
 constexpr int C12_TILE_RS = 36 * 32, C12_TILE_ROWS = 20;       // halves
 
 __global__ __launch_bounds__(256, BF_C12_MINW) void conv12_bf16_kernel(
@@ -135,8 +141,10 @@ __global__ __launch_bounds__(256, BF_C12_MINW) void conv12_bf16_kernel(
             d[0] = lo; d[1] = hi;
         }
     };
-    if (tid >= 240)     // columns 40 and 41 (under the zero weights of the sixth tap): finite values, written once
+#if BF_C12_PIXPAD
+    if (tid >= 240)
         for (int r = tid - 240; r < C12_PIX_ROWS; r += 16) *reinterpret_cast<uint4*>(&pix[r * C12_PIX_RS + 160]) = make_uint4(0, 0, 0, 0);
+#endif
     const int half = blockIdx.x & 1;
     load_raw(half);
     store_pix();
@@ -153,10 +161,12 @@ __global__ __launch_bounds__(256, BF_C12_MINW) void conv12_bf16_kernel(
     // fragment f = 4 s + kq of a pixel: kernel row f / 3, taps 2 (f % 3) and 2 (f % 3) + 1; f = 15 has zero weights and
     // re-reads fragment 14
     int foff[4];
+    bool last_pair[4];                                     // the fragment holds taps 4 and 5 (the sixth: zero weights)
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int f = 4 * s + kq > 14 ? 14 : 4 * s + kq;
         foff[s] = (f / 3) * C12_PIX_RS + 8 * (f % 3);
+        last_pair[s] = f % 3 == 2;
     }
     __syncthreads();
     BF_STAMP(0);                                           // pixels staged, conv1's weights here
@@ -171,7 +181,8 @@ __global__ __launch_bounds__(256, BF_C12_MINW) void conv12_bf16_kernel(
             const uint16_t* pp = &pix[my * C12_PIX_RS + 4 * mx];
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const uint2 f0 = *reinterpret_cast<const uint2*>(pp + foff[s]), f1 = *reinterpret_cast<const uint2*>(pp + foff[s] + 4);
+                // (pixel column 40 does not exist: under the sixth tap's zero weights the last column reads its fifth tap's pixel again)
+                const uint2 f0 = *reinterpret_cast<const uint2*>(pp + foff[s]), f1 = *reinterpret_cast<const uint2*>(pp + foff[s] + (last_pair[s] && mx == 35 ? 0 : 4));
                 pf[s] = make_uint4(f0.x, f0.y, f1.x, f1.y);
             }
         };
