@@ -31,31 +31,18 @@
 #ifndef Q8_C2_D
 #define Q8_C2_D 4            // conv2: depth of the fragment ring (reads in flight + the one in use)
 #endif
-#ifndef Q8_C4_D
-#define Q8_C4_D 3            // conv4: depth of the fragment ring
-#endif
-#ifndef Q8_C4_PF
-#define Q8_C4_PF 1           // conv4: sweeps the weight fragments run ahead
-#endif
 #ifndef Q8_C3_D
 #define Q8_C3_D 3            // conv3: depth of the fragment ring
 #endif
 #ifndef Q8_C3_PF
-#define Q8_C3_PF 2           // conv3, four-wave form: sweeps the weight fragments run ahead
+#define Q8_C3_PF 2           // conv3: sweeps the weight fragments run ahead (a main sweep is 336 pipe cycles: one ahead does not cover an L2 round trip)
 #endif
-#ifndef Q8_C4W4_PF
-#define Q8_C4W4_PF 3         // conv4, four-wave form: the same (a main sweep of five tiles is 240 pipe cycles)
+#ifndef Q8_C4_PF
+#define Q8_C4_PF 3           // conv4: the same (a main sweep of five tiles is 240 pipe cycles)
 #endif
-#ifndef Q8_C4W4_D
-#define Q8_C4W4_D 6          // conv4, four-wave form: depth of the fragment ring
+#ifndef Q8_C4_D
+#define Q8_C4_D 6            // conv4: depth of the fragment ring
 #endif
-#ifndef Q8_C34_NW
-#define Q8_C34_NW 4          // waves per workgroup of the conv3 + conv4 kernel (6: the first form, kept for A/B)
-#endif
-#ifndef Q8_C34_WAVES
-#define Q8_C34_WAVES 4       // 128 registers, four waves per SIMD: two workgroups of six waves fit a CU however their waves fall on its SIMDs
-#endif                       // (at 168 registers, three per SIMD, the second workgroup of a CU did not start: ONE was resident, measured).  The
-                             // tile is dynamic LDS because the compiler, seeing 75 KB, settles for three waves per SIMD whatever it is asked.
 #ifndef Q8_PRIO
 #define Q8_PRIO 1            // wave priority 3 outside the k-loops (staging, conv1, relayout, epilogue): these short phases of loads, LDS traffic
 #endif                       // and vector arithmetic otherwise wait behind the other workgroup's matrix instructions for every issue slot
@@ -421,20 +408,18 @@ constexpr int c4_step(int k) { return 2 * (k / 3) + (k % 3 == 1 ? 1 : 0); }
 
 __device__ __forceinline__ int c34_row_base(int y, int plane) { return plane * C34_PLANE + y * C34_RS; }
 
-// NW waves per workgroup.  Six (round 5's first form: conv3 wave = channel tile with both passes, conv4 wave = (row of three
-// pooling tiles, three channel tiles)) fall 2-2-1-1 on a CU's four SIMDs, for both resident workgroups alike: two SIMDs carry
-// twice the work.  Four (one per SIMD and workgroup, 256 registers each): conv3 in twelve units (channel tile, pass), three per
-// wave -- (w, rows 7-13), one of the four units of tiles 4 and 5, (w, rows 0-6) --, conv4 wave = (five / four pooling tiles,
-// three channel tiles).
-template <int NW>
+// Four waves per workgroup, one per SIMD (256 registers each): conv3 in twelve units (channel tile, pass), three per wave --
+// (w, rows 7-13), one of the four units of tiles 4 and 5, (w, rows 0-6) --, conv4 wave = (five / four pooling tiles, three channel
+// tiles).  (The first form had six waves -- conv3 wave = channel tile, conv4 wave = (row of three tiles, three channel tiles) --
+// and two SIMDs of a CU carried two of them between the barriers: 6.66 against 6.1 us per frame,
+// tools/variants/conv34_q8_six_waves.hip.txt.)
 __device__ __forceinline__ void conv34_q8_body(
     uint8_t* __restrict__ lds, const float* __restrict__ in, const uint16_t* __restrict__ w3m, const uint8_t* __restrict__ w3x, const float* __restrict__ b3,
     const uint16_t* __restrict__ w4m, const uint8_t* __restrict__ w4x, const float* __restrict__ b4,
     float* __restrict__ out, int* __restrict__ overflow)
 {
 #pragma clang fp contract(off)
-    static_assert(NW == 6 || NW == 4, "six or four waves");
-    constexpr int NTHR = 64 * NW;
+    constexpr int NW = 4, NTHR = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kq = lane >> 4;
     const int patch = blockIdx.x;
     Q8_STAMP_BEGIN;
@@ -492,20 +477,17 @@ __device__ __forceinline__ void conv34_q8_body(
     // both planes and are stored at once; rows 0 .. 6 wait, split, for the barrier.  ONE sequence of sweeps over all units: the
     // weight fragments run WPF sweeps ahead and the fragment reads D - 1 steps ahead ACROSS the unit boundaries (unit by
     // unit, every unit began by waiting an L2 round trip for its first weights with nothing left to overlap it).
-    constexpr int NU = NW == 4 ? 3 : 2;
-    const int nb = 4 + (wave >> 1), pb = 1 - (wave & 1);    // (four waves) the wave's middle unit: tile 4 or 5, either pass
-    int un[NU], up[NU];
-    un[0] = wave; up[0] = 1;
-    if constexpr (NW == 4) { un[1] = nb; up[1] = pb; }
-    un[NU - 1] = wave; up[NU - 1] = 0;
+    constexpr int NU = 3;
+    const int un[NU] = {wave, 4 + (wave >> 1), wave};      // the middle unit: tile 4 or 5, either pass
+    const int up[NU] = {1, 1 - (wave & 1), 0};
     Split4 c3[NU][7];
     {
         constexpr int NSW = 5, ROWS = 9, UT = NSW * ROWS, NT = NU * UT, D = Q8_C3_D;
         constexpr int SW_KIND[NSW] = {0, 0, 1, 0, 2};       // (2: the last column's cross terms with the taps paired vertically, as in conv2)
         constexpr int SW_COL[NSW] = {0, 1, 0, 2, 2};
         constexpr int SW_PAIR[NSW] = {0, 0, 0, 0, 1};
-        constexpr int WPF = NW == 4 ? Q8_C3_PF : 1;         // sweeps the weight fragments run ahead (a main sweep is 336 pipe cycles: one ahead
-        uint4 wb[WPF + 1][3][2];                            // does not cover an L2 round trip)
+        constexpr int WPF = Q8_C3_PF;
+        uint4 wb[WPF + 1][3][2];
         auto wload = [&](int K, uint4 (&dst)[3][2]) {       // K: sweep of the whole sequence
             const int u = K / NSW, k = K % NSW;
             const uint4* wm = reinterpret_cast<const uint4*>(w3m) + (size_t)un[u] * 9 * 2 * 64 + lane;
@@ -584,11 +566,11 @@ __device__ __forceinline__ void conv34_q8_body(
     }
     // ---- conv4: wave = (group of MT pooling tiles from T0 on, channel tiles 3 nh .. 3 nh + 2): a fragment read feeds three
     // MFMAs (with two channel tiles per wave the LDS, at 1 650 reads of 1 KB per patch, took as long as the matrix pipe)
-    constexpr int MT = NW == 6 ? 3 : 5, NN = 3;
-    // (four waves: the group of five tiles goes to waves 0, 1 of even patches and to waves 2, 3 of odd ones, so that the two
-    // workgroups of a CU do not both put their longer waves on the same SIMDs)
-    const int nh = wave & 1, T0 = MT * (NW == 4 ? ((wave >> 1) ^ (patch & 1)) : (wave >> 1));
-    const bool last_tile = T0 + MT - 1 < 9;                 // (four waves: tile 9 of the second group does not exist; uniform over the wave)
+    constexpr int MT = 5, NN = 3;
+    // (the group of five tiles goes to waves 0, 1 of even patches and to waves 2, 3 of odd ones, so that the two workgroups of a CU
+    // do not both put their longer waves on the same SIMDs)
+    const int nh = wave & 1, T0 = MT * ((wave >> 1) ^ (patch & 1));
+    const bool last_tile = T0 + MT - 1 < 9;                 // (tile 9 of the second group does not exist; uniform over the wave)
     f32x4 acc[MT][NN];
 #pragma unroll
     for (int n = 0; n < NN; n++) {
@@ -603,7 +585,7 @@ __device__ __forceinline__ void conv34_q8_body(
     int ta[MT][2];
 #pragma unroll
     for (int tl = 0; tl < MT; tl++) {
-        const int t = T0 + tl, tt = t > 8 ? 8 : t;          // (four waves: tile 9 of the second group does not exist -- clamped, its results are dropped)
+        const int t = T0 + tl, tt = t > 8 ? 8 : t;          // (tile 9: clamped, never computed)
         const int base = (4 * (tt / 3) + dy) * C34_RS + (4 * (tt % 3) + dx) * C34_PS;
         ta[tl][0] = base + ((kq ^ ((dy & 1) << 1)) << 4);
         ta[tl][1] = base + ((kq ^ (((dy + 1) & 1) << 1)) << 4);
@@ -611,7 +593,7 @@ __device__ __forceinline__ void conv34_q8_body(
     const uint4* wm4 = reinterpret_cast<const uint4*>(w4m) + (size_t)(NN * nh) * 27 * 2 * 64 + lane;
     const uint4* wx4 = reinterpret_cast<const uint4*>(w4x) + ((size_t)(NN * nh) * 14 * 64 + lane) * 2;
     // sweeps: per pair u of k-steps: M(2u), M(2u + 1), X(u); the last pair has one step
-    constexpr int PF = NW == 6 ? Q8_C4_PF : Q8_C4W4_PF, D4 = NW == 6 ? Q8_C4_D : Q8_C4W4_D, NT4 = C4_NSW * MT;
+    constexpr int PF = Q8_C4_PF, D4 = Q8_C4_D, NT4 = C4_NSW * MT;
     uint4 wb4[PF + 1][NN][2], ar4[D4][2];
     auto wload4 = [&](auto kc, uint4 (&dst)[NN][2]) {
         constexpr int k = decltype(kc)::value;
@@ -655,7 +637,7 @@ __device__ __forceinline__ void conv34_q8_body(
         if constexpr (u + D4 - 1 < NT4) a_read4(std::integral_constant<int, u + D4 - 1>{}, ar4[(u + D4 - 1) % D4]);
         if constexpr (tl == 0 && k + PF < C4_NSW) wload4(std::integral_constant<int, k + PF>{}, wb4[(k + PF) % (PF + 1)]);
         __builtin_amdgcn_sched_barrier(0);
-        if (NW == 6 || tl + 1 < MT || last_tile) {
+        if (tl + 1 < MT || last_tile) {
 #pragma unroll
             for (int n = 0; n < NN; n++) {
                 if constexpr (c4_kind(k) == 0)
@@ -694,23 +676,13 @@ __device__ __forceinline__ void conv34_q8_body(
 #endif
 }
 
-// (the tile is dynamic LDS: seeing 75 KB of static LDS the compiler settles for three waves per SIMD whatever it is asked)
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(Q8_C34_WAVES, Q8_C34_WAVES))) void conv34_q8_w6_kernel(
+__global__ __launch_bounds__(256, 2) void conv34_q8_kernel(
     const float* __restrict__ in, const uint16_t* __restrict__ w3m, const uint8_t* __restrict__ w3x, const float* __restrict__ b3,
     const uint16_t* __restrict__ w4m, const uint8_t* __restrict__ w4x, const float* __restrict__ b4,
     float* __restrict__ out, int* __restrict__ overflow)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];       // 2 * C34_PLANE bytes
-    conv34_q8_body<6>(lds_dyn, in, w3m, w3x, b3, w4m, w4x, b4, out, overflow);
-}
-
-__global__ __launch_bounds__(256, 2) void conv34_q8_w4_kernel(
-    const float* __restrict__ in, const uint16_t* __restrict__ w3m, const uint8_t* __restrict__ w3x, const float* __restrict__ b3,
-    const uint16_t* __restrict__ w4m, const uint8_t* __restrict__ w4x, const float* __restrict__ b4,
-    float* __restrict__ out, int* __restrict__ overflow)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];       // 2 * C34_PLANE bytes
-    conv34_q8_body<4>(lds_dyn, in, w3m, w3x, b3, w4m, w4x, b4, out, overflow);
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * C34_PLANE];
+    conv34_q8_body(lds, in, w3m, w3x, b3, w4m, w4x, b4, out, overflow);
 }
 
 }  // namespace
@@ -862,13 +834,8 @@ static void q8_residency(const char* name, int which, int nwg)
 int k_cnn_q8_conv34(ck_ctx* ctx, const float* p2, int np, float* p4, int* overflow)
 {
     const CnnWeights& W = ctx->cnn;
-#if Q8_C34_NW == 4
-    hipLaunchKernelGGL(conv34_q8_w4_kernel, dim3(np), dim3(256), (size_t)(2 * C34_PLANE), ctx->stream, p2, (const uint16_t*)W.c3w_h2.p, (const uint8_t*)W.c3x_q8.p,
+    hipLaunchKernelGGL(conv34_q8_kernel, dim3(np), dim3(256), 0, ctx->stream, p2, (const uint16_t*)W.c3w_h2.p, (const uint8_t*)W.c3x_q8.p,
                        (const float*)W.c3b.p, (const uint16_t*)W.c4w_h2.p, (const uint8_t*)W.c4x_q8.p, (const float*)W.c4b.p, p4, overflow);
-#else
-    hipLaunchKernelGGL(conv34_q8_w6_kernel, dim3(np), dim3(384), (size_t)(2 * C34_PLANE), ctx->stream, p2, (const uint16_t*)W.c3w_h2.p, (const uint8_t*)W.c3x_q8.p,
-                       (const float*)W.c3b.p, (const uint16_t*)W.c4w_h2.p, (const uint8_t*)W.c4x_q8.p, (const float*)W.c4b.p, p4, overflow);
-#endif
     CK_HIP(ctx, hipGetLastError());
 #if Q8_DBG_TIME
     {

@@ -26,6 +26,19 @@ def test_header_symbols_are_exported():
     assert sorted(capi.EXPORTS) == names
 
 
+def test_header_constants_equal_the_python_side():
+    """the enums of include/camkifu_amd.h (status codes, memory spaces, classifier modes) and their mirrors in capi.py"""
+    from camkifu_amd import capi
+    src = open(os.path.join(ROOT, "include", "camkifu_amd.h")).read()
+    consts = {k: int(v) for body in re.findall(r"enum\s*\{([^}]*)\}", src) for k, v in re.findall(r"(CK_[A-Z0-9_]+)\s*=\s*(-?\d+)", body)}
+    assert {"CK_CNN_FP32", "CK_CNN_BF16", "CK_CNN_F16X2", "CK_CNN_F16Q8"} <= set(consts)
+    mirrored = [k for k in consts if hasattr(capi, k)]
+    assert len(mirrored) >= 6, mirrored
+    for k in mirrored:
+        assert getattr(capi, k) == consts[k], k
+    assert capi.CK_CNN_DEFAULT == consts["CK_CNN_F16X2"]        # the f32-equivalent mode stays the default
+
+
 def test_no_gpu_means_loud_failure():
     import pytest
     import torch
