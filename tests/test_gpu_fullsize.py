@@ -157,3 +157,28 @@ def test_config5_bf16_labels_against_the_oracle(ck, ora):
         flips += int((lo != l16[g]).sum())
         assert np.abs(yo - y16[g]).max() < 0.05
     assert flips == 0, "bf16 classifier flips %d labels against the oracle" % flips
+
+
+def test_f16q8_grids_and_confidences_against_the_oracle(ck, ora):
+    """CK_CNN_F16Q8 (cross terms as e4m3) on the shipped model over gobans of every density: the 19x19 grids bit-identical to
+    the oracle's, the softmax within 1e-4 (measured ~1e-5), the confidences the fold's thresholds look at within 1e-4"""
+    from camkifu_amd import capi, synth
+    from camkifu_amd.stone.nn_manager import NNManager
+    W8 = NNManager.init_net()
+    ck.cnn_set_weights(W8)
+    gobans = []
+    for seed in range(12):
+        sc = synth.scene(480, 640, seed=900 + seed, density=0.05 * seed)
+        gobans.append(ora.warp_perspective(sc["frame"].numpy(), ora.get_perspective_transform(sc["corners"], DST)))
+    gobans = np.stack(gobans)
+    ck.cnn_set_mode(capi.CK_CNN_F16Q8)
+    try:
+        y8, l8, c8 = ck.cnn_predict(gobans)
+    finally:
+        ck.cnn_set_mode(capi.CK_CNN_DEFAULT)
+    for g in range(len(gobans)):
+        yo = ora.cnn_predict_regions(W8, gobans[g])
+        lo, co = ora.decode_all(yo)
+        assert np.array_equal(lo, l8[g]), g
+        assert np.abs(yo - y8[g]).max() <= 1e-4
+        assert np.abs(co - c8[g]).max() <= 1e-4
