@@ -387,14 +387,14 @@ __global__ __launch_bounds__(256, 2) void conv12_q8_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// conv3 + conv4 of one patch per workgroup of six waves.
+// conv3 + conv4 of one patch per workgroup of four waves.
 //   in   : [patch][16 * 16][32] f32 (conv12's pooled output)      out : [patch][6 * 6][90] f32
 //   w3m  : the c3w_h2 pack [channel tile 6][tap 9][plane][lane][8]          w3x : e4m3 [channel tile 6][kernel row 3 x pair 2, then the 2 vertical pairs of column 2][lane][32 B]
 //   w4m  : the c4w_h2 pack [channel tile 6][step 27 = tap * 3 + cc][plane][lane][8]      w4x : e4m3 [channel tile 6][pair 14 of steps][lane][32 B]
-// conv3 (wave = channel tile, D = W x P on row tiles, two passes of seven rows, as conv34_bf16_kernel): sweeps M0 M1 X01 M2 X2
-// over the nine input rows of a pass; a lane ends up with four consecutive channels of a pixel -> split, into conv4's tile.
-// conv4 (wave = (row of three pooling tiles, three channel tiles), D = P x W, pool in the lane): per pair of k-steps two main
-// sweeps and one cross sweep over the wave's tiles.
+// conv3 (D = W x P on row tiles as in conv34_bf16_kernel, in twelve units (channel tile, seven output rows), three per wave):
+// sweeps M0 M1 X01 M2 X2 over the nine input rows of a unit; a lane ends up with four consecutive channels of a pixel -> split,
+// into conv4's tile.  conv4 (wave = (five / four pooling tiles, three channel tiles), D = P x W, pool in the lane): per pair of
+// k-steps two main sweeps and one cross sweep over the wave's tiles.
 // LDS (bytes): conv4's tile [14][14][96 channels] in two planes of 192 bytes per pixel (hi at 0, q at 37 632), chunk (cc, kq) of
 // the pixel in row y at slot 4 cc + (kq ^ 2 (y & 1)).  conv3's input (a hi plane [256 px][64] and a q plane [256 px][64],
 // swizzled by swz32) lies where rows 0 .. 6 of the two planes will be (16 384 < 7 x 2 688): the first pass's rows 7 .. 13 are
