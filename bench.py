@@ -795,9 +795,11 @@ def main():
                                                  "answers on the host; never the headline value")
             del host_i420, landing
 
-        # (3) BASELINE config 4's frame size on this GPU: 3840 x 2160, 64-frame batches, its own film and pipeline
+        # (3) BASELINE config 4's frame size on this GPU: 3840 x 2160, its own film and pipeline
         if world == 1:
-            H4, W4, F4 = 2160, 3840, 64
+            # 128-frame batches: at 64 (rounds 3-5) a step took 11.2 ms, as long as 256 frames of 1080p -- a fixed ~6 ms of per-batch
+            # pipeline latency, not GPU time (128: 15.8 ms, 256: 32.2 ms) -- and the leg read 5.7 k frames/s where the GPU does 8.1 k
+            H4, W4, F4 = 2160, 3840, int(os.environ.get("CK_BENCH_F4", "128"))
             fr4, corners4, truth4, moves4, hands4 = synth.film(F4, H4, W4, seed=synth.SEED, device=dev, quiet=52, move_every=32, hand_frames=12)
             p4 = pipeline.FastFilePipeline(H4, W4, ControllerHeadless(), rank=0, world=1, device=cdev, lanes=lanes, ctx_bg=ctx_bg)
             p4.process_batch(fr4, F4)
@@ -819,8 +821,8 @@ def main():
                 stone_grid_match_pct=round(100.0 * float((g4[calm4] == np.asarray(truth4)[calm4]).mean()), 3),
                 stages=st4, filter_pass=roofline_of("median", st4, args.cnn, F4, H4, W4, with_traffic=False),
                 filter_pass_fused=filter_fused_of(st4, H4, W4),
-                note="BASELINE config 4's frame size (3840 x 2160) in 64-frame batches resident in HBM on ONE GPU: same pipeline, same "
-                     "timed-region protocol as the headline; the 8-GPU half of config 4 is the driver's scaling run")
+                note="BASELINE config 4's frame size (3840 x 2160) in %d-frame batches resident in HBM on ONE GPU: same pipeline, same "
+                     "timed-region protocol as the headline; the 8-GPU half of config 4 is the driver's scaling run" % F4)
             del fr4
 
     sync()
