@@ -29,9 +29,10 @@ EXPORTS = [
     "ck_mog2_create", "ck_mog2_apply", "ck_mog2_destroy",
     "ck_cnn_set_weights", "ck_cnn_set_mode", "ck_cnn_predict", "ck_cnn_maps", "ck_stones_detect",
     "ck_cnn_regions", "ck_stones_run", "ck_zone_counts", "ck_mog2_band_run",
+    "ck_board_detect_records", "ck_cnn_regions_records",
     "ck_contour_stones", "ck_contours_external", "ck_find_intersections", "ck_update_grid",
-    "ck_ordered_hull", "ck_boardfold_create", "ck_boardfold_destroy", "ck_boardfold_reset", "ck_boardfold_step",
-    "ck_policy_create", "ck_policy_destroy", "ck_policy_run", "ck_policy_get_state", "ck_policy_set_state",
+    "ck_ordered_hull", "ck_boardfold_create", "ck_boardfold_destroy", "ck_boardfold_reset", "ck_boardfold_step", "ck_boardfold_run", "ck_round10", "ck_round10_reference",
+    "ck_policy_create", "ck_policy_destroy", "ck_policy_run", "ck_policy_run_records", "ck_policy_get_state", "ck_policy_set_state",
     "ck_policy_watch",
 ]
 
@@ -48,6 +49,15 @@ class BoardResult(C.Structure):
 
 BOARD_DTYPE = np.dtype([("status", "<i4"), ("n_contours", "<i4"), ("n_lines", "<i4"), ("reserved", "<i4"),
                         ("biggest_area", "<f8")])          # ck_board_result, 24 bytes
+
+
+REC_LMAX = 64                                               # CK_REC_LMAX
+REC_LINES_CUT, REC_FAILED = 1, 2                            # CK_REC_*
+REC_DTYPE = np.dtype([("status", "<i4"), ("n_contours", "<i4"), ("n_lines", "<i4"), ("flags", "<i4"),
+                      ("biggest_area", "<f8"), ("lines", "<f4", (REC_LMAX, 2)),
+                      ("region_conf", "<f8", (10, 10)), ("region_label", "u1", (10, 10)), ("pad", "u1", (4,))])   # ck_frame_record
+REC_BYTES = REC_DTYPE.itemsize
+assert REC_BYTES == 1440
 
 
 class CkError(RuntimeError):
@@ -94,6 +104,11 @@ def lib():
         L.ck_boardfold_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_longlong,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ck_policy_run.argtypes = [C.c_void_p, C.c_int, C.c_longlong] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p]
+        L.ck_policy_run_records.argtypes = [C.c_void_p, C.c_int, C.c_longlong] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p]
+        for fn in (L.ck_round10, L.ck_round10_reference):
+            fn.argtypes, fn.restype = [C.c_double], C.c_double
+        L.ck_boardfold_run.argtypes = ([C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
+                                       + [C.c_void_p] * 5)
         L.ck_policy_get_state.argtypes = [C.c_void_p] * 6
         L.ck_policy_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.ck_policy_watch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_longlong]
@@ -283,6 +298,42 @@ class Context:
         return [dict(status=int(r["status"]), n_contours=int(r["n_contours"]), n_lines=int(r["n_lines"]),
                      biggest_area=float(r["biggest_area"]), lines=lines[f, :min(int(r["n_lines"]), cap)].copy())
                 for f, r in enumerate(res)]
+
+    # ---- per-frame result records, written in place (host memory or HBM) -------------------------------------------
+    def wait_stream(self, stream):
+        """everything queued on `stream` (a torch.cuda.Stream) up to now runs before anything this context launches from now
+        on -- for a tensor another thread produced on a stream that is not this thread's current one (pipeline._take)"""
+        self._chk(lib().ck_stream_wait(self._h, C.c_void_p(stream.cuda_stream)))
+
+    def _rec(self, rec, n):
+        """-> (pointer, space, keepalive) of n records: a C-contiguous numpy array of REC_DTYPE, or a contiguous torch uint8
+        tensor (n, REC_BYTES) in HBM"""
+        if _is_torch(rec):
+            if tuple(rec.shape) != (n, REC_BYTES) or not rec.is_contiguous() or rec.element_size() != 1:
+                raise ValueError("records: expected a contiguous uint8 tensor of shape (%d, %d), got %r" % (n, REC_BYTES, tuple(rec.shape)))
+            if rec.is_cuda:
+                return self._in(rec)
+            rec = rec.numpy().view(REC_DTYPE).reshape(n)
+        if rec.dtype != REC_DTYPE or rec.shape != (n,) or not rec.flags.c_contiguous or not rec.flags.writeable:
+            raise ValueError("records: expected a writeable C-contiguous array of %d REC_DTYPE rows" % n)
+        return rec.ctypes.data_as(C.c_void_p), CK_HOST, rec
+
+    def board_detect_records(self, bgr, rec, hough_thresh=-1):
+        """K1..K6 of the frames -> the board half of their records, in place (ck_board_detect_records)"""
+        n, h, w = self._shape(bgr, 3)
+        p, sp, keep = self._in(bgr)
+        rp, rsp, keep2 = self._rec(rec, n)
+        self._chk(lib().ck_board_detect_records(self._h, p, n, h, w, sp, int(hough_thresh), rp, rsp))
+        return rec
+
+    def cnn_regions_records(self, goban, rec):
+        """K10..K12 of the goban images -> the stones half of their records, in place (ck_cnn_regions_records)"""
+        shp = tuple(goban.shape)
+        n = 1 if len(shp) == 3 else shp[0]
+        p, sp, keep = self._in(goban)
+        rp, rsp, keep2 = self._rec(rec, n)
+        self._chk(lib().ck_cnn_regions_records(self._h, p, n, sp, rp, rsp))
+        return rec
 
     # ---- frame source ------------------------------------------------------------------------
     def i420_to_bgr(self, i420, h, w, to_device=None, out=None):
@@ -601,6 +652,40 @@ class BoardFoldCore:
         return bool(o[0]), bool(o[1]), cen, (None if o[12] < 0 else (int(o[12]), int(o[13])))
 
 
+    def run(self, h, w, recs, k, counter, hold, seen, looked, cur_hull, order=None, hold_after_same_hit=-1):
+        """ck_boardfold_run over the REC_DTYPE array `recs` (frame f at recs[order[f]], or recs[f]) from frame k ->
+        (k, counter, hold, seen, looked, found, update, centers, stats): stops after the first frame that changes the corners
+        (with hold_after_same_hit < 0: after every hit), or at the end of the batch"""
+        assert recs.dtype == REC_DTYPE and recs.flags.c_contiguous
+        n = len(recs)
+        if order is not None:
+            assert order.dtype == np.int32 and order.flags.c_contiguous
+            n = len(order)
+        hull = None if cur_hull is None else np.ascontiguousarray(cur_hull, np.int32).reshape(8)
+        if not hasattr(self, "_io32"):
+            self._io32, self._io64 = np.zeros(2, np.int32), np.zeros(3, np.int64)
+        io32, io64 = self._io32, self._io64
+        io32[:] = (k, hold)
+        io64[:] = (counter, seen, looked)
+        o = self._out
+        base, b32, b64 = o.ctypes.data, io32.ctypes.data, io64.ctypes.data
+        rc = lib().ck_boardfold_run(self._h, int(h), int(w), recs.ctypes.data_as(C.c_void_p),
+                                    None if order is None else order.ctypes.data_as(C.c_void_p), n, C.c_void_p(b32),
+                                    C.c_void_p(b64), C.c_void_p(b32 + 4), C.c_void_p(b64 + 8),
+                                    None if hull is None else hull.ctypes.data_as(C.c_void_p), int(hold_after_same_hit),
+                                    C.c_void_p(base), C.c_void_p(base + 4), C.c_void_p(base + 16), C.c_void_p(base + 8),
+                                    C.c_void_p(base + 48))
+        state = (int(io32[0]), int(io64[0]), int(io32[1]), int(io64[1]), int(io64[2]))
+        if rc == 4:
+            err = IndexError("corner hull has fewer than 4 vertices")      # what the reference raises (bf_auto.py:206)
+            err.fold_state = state
+            raise err
+        if rc != 0:
+            raise CkError("ck_boardfold_run: error %d" % rc)
+        cen = [(int(o[4 + 2 * i]), int(o[5 + 2 * i])) for i in range(int(o[2]))]
+        return state + (bool(o[0]), bool(o[1]), cen, (None if o[12] < 0 else (int(o[12]), int(o[13]))))
+
+
 class PolicyCore:
     """ck_policy: SfNeural's emission policy over ordered runs of frames (host only, no GPU needed)."""
     SUGGEST, BULK = 1, 2
@@ -620,14 +705,22 @@ class PolicyCore:
         except Exception:
             pass
 
-    def run(self, first_counter, region_label, region_conf, fgcount, board_of, apply):
+    def run(self, first_counter, region_label, region_conf, fgcount, board_of, apply, records=None, order=None):
         """Ordered run over n frames.  `board_of()` -> uint8 (19,19) goban as the controller holds it now;
         `apply(kind, [(color, r, c), ...], frame_index)` executes a request; if it raises, the run stops there and
-        the rest of that frame is never done -- what an exception out of SfNeural._find means in the reference."""
-        rl = np.ascontiguousarray(region_label, np.uint8).reshape(-1, 100)
-        rc = np.ascontiguousarray(region_conf, np.float64).reshape(-1, 100)
-        n = len(rl)
-        assert len(rc) == n
+        the rest of that frame is never done -- what an exception out of SfNeural._find means in the reference.
+        `records`: a C-contiguous REC_DTYPE array to read the classifier's answers from (region_label / region_conf are
+        then ignored: ck_policy_run_records, no copy of the two strided fields), frame f at records[order[f]] when `order`
+        (int32) is given"""
+        if records is not None:
+            assert records.dtype == REC_DTYPE and records.flags.c_contiguous
+            assert order is None or (order.dtype == np.int32 and order.flags.c_contiguous)
+            n = len(records) if order is None else len(order)
+        else:
+            rl = np.ascontiguousarray(region_label, np.uint8).reshape(-1, 100)
+            rc = np.ascontiguousarray(region_conf, np.float64).reshape(-1, 100)
+            n = len(rl)
+            assert len(rc) == n
         fg = None
         if fgcount is not None:
             fg = np.ascontiguousarray(fgcount, np.int32).reshape(n, 361)
@@ -636,10 +729,14 @@ class PolicyCore:
         b = io.ctypes.data
         while True:
             board = np.ascontiguousarray(board_of(), np.uint8).reshape(361)
-            rcode = lib().ck_policy_run(self._h, n, int(first_counter), rl.ctypes.data_as(C.c_void_p),
-                                        rc.ctypes.data_as(C.c_void_p), None if fg is None else fg.ctypes.data_as(C.c_void_p),
-                                        board.ctypes.data_as(C.c_void_p), C.c_void_p(b), C.c_void_p(b + 4), C.c_void_p(b + 8),
-                                        mv.ctypes.data_as(C.c_void_p), len(mv), C.c_void_p(b + 12))
+            tail = (None if fg is None else fg.ctypes.data_as(C.c_void_p), board.ctypes.data_as(C.c_void_p), C.c_void_p(b),
+                    C.c_void_p(b + 4), C.c_void_p(b + 8), mv.ctypes.data_as(C.c_void_p), len(mv), C.c_void_p(b + 12))
+            if records is not None:
+                rcode = lib().ck_policy_run_records(self._h, n, int(first_counter), records.ctypes.data_as(C.c_void_p),
+                                                    None if order is None else order.ctypes.data_as(C.c_void_p), *tail)
+            else:
+                rcode = lib().ck_policy_run(self._h, n, int(first_counter), rl.ctypes.data_as(C.c_void_p),
+                                            rc.ctypes.data_as(C.c_void_p), *tail)
             if rcode != 0:
                 raise CkError("ck_policy_run: error %d" % rcode)
             if io[2] == 0:

@@ -2,6 +2,7 @@
 // Host-side glue only: argument checks, staging between host and HBM, and the order in
 // which the stage kernels are launched on the context's stream.
 #include <stdarg.h>
+#include <stddef.h>
 
 #include <cfloat>
 #include <cmath>
@@ -239,7 +240,7 @@ int ck_ctx_destroy2(ck_ctx* ctx)
                        &ctx->labels2, &ctx->runs, &ctx->ghost, &ctx->misc, &ctx->bflag, &ctx->comp, &ctx->lists, &ctx->pts, &ctx->accum, &ctx->peaks,
                        &ctx->goban, &ctx->act0, &ctx->act1, &ctx->act2, &ctx->ybuf, &ctx->lblbuf, &ctx->confbuf,
                        &ctx->rlblbuf, &ctx->rconfbuf, &ctx->fgcbuf,
-                       &ctx->out_stage, &ctx->mats,
+                       &ctx->out_stage, &ctx->mats, &ctx->rec_stage,
                        &ctx->cnn.c1w, &ctx->cnn.c1b, &ctx->cnn.c2w, &ctx->cnn.c2b, &ctx->cnn.c3w, &ctx->cnn.c3b,
                        &ctx->cnn.c4w, &ctx->cnn.c4b, &ctx->cnn.d1w, &ctx->cnn.d1b, &ctx->cnn.d2w, &ctx->cnn.d2b,
                        &ctx->cnn.c2w_bf, &ctx->cnn.c3w_bf, &ctx->cnn.c4w_bf, &ctx->cnn.d1w_bf, &ctx->cnn.c1w_f16, &ctx->cnn.d1w_bfp, &ctx->cnn.c1w_q8, &ctx->cnn.c2x_q8, &ctx->cnn.c3x_q8, &ctx->cnn.c4x_q8, &ctx->cnn.d1w_h2,
@@ -258,6 +259,7 @@ int ck_ctx_destroy2(ck_ctx* ctx)
     if (ctx->handover) (void)hipEventDestroy(ctx->handover);
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
     if (ctx->host_pinned2) (void)hipHostFree(ctx->host_pinned2);
+    if (ctx->rec_host) (void)hipHostFree(ctx->rec_host);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CK_OK;
@@ -541,7 +543,17 @@ int ck_cnn_set_mode(ck_ctx* ctx, int mode)
 }
 
 // where the region outputs of a call go (all optional)
-struct RegionOut { uint8_t* label = nullptr; double* conf = nullptr; };
+struct RegionOut { uint8_t* label = nullptr; double* conf = nullptr; ck_frame_record* rec = nullptr; int rec_space = CK_HOST; };
+
+static int ensure_rec_host(ck_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->rec_host_cap) return CK_OK;
+    if (ctx->rec_host) { CK_HIP(ctx, hipHostFree(ctx->rec_host)); ctx->rec_host = nullptr; ctx->rec_host_cap = 0; }
+    bytes += bytes / 4 + 4096;
+    CK_HIP(ctx, hipHostMalloc(&ctx->rec_host, bytes, hipHostMallocDefault));
+    ctx->rec_host_cap = bytes;
+    return CK_OK;
+}
 
 static int cnn_predict_dev(ck_ctx* ctx, const uint8_t* d_goban, int n, float* y, uint8_t* labels, double* conf, int out_space,
                            RegionOut ro = RegionOut())
@@ -566,6 +578,13 @@ static int cnn_predict_dev(ck_ctx* ctx, const uint8_t* d_goban, int n, float* y,
     } else {
         CK_TRY(k_cnn_predict(ctx, d_goban, n, (float*)ctx->ybuf.p, (uint8_t*)ctx->lblbuf.p, (double*)ctx->confbuf.p, nullptr,
                              (uint8_t*)ctx->rlblbuf.p, (double*)ctx->rconfbuf.p));
+    }
+    if (ro.rec && ro.rec_space == CK_DEVICE)
+        CK_TRY(k_records_put_regions(ctx, (const uint8_t*)ctx->rlblbuf.p, (const double*)ctx->rconfbuf.p, n, ro.rec));
+    else if (ro.rec) {           // records in host memory: both region arrays to pinned staging, scattered after the call's sync
+        CK_TRY(ensure_rec_host(ctx, (size_t)n * 900));
+        CK_TRY(ck_from_device(ctx, ctx->rec_host, ctx->rconfbuf.p, (size_t)n * 800, CK_HOST));
+        CK_TRY(ck_from_device(ctx, (uint8_t*)ctx->rec_host + (size_t)n * 800, ctx->rlblbuf.p, (size_t)n * 100, CK_HOST));
     }
     if (ro.label) CK_TRY(ck_from_device(ctx, ro.label, ctx->rlblbuf.p, (size_t)n * 100, out_space));
     if (ro.conf) CK_TRY(ck_from_device(ctx, ro.conf, ctx->rconfbuf.p, (size_t)n * 100 * sizeof(double), out_space));
@@ -672,6 +691,66 @@ int ck_cnn_regions(ck_ctx* ctx, const uint8_t* goban, int n, int in_space, uint8
     RegionOut ro; ro.label = region_label; ro.conf = region_conf;
     CK_TRY(cnn_predict_dev(ctx, (const uint8_t*)d_in, n, nullptr, nullptr, nullptr, out_space, ro));
     return cnn_finish(ctx, (const uint8_t*)d_in, n, nullptr, nullptr, nullptr, out_space, ro);
+    CK_API_END(ctx)
+}
+
+int ck_cnn_regions_records(ck_ctx* ctx, const uint8_t* goban, int n, int in_space, ck_frame_record* rec, int rec_space)
+{
+    CK_API_BEGIN(ctx)
+    if (!ctx) return CK_ERR_ARG;
+    if (!goban || n <= 0 || !rec) return ck_fail(ctx, CK_ERR_ARG, "NULL argument or n <= 0");
+    if (rec_space != CK_HOST && rec_space != CK_DEVICE) return ck_fail(ctx, CK_ERR_ARG, "bad memory space %d", rec_space);
+    CK_HIP(ctx, hipSetDevice(ctx->device));
+    const void* d_in;
+    CK_TRY(ck_to_device(ctx, goban, (size_t)n * 380 * 380 * 3, in_space, ctx->in_stage, &d_in));
+    RegionOut ro; ro.rec = rec; ro.rec_space = rec_space;
+    CK_TRY(cnn_predict_dev(ctx, (const uint8_t*)d_in, n, nullptr, nullptr, nullptr, CK_HOST, ro));
+    CK_TRY(cnn_finish(ctx, (const uint8_t*)d_in, n, nullptr, nullptr, nullptr, CK_HOST, ro));
+    if (rec_space == CK_HOST) {
+        const double* conf = (const double*)ctx->rec_host;
+        const uint8_t* lab = (const uint8_t*)ctx->rec_host + (size_t)n * 800;
+        for (int f = 0; f < n; f++) {
+            memcpy(rec[f].region_conf, conf + (size_t)f * 100, 800);
+            memcpy(rec[f].region_label, lab + (size_t)f * 100, 100);
+        }
+    }
+    return CK_OK;
+    CK_API_END(ctx)
+}
+
+int ck_board_detect_records(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
+                            int hough_thresh, ck_frame_record* rec, int rec_space)
+{
+    CK_API_BEGIN(ctx)
+    CK_TRY(check_img(ctx, bgr, n, h, w));
+    if (!rec) return ck_fail(ctx, CK_ERR_ARG, "rec is NULL");
+    if (rec_space != CK_HOST && rec_space != CK_DEVICE) return ck_fail(ctx, CK_ERR_ARG, "bad memory space %d", rec_space);
+    // the board results are born on the host (K4's boxes, K6's peak order): n packed board halves in pinned memory,
+    // then into the records -- a memcpy per record on the host, one upload + one small kernel for records in HBM
+    const size_t part = offsetof(ck_frame_record, region_conf);
+    const size_t lines_bytes = (size_t)n * CK_REC_LMAX * 2 * sizeof(float), res_bytes = (size_t)n * sizeof(ck_board_result);
+    CK_TRY(ensure_rec_host(ctx, (size_t)n * part + lines_bytes + res_bytes));
+    uint8_t* parts = (uint8_t*)ctx->rec_host;
+    float* lines = (float*)(parts + (size_t)n * part);
+    ck_board_result* res = (ck_board_result*)((uint8_t*)lines + lines_bytes);
+    CK_TRY(ck_board_detect(ctx, bgr, n, h, w, in_space, hough_thresh, lines, CK_REC_LMAX, res));
+    for (int f = 0; f < n; f++) {
+        ck_frame_record* r = (ck_frame_record*)(parts + (size_t)f * part);       // (only the head of it exists here)
+        const int kept = res[f].n_lines < CK_REC_LMAX ? (res[f].n_lines < 0 ? 0 : res[f].n_lines) : CK_REC_LMAX;
+        r->status = res[f].status; r->n_contours = res[f].n_contours; r->n_lines = res[f].n_lines;
+        r->flags = res[f].n_lines > CK_REC_LMAX ? CK_REC_LINES_CUT : 0;
+        r->biggest_area = res[f].biggest_area;
+        memcpy(r->lines, lines + (size_t)f * CK_REC_LMAX * 2, (size_t)kept * 2 * sizeof(float));
+        memset(&r->lines[kept][0], 0, (size_t)(CK_REC_LMAX - kept) * 2 * sizeof(float));
+    }
+    if (rec_space == CK_HOST) {
+        for (int f = 0; f < n; f++) memcpy(&rec[f], parts + (size_t)f * part, part);
+        return CK_OK;
+    }
+    CK_TRY(ck_ensure(ctx, ctx->rec_stage, (size_t)n * part));
+    CK_HIP(ctx, hipMemcpyAsync(ctx->rec_stage.p, parts, (size_t)n * part, hipMemcpyHostToDevice, ctx->stream));
+    CK_TRY(k_records_put_board(ctx, (const uint8_t*)ctx->rec_stage.p, n, rec));
+    return finish(ctx);
     CK_API_END(ctx)
 }
 

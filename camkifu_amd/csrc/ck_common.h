@@ -104,6 +104,11 @@ struct ck_ctx {
     size_t host_pinned_cap = 0;
     void* host_pinned2 = nullptr;    // second arena (contour survey) so that a caller's data in the first one survives
     size_t host_pinned2_cap = 0;
+    // per-frame result records (ck_board_detect_records / ck_cnn_regions_records): pinned staging of one half of n records,
+    // and its device twin for records that live in HBM
+    void* rec_host = nullptr;
+    size_t rec_host_cap = 0;
+    DevBuf rec_stage;
 
     CnnWeights cnn;
     int* cnn_flag_host = nullptr;    // host-mapped flag: the split-precision kernels met a value outside the fp16 range
@@ -256,6 +261,10 @@ int k_mog2_apply(ck_ctx* ctx, Mog2State& st, const uint8_t* d_img, double lr, ui
 int k_mog2_run(ck_ctx* ctx, Mog2State& st, const uint8_t* d_gobans, int n, const double* learning_rates,
                int32_t* d_fgcount, uint8_t* d_last_fg, int skip_row, int skip_col);
 int k_zone_counts(ck_ctx* ctx, const uint8_t* d_mask, int n, int side, int32_t* d_fgcount);
+// per-frame records in HBM (k_records.hip): the board half from n packed 536-byte parts, the stones half from the classifier's
+// contiguous region outputs
+int k_records_put_board(ck_ctx* ctx, const uint8_t* d_parts, int n, ck_frame_record* d_rec);
+int k_records_put_regions(ck_ctx* ctx, const uint8_t* d_rlabel, const double* d_rconf, int n, ck_frame_record* d_rec);
 
 // host geometry (ck_host_geom.cpp)
 void ck_invert3x3(const double* s, double* d);

@@ -1,5 +1,5 @@
 """Fast video-file processing: batches of frames through the stateless GPU core, sharded over the GPUs of
-one node, fixed-size per-frame records gathered over RCCL, then the ORDERED fold on rank 0.
+one node, fixed-size per-frame records gathered TO RANK 0 over RCCL, then the ORDERED fold there.
 
 What shards and what does not.  Per frame, K1..K6 (frame -> Hough lines) and, given a
 transform, K8 + K10..K12 (frame -> the classifier's answer for its 100 regions) are stateless: frame f of a
@@ -13,7 +13,17 @@ The background model (K9, MOG2) is per-pixel state over TIME, so it cannot follo
 by PIXEL instead: with world > 1 every rank keeps the mixtures of a band of intersection rows, receives that
 band of every goban image of the batch in one all-to-all (xGMI), runs the band through the whole batch in frame
 order (ck_mog2_band_run) and contributes its foreground counts to the gather.  With world == 1 the whole chain
-is one call (ck_stones_run)."""
+is one call (ck_stones_run).
+
+Where the records live.  The library writes both halves of a frame's record (ck_frame_record, 1440 bytes) IN PLACE into
+one buffer per shard -- in HBM when the records go through RCCL, in host memory otherwise -- so nothing is packed by
+numpy and nothing crosses PCIe before the gather; only rank 0 brings the gathered records (and the foreground counts) to
+the host, in one copy each.  The other ranks learn a batch's outcome from the transform broadcast (16 doubles) and a
+one-word all-reduce after the background model.
+
+A failed batch (finish() raises on every rank) leaves a gap: the board fold on rank 0 advances over the frames whose
+records are missing as frames without a contour, so the running frame count -- which places the every-4th-frame grouping
+and, in hold-off-aware mode, every rank's plan of the next batch -- stays that of the film."""
 import os
 
 import numpy as np
@@ -22,14 +32,12 @@ from . import capi, cvconf
 from .golib_shim import gsize, E, B, W
 from .stone import nn_manager as nm
 
-LMAX = 64                                    # Hough lines carried per frame record (more are flagged, not fatal)
-FLAG_LINES_CUT, FLAG_FAILED = 1, 2
-
-REC = np.dtype([("status", "<i4"), ("n_contours", "<i4"), ("n_lines", "<i4"), ("flags", "<i4"),
-                ("biggest_area", "<f8"), ("lines", "<f4", (LMAX, 2)),
-                ("region_conf", "<f8", (10, 10)), ("region_label", "u1", (10, 10)), ("pad", "u1", (4,))])
-REC_BYTES = REC.itemsize
+LMAX = capi.REC_LMAX                         # Hough lines carried per frame record (more are flagged, not fatal)
+FLAG_LINES_CUT, FLAG_FAILED = capi.REC_LINES_CUT, capi.REC_FAILED
+REC = capi.REC_DTYPE                         # ck_frame_record (include/camkifu_amd.h)
+REC_BYTES = capi.REC_BYTES
 assert REC_BYTES % 8 == 0
+FLAGS_AT = REC.fields["flags"][1]            # byte offset of a record's flags word
 _SYMBOL = (E, B, W)
 
 
@@ -49,6 +57,22 @@ def pack_records(board, region_label, region_conf, failed=False):
     list of per-frame dicts; region_label (n, 10, 10) u8; region_conf (n, 10, 10) f64 -> REC array (n,).
     Never raises on content: a frame with more than LMAX lines keeps the first LMAX (OpenCV's order = most votes
     first) and is flagged, so that no rank can fail before a collective the others are already waiting in."""
+    dict_form = isinstance(board, (list, tuple)) and (len(board) == 0 or isinstance(board[0], dict))
+    n = len(board) if dict_form else len(board[0])
+    rec = np.zeros(n, REC)
+    if n == 0:
+        return rec
+    fill_board(rec, board)
+    if failed:
+        rec["flags"] |= FLAG_FAILED
+    rec["region_label"] = np.asarray(region_label, np.uint8).reshape(n, 10, 10)
+    rec["region_conf"] = np.asarray(region_conf, np.float64).reshape(n, 10, 10)
+    return rec
+
+
+def fill_board(rec, board):
+    """the board half of the REC rows `rec` (a numpy view, written in place) from what Context.board_detect hands over -- the
+    host-side twin of ck_board_detect_records, for the stand-in contexts of the CPU tests"""
     if isinstance(board, (list, tuple)) and (len(board) == 0 or isinstance(board[0], dict)):
         res = np.zeros(len(board), capi.BOARD_DTYPE)
         lines = np.zeros((len(board), LMAX, 2), np.float32)
@@ -58,20 +82,56 @@ def pack_records(board, region_label, region_conf, failed=False):
             lines[f, :k] = np.asarray(b["lines"], np.float32).reshape(-1, 2)[:k]
     else:
         res, lines = board
-    n = len(res)
-    rec = np.zeros(n, REC)
-    if n == 0:
+    if len(res) == 0:
         return rec
     for name in ("status", "n_contours", "n_lines", "biggest_area"):
         rec[name] = res[name]
-    rec["flags"] = np.where(res["n_lines"] > LMAX, FLAG_LINES_CUT, 0) | (FLAG_FAILED if failed else 0)
+    rec["flags"] = np.where(res["n_lines"] > LMAX, FLAG_LINES_CUT, 0)
     kept = np.minimum(res["n_lines"], LMAX)
     width = min(LMAX, lines.shape[1])
     live = np.arange(width)[None, :] < kept[:, None]
     rec["lines"][:, :width] = np.where(live[..., None], lines[:, :width], np.float32(0))
-    rec["region_label"] = np.asarray(region_label, np.uint8).reshape(n, 10, 10)
-    rec["region_conf"] = np.asarray(region_conf, np.float64).reshape(n, 10, 10)
+    rec["lines"][:, width:] = 0
     return rec
+
+
+def record_buffer(rows, device=None):
+    """`rows` zeroed records in one buffer: a numpy REC array (host), or a torch uint8 tensor (rows, REC_BYTES) on `device`"""
+    if device is None:
+        return np.zeros(rows, REC)
+    import torch
+    return torch.zeros((rows, REC_BYTES), dtype=torch.uint8, device=device)
+
+
+def shard_buffer(n, device=None):
+    """the record buffer of a shard of n frames: row 0 is the shard's HEADER (only its flags word is used: a rank whose
+    shard is empty can still say that it failed), rows 1 .. n the frames' records, and one spare row, so that the first
+    ceil(n_total / world) + 1 rows are what this rank contributes to the gather whatever the deal gave it"""
+    return record_buffer(n + 2, device)
+
+
+def records_view(buf):
+    """a host record buffer (numpy REC array, or uint8 bytes of it) as a REC array"""
+    a = buf if isinstance(buf, np.ndarray) else buf.numpy()
+    return a if a.dtype == REC else a.view(REC).reshape(a.shape[:-1])
+
+
+def board_into(ctx, frames, rows):
+    """K1-K6 of `frames` -> the board half of the record rows, in place; a context without the record entry points (the
+    stand-ins of the CPU tests) answers in the old form and the rows are filled here"""
+    if hasattr(ctx, "board_detect_records"):
+        return ctx.board_detect_records(frames, rows)
+    return fill_board(rows, ctx.board_detect(frames, -1, LMAX, True))
+
+
+def regions_into(ctx, gobans, rows):
+    """K10-K12 of the goban images -> the stones half of the record rows, in place"""
+    if hasattr(ctx, "cnn_regions_records"):
+        return ctx.cnn_regions_records(gobans, rows)
+    lab, conf = ctx.cnn_regions(gobans)
+    rows["region_label"] = np.asarray(GpuCore._host(lab), np.uint8).reshape(len(rows), 10, 10)
+    rows["region_conf"] = np.asarray(GpuCore._host(conf), np.float64).reshape(len(rows), 10, 10)
+    return rows
 
 
 def grid_of(region_label, region_conf=None):
@@ -92,40 +152,71 @@ def grid_of(region_label, region_conf=None):
 
 class _Group:
     """the few collectives the pipeline needs, on whatever backend torch.distributed was initialised with
-    (nccl = RCCL over xGMI on GPUs, gloo on CPU); world == 1 needs no process group at all"""
+    (nccl = RCCL over xGMI on GPUs, gloo on CPU); world == 1 needs no process group at all.
+
+    What is gathered is gathered TO RANK 0 (the rank that folds) and comes to the host there, in one copy; the other
+    ranks bring nothing to the host but the broadcast wire and one flag word per batch.  `host_bytes` counts what each
+    kind of collective brought to THIS rank's host memory (tests hold ranks != 0 to the wire and the flags)."""
 
     def __init__(self, rank, world, device):
         self.rank, self.world, self.device = rank, world, device
+        self.host_bytes = dict(gather=0, bcast=0, flag=0)
 
-    def _t(self, a):
+    def on_wire(self, a):
+        """a numpy array or a torch tensor -> a tensor where the collectives' buffers live (no copy when it is there already)"""
         import torch
-        t = torch.from_numpy(np.ascontiguousarray(a))
-        return t.to(self.device) if self.device is not None else t
+        if isinstance(a, np.ndarray) and a.dtype.fields is not None:
+            a = np.ascontiguousarray(a).view(np.uint8).reshape(a.shape + (a.dtype.itemsize,))       # records: as bytes, no copy
+        t = a if hasattr(a, "is_cuda") else torch.from_numpy(np.ascontiguousarray(a))
+        want = torch.device(self.device) if self.device is not None else torch.device("cpu")
+        return t if t.device == want else t.to(want)
 
-    def all_gather_rows(self, local, per):
-        """each rank contributes `per` rows (padded with zeros) -> (world, per, ...) on every rank"""
+    def gather_rows(self, mine):
+        """every rank contributes the same number of rows (a tensor or an array, any dtype, first axis = rows) -> on rank 0 a
+        numpy uint8 array (world, rows, bytes per row), None elsewhere.  ONE device-to-host copy, on rank 0 only."""
         import torch
         import torch.distributed as dist
-        buf = np.zeros((per,) + local.shape[1:], local.dtype)
-        buf[:len(local)] = local
-        flat = self._t(buf.view(np.uint8).reshape(per, -1))
-        out = torch.empty((self.world * per, flat.shape[1]), dtype=torch.uint8, device=flat.device)
-        dist.all_gather_into_tensor(out, flat)
-        return out.cpu().numpy().reshape(self.world, per, -1).view(local.dtype).reshape((self.world, per) + local.shape[1:])
+        t = self.on_wire(mine)
+        t = t.reshape(t.shape[0], -1)
+        if t.dtype != torch.uint8:
+            t = t.view(torch.uint8)
+        if not t.is_contiguous():
+            t = t.contiguous()
+        if self.rank != 0:
+            dist.gather(t, None, dst=0)
+            return None
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=torch.uint8, device=t.device)
+        dist.gather(t, list(out.unbind(0)), dst=0)
+        self.host_bytes["gather"] += out.numel()
+        return out.cpu().numpy() if out.is_cuda else out.numpy()
 
     def broadcast_array(self, a, src=0):
         import torch.distributed as dist
-        t = self._t(a)
+        t = self.on_wire(a)
         dist.broadcast(t, src)
+        self.host_bytes["bcast"] += t.numel() * t.element_size()
         return t.cpu().numpy()
 
-    def all_to_all_bands(self, send_parts, recv_sizes):
-        """send_parts[d]: torch uint8 tensor (any strides) for rank d; recv_sizes[s]: bytes rank s sends here (both sides
-        can work them out from the batch size) -> list of what every rank sent here.  Each part is copied ONCE, straight
-        into its slot of the send buffer."""
+    def max_flag(self, value):
+        """one int32 word all-reduced with MAX: every rank learns whether (and which) rank raised a flag"""
         import torch
         import torch.distributed as dist
-        sizes = [int(p.numel()) for p in send_parts]
+        t = self.on_wire(np.array([int(value)], np.int32))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self.host_bytes["flag"] += 4
+        return int(t.item())
+
+    def all_to_all_bands(self, send_parts, recv_sizes, self_through_collective=False):
+        """send_parts[d]: torch uint8 tensor (any strides) for rank d; recv_sizes[s]: bytes rank s sends here (both sides
+        can work them out from the batch size) -> list of what every rank sent here.  Each part is copied ONCE, straight
+        into its slot of the send buffer; this rank's own part does not go through the collective at all (a device copy),
+        unless `self_through_collective` (kept for exercising the call with a single rank)."""
+        import torch
+        import torch.distributed as dist
+        me = self.rank
+        own = None if self_through_collective else send_parts[me].contiguous()
+        sizes = [int(p.numel()) if (d != me or own is None) else 0 for d, p in enumerate(send_parts)]
+        recv_sizes = [int(r) if (s != me or own is None) else 0 for s, r in enumerate(recv_sizes)]
         send = torch.empty(sum(sizes), dtype=torch.uint8, device=send_parts[0].device)
         at = 0
         for p, k in zip(send_parts, sizes):
@@ -133,8 +224,12 @@ class _Group:
                 send[at:at + k].view(p.shape).copy_(p)
             at += k
         recv = torch.empty(int(sum(recv_sizes)), dtype=torch.uint8, device=send.device)
-        dist.all_to_all_single(recv, send, [int(r) for r in recv_sizes], sizes)
-        return list(torch.split(recv, [int(r) for r in recv_sizes]))
+        if self.world > 1 or own is None:                     # (the same decision on every rank)
+            dist.all_to_all_single(recv, send, recv_sizes, sizes)
+        parts = list(torch.split(recv, recv_sizes))
+        if own is not None:
+            parts[me] = own.reshape(-1)
+        return parts
 
 
 def rccl_group_options():
@@ -171,23 +266,22 @@ def _device_of(ctx):
     return ctx.device if isinstance(ctx, capi.Context) else None
 
 
-def _take(frames, indices):
-    """the frames with those indices, contiguous (a slice when they are consecutive), COMPLETE when this returns.
-    The gather runs on this thread's current torch stream, but its result goes to a lane thread, which hands it to the
-    library behind ITS current stream (capi.Context._in) -- another stream when this is the exchange thread -- so the
-    gather is waited for here; and its index tensor is kept until then: a freed block is reused by the next allocation on
-    the stream from any thread (round 4: an index tensor recycled into an output buffer under a queued gather)."""
+def _take(frames, indices, keep=None):
+    """-> (the frames with those indices, contiguous; the torch stream their gather was queued on, or None when there is
+    nothing to wait for: a slice of consecutive frames, host arrays).  No host wait: the gather runs on this thread's
+    current torch stream and whoever hands the result to the library on another thread orders the context's stream behind
+    that stream first (Context.wait_stream -- capi._in only knows the consumer thread's own current stream).  The index
+    tensor goes onto `keep` (the batch's ticket holds it until finish())."""
     if len(indices) and indices[-1] - indices[0] + 1 == len(indices):
-        return frames[indices[0]:indices[-1] + 1]
+        return frames[indices[0]:indices[-1] + 1], None
     if hasattr(frames, "index_select"):
         import torch
         index = torch.as_tensor(indices, device=frames.device)
         out = frames.index_select(0, index)
-        if out.is_cuda:
-            torch.cuda.current_stream(out.device).synchronize()
-        del index                                             # only now: the gather has run
-        return out
-    return np.ascontiguousarray(np.asarray(frames)[list(indices)])
+        if keep is not None:
+            keep.append(index)
+        return out, (torch.cuda.current_stream(out.device) if out.is_cuda else None)
+    return np.ascontiguousarray(np.asarray(frames)[list(indices)]), None
 
 
 class BoardFold:
@@ -205,6 +299,7 @@ class BoardFold:
         self.episode = 8                                     # frames the last detection took
         self.recent = [1]                                    # extra grouping rounds the last few detections needed (run_lazy's first request)
         self._run = self._opened = 0                         # frames looked at since the window in progress opened / the count it opened on
+        self._mtx_hull = None                                # the hull the transform in force was derived from (_run_records)
         self.generosity = 1                                  # grouping rounds a window's first request covers beyond the recent maximum
         self.rounds_seen = {}                                # how many detections needed 0, 1, 2 ... extra grouping rounds (diagnostics)
 
@@ -224,15 +319,29 @@ class BoardFold:
             f.corners.frame = self.frame
             hit = f._detect(self.frame, record=dict(status=int(rec["status"]), n_lines=k, lines=np.asarray(rec["lines"])[:k]))
             if hit:
-                try:
-                    f.mtx = capi.get_perspective_transform(np.asarray(f.corners.hull, np.float32), f.transform_dst)
-                    self.hold = self.refresh_frames
-                except (capi.CkError, TypeError, ValueError):
-                    f.mtx = None                             # degenerate quadrilateral: keep looking
+                self._hit()
         f.total_f_processed += 1
         return f.mtx
 
-    def run(self, recs):
+    def _hit(self):
+        """what BoardFinder._doframe does after a detection (board/boardfinder.py:43-48): the transform from the corners'
+        hull; the hold-off starts when there is one"""
+        f = self.finder
+        try:
+            f.mtx = capi.get_perspective_transform(np.asarray(f.corners.hull, np.float32), f.transform_dst)
+            self.hold, self._mtx_hull = self.refresh_frames, f.corners.hull
+        except (capi.CkError, TypeError, ValueError):
+            f.mtx, self._mtx_hull = None, None               # degenerate quadrilateral: keep looking
+
+    def run(self, recs, order=None):
+        """the fold over a batch of records.  A contiguous REC array (what the gather leaves on rank 0; frame f at
+        recs[order[f]] when `order` is given) goes through ck_boardfold_run: the loop over the frames, the hold-off and the
+        per-frame step are the library's, and Python is entered only where the corners change; anything else frame by
+        frame (`step`)."""
+        if isinstance(recs, np.ndarray) and recs.dtype == REC and recs.flags.c_contiguous:
+            return self._run_records(recs, order)
+        if order is not None:
+            recs = [recs[int(j)] for j in order]
         k, n = 0, len(recs)
         while k < n:
             if self.hold > 0:                                # nothing is looked at during the hold-off
@@ -244,6 +353,32 @@ class BoardFold:
                 continue
             self.step(recs[k])
             k += 1
+        return self.mtx
+
+    def _run_records(self, recs, order=None):
+        f, k = self.finder, 0
+        n = len(recs) if order is None else len(order)
+        f.corners.frame = self.frame
+        h, w = self.frame.shape[0], self.frame.shape[1]
+        while k < n:
+            # a hit that does not move the corners re-derives the transform in force from the same hull: the library then
+            # only starts the hold-off and goes on; otherwise (no valid transform from this hull yet) every hit comes back
+            same = self.refresh_frames if (f.mtx is not None and f.corners.hull is not None and f.corners.hull == self._mtx_hull) else -1
+            try:
+                k, count, self.hold, self.seen, self.looked, found, update, centers, stats = f.core.run(
+                    h, w, recs, k, f.total_f_processed, self.hold, self.seen, self.looked, f.corners.hull, order, same)
+            except IndexError as why:                        # (the counters stand where the failing frame left them)
+                _, f.total_f_processed, self.hold, self.seen, self.looked = why.fold_state
+                raise
+            f.total_f_processed = count
+            if stats is not None:
+                f.last_stats = stats
+            if update:                                       # what _detect does with the step's answer (board/bf_auto.py)
+                f.corners.clear()
+                for p in centers:
+                    f.corners.submit(p)
+            if found and (update or same < 0):
+                self._hit()
         return self.mtx
 
     def state(self):
@@ -365,9 +500,11 @@ class StonesFold:
         self.frames_seen = 0                                 # = SfNeural.total_f_processed
         self.refused = []
 
-    def run(self, region_label, region_conf, fgcount):
-        """-> per-frame lists of (kind, [(colour, r, c), ...]) requests, in frame order"""
-        n = len(region_label)
+    def run(self, region_label, region_conf, fgcount, records=None, order=None):
+        """-> per-frame lists of (kind, [(colour, r, c), ...]) requests, in frame order.  `records`: the batch's REC array
+        (frame f at records[order[f]] when `order` is given) -- the policy then reads the classifier's answers from the
+        records where they lie (ck_policy_run_records)"""
+        n = len(region_label) if records is None else (len(records) if order is None else len(order))
         out = [()] * n                     # frames that emit nothing share one empty tuple (no per-frame allocation)
 
         def apply(kind, moves, k):
@@ -383,7 +520,10 @@ class StonesFold:
                     self.sink.bulk_update(named)
             except DeletedError as locked:                   # no user, no deletion watch in a batch run: cannot happen
                 self.refused.append(locked)
-        self.policy.run(self.frames_seen, region_label, region_conf, fgcount, self.sink.board_codes, apply)
+        if records is not None and not (records.dtype == REC and records.flags.c_contiguous):
+            records = records if order is None else records[order]
+            region_label, region_conf, records, order = records["region_label"], records["region_conf"], None, None
+        self.policy.run(self.frames_seen, region_label, region_conf, fgcount, self.sink.board_codes, apply, records=records, order=order)
         self.frames_seen += n
         return out
 
@@ -402,7 +542,10 @@ class GpuCore:
     slices of one goban tensor, and a dedicated context runs the model over it batch after batch (world == 1); with
     world > 1 the goban tensor is handed back for the pixel-sharded exchange instead."""
 
-    def __init__(self, lanes, bg_ctx=None, local_model=True):
+    def __init__(self, lanes, bg_ctx=None, local_model=True, records_device=None):
+        """records_device: where the shard's record buffer lives -- a torch device (HBM: the records go through RCCL from
+        there) or None (host memory: one rank, or collectives on host buffers)"""
+        self.records_device = records_device
         # A context belongs to ONE thread (the library refuses a second one: CK_ERR_STATE).  A lane given without a board
         # context, or a core given without a model context, gets one of its own when the stones context is a real
         # capi.Context; with stand-in contexts (tests) the orphan work shares the stones context AND its thread.
@@ -484,15 +627,17 @@ class GpuCore:
                 self._in_order(seq, lambda: None)            # the batches behind must not wait for it forever
 
     def _batch(self, frames, mtx, rates, take_turn, want_board=True):
+        """-> (the shard's record buffer (shard_buffer: header row, n records written in place by the library, a spare row),
+        foreground counts (n, 19, 19) or None, goban images or None)"""
         n = len(frames)
+        recs = shard_buffer(n, self.records_device)
         if n == 0:
-            return ((np.zeros(0, capi.BOARD_DTYPE), np.zeros((0, LMAX, 2), np.float32)), np.zeros((0, 10, 10), np.uint8),
-                    np.zeros((0, 10, 10)), None, None)
+            return recs, None, None
         cuts = self._cuts(n)
         parts = [frames[cuts[i]:cuts[i + 1]] for i in range(len(self.lanes))]
-        board_f = [pb.submit(cb.board_detect, fr, -1, LMAX, True) if len(fr) and want_board else None
-                   for (pb, _), (cb, _), fr in zip(self.pools, self.lanes, parts)]
-        rl, rc, fg, gobans = np.zeros((n, 10, 10), np.uint8), np.zeros((n, 10, 10)), None, None
+        board_f = [pb.submit(board_into, cb, fr, recs[1 + cuts[i]:1 + cuts[i + 1]]) if len(fr) and want_board else None
+                   for i, ((pb, _), (cb, _), fr) in enumerate(zip(self.pools, self.lanes, parts))]
+        fg, gobans = None, None
         if mtx is not None:
             on_gpu = hasattr(frames, "is_cuda") and frames.is_cuda
             if on_gpu:
@@ -506,26 +651,24 @@ class GpuCore:
                 cs.warp_perspective(fr, mtx, out=view)
                 return view
 
-            def classify(cs, view):
-                lab, conf = cs.cnn_regions(view)
-                return self._host(lab), self._host(conf)
+            def classify(cs, view, lo, hi):
+                regions_into(cs, view, recs[1 + lo:1 + hi])
             warp_f = [ps.submit(stones, cs, fr, cuts[i], cuts[i + 1]) if len(fr) else None
                       for i, ((_, ps), (_, cs), fr) in enumerate(zip(self.pools, self.lanes, parts))]
             views = [f.result() if f is not None else None for f in warp_f]
-            cnn_f = [ps.submit(classify, cs, v) if v is not None else None
-                     for (_, ps), (_, cs), v in zip(self.pools, self.lanes, views)]
+            cnn_f = [ps.submit(classify, cs, v, cuts[i], cuts[i + 1]) if v is not None else None
+                     for i, ((_, ps), (_, cs), v) in enumerate(zip(self.pools, self.lanes, views))]
             if self.local_model:
                 fg_f = take_turn(lambda: self.bg_pool.submit(self._model_run, gobans, rates))
-            for i, f in enumerate(cnn_f):
+            for f in cnn_f:
                 if f is not None:
-                    rl[cuts[i]:cuts[i + 1]], rc[cuts[i]:cuts[i + 1]] = f.result()
+                    f.result()
             if self.local_model:
                 fg, gobans = self._host(fg_f.result()), None
-        if not want_board:                                   # the fold will ask for the records it looks at (run_lazy)
-            return (np.zeros(n, capi.BOARD_DTYPE), np.zeros((n, LMAX, 2), np.float32)), rl, rc, fg, gobans
-        res = [f.result() for f in board_f if f is not None]
-        board = (np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res]))
-        return board, rl, rc, fg, gobans
+        for f in board_f:
+            if f is not None:
+                f.result()
+        return recs, fg, gobans
 
     def _model_run(self, gobans, rates):
         if self._handle is None:
@@ -537,12 +680,28 @@ class _BandExchangeBroken(RuntimeError):
     """this rank could not take part in the band all-to-all at all (not even with blank bands)"""
 
 
+class Gathered:
+    """the records of a whole batch on rank 0 as the gather left them: `rows` (a REC array: rank after rank, each rank's
+    header row first) and `order` (int32: frame f of the batch is rows[order[f]]).  The folds read them in place."""
+    __slots__ = ("rows", "order")
+
+    def __init__(self, rows, order):
+        self.rows, self.order = rows, np.ascontiguousarray(order, np.int32)
+
+    def __len__(self):
+        return len(self.order)
+
+    def in_frame_order(self):
+        return self.rows[self.order]
+
+
 class _Ticket:
     """one batch on its way through the stages: GPU core -> exchange (records, transform, bands, counts) -> stones fold"""
-    __slots__ = ("core", "exchange", "mtx", "rates", "n_total", "frames", "have_mtx", "lazy_fold")
+    __slots__ = ("core", "exchange", "mtx", "rates", "n_total", "frames", "have_mtx", "lazy_fold", "keep")
 
     def __init__(self, core, mtx, rates, n_total, frames):
         self.core, self.exchange, self.lazy_fold = core, None, None
+        self.keep = []                                        # tensors queued work still reads (index tensors of _take): until finish()
         self.mtx, self.rates, self.n_total, self.frames = mtx, rates, n_total, frames
         self.have_mtx = mtx is not None
 
@@ -579,8 +738,14 @@ class FastFilePipeline:
         # a single GPU (tests/test_gpu_multirank.py does, over RCCL)
         self.exchange = world > 1 or bool(force_exchange)
         self._owns_compute = compute is None
+        # the records go through RCCL from HBM: the library writes them there (GpuCore) and nothing is staged on the host;
+        # with one rank, or collectives on host buffers (gloo), they are written in host memory and used from there
+        self.records_device = None
+        if self.exchange and device is not None and str(device).startswith("cuda"):
+            self.records_device = device
         if compute is None:
-            compute = GpuCore(lanes or [(ctx_board, ctx)], bg_ctx=ctx_bg, local_model=not self.exchange)
+            compute = GpuCore(lanes or [(ctx_board, ctx)], bg_ctx=ctx_bg, local_model=not self.exchange,
+                              records_device=self.records_device)
         self.compute = compute
         gpu = getattr(compute, "device", None)
         if gpu is None:
@@ -603,7 +768,7 @@ class FastFilePipeline:
         self.band_model = band_model                          # callable(gobans_band (n, rows, 380, 3), rates) -> counts (n, band, 19)
         self.errors = []
         self.host_seconds = dict(pack=0.0, collectives=0.0, band_model=0.0, fold=0.0, fold_board=0.0, fold_stones=0.0,
-                                 gather=0.0, bcast=0.0, band_exchange=0.0, counts_gather=0.0)
+                                 gather=0.0, bcast=0.0, band_exchange=0.0, counts_gather=0.0, flags=0.0, unpack=0.0)
         # hold-off-aware mode: the GPU core leaves the board path out and the board fold computes, through the lanes' board
         # contexts (on their own threads), only the records it looks at.  One rank: the fold runs on a thread of its own and
         # asks as it goes (_lazy_fold).  Frames dealt across ranks: every rank works out the batch's first request from the
@@ -617,7 +782,9 @@ class FastFilePipeline:
     # ---- pixel-sharded background model (world > 1) -------------------------------------------------------
     def _band_counts(self, gobans, n_total, rates):
         """all-to-all of goban bands, this rank's band through the whole batch in frame order -> its counts
-        (n_total, band rows, 19)"""
+        (n_total, band rows, 19) int32, left where the model put them (HBM with real contexts: they are gathered from there).
+        Stream-ordered: the scatter into frame order is queued behind the collective on this thread's torch stream and the
+        model's context is ordered behind that stream when it takes the tensor (capi.Context._in) -- no host wait."""
         import time
         import torch
         t0 = time.perf_counter()
@@ -645,7 +812,7 @@ class FastFilePipeline:
                 send = [torch.zeros((n_mine, b - a, 380, 3), dtype=torch.uint8, device=self.group.device or "cpu") for a, b in px]
             except Exception as worse:
                 raise _BandExchangeBroken("%s (and no memory for blank bands: %s)" % (why, worse))
-        parts = self.group.all_to_all_bands(send, expect)
+        parts = self.group.all_to_all_bands(send, expect, bool(os.environ.get("CK_BAND_SELF_THROUGH_COLLECTIVE")))
         if late is not None:
             raise late
         if self.world == 1:
@@ -654,15 +821,15 @@ class FastFilePipeline:
             full = torch.empty((n_total, hi - lo, 380, 3), dtype=torch.uint8, device=parts[0].device)
             for src, part in enumerate(parts):                    # frame f of the batch came from rank f mod world
                 full[src::self.world] = part.reshape(-1, hi - lo, 380, 3)
-        if full.is_cuda:
-            torch.cuda.current_stream(full.device).synchronize()
         t1 = time.perf_counter()
         counts = self._band_model()(full, rates)
-        counts = counts.cpu().numpy() if hasattr(counts, "cpu") else np.asarray(counts)
         t2 = time.perf_counter()
         self.host_seconds["band_exchange"] += t1 - t0
         self.host_seconds["band_model"] += t2 - t1
-        return counts.astype(np.int32).reshape(n_total, bands[self.rank][1] - bands[self.rank][0], gsize)
+        rows = bands[self.rank][1] - bands[self.rank][0]
+        if hasattr(counts, "reshape") and hasattr(counts, "is_cuda"):
+            return counts.reshape(n_total, rows, gsize).to(torch.int32)
+        return np.asarray(counts).astype(np.int32).reshape(n_total, rows, gsize)
 
     def _band_model(self):
         """this rank's band of the background model on ITS OWN context: a lane's context belongs to that lane's thread,
@@ -684,17 +851,32 @@ class FastFilePipeline:
         return self.band_model
 
     # ---- one batch --------------------------------------------------------------------------------------
+    def _as_shard(self, out, n_mine):
+        """what a GPU core returns -> (record buffer, counts, gobans).  The built-in core hands over the buffer the library
+        wrote; a `compute` of the old form (board, region_label, region_conf, counts, gobans) -- the stand-ins of the CPU
+        tests -- is packed here"""
+        if len(out) == 3:
+            return out
+        import time
+        t0 = time.perf_counter()
+        board, rl, rc, fg, gobans = out
+        recs = shard_buffer(n_mine)
+        packed = pack_records(board, rl, rc)
+        if len(packed) != n_mine:
+            raise RuntimeError("the GPU core handed back %d records for a shard of %d frames" % (len(packed), n_mine))
+        recs[1:1 + n_mine] = packed
+        self.host_seconds["pack"] += time.perf_counter() - t0
+        return recs, fg, gobans
+
     def _guarded(self, frames, mtx, rates, n_mine, seq):
         try:
             if self.board_lazy:
-                return self.compute(frames, mtx, rates, seq, board=False), None
+                return self._as_shard(self.compute(frames, mtx, rates, seq, board=False), n_mine), None
             if seq is not None:
-                return self.compute(frames, mtx, rates, seq), None
-            return self.compute(frames, mtx, rates), None
+                return self._as_shard(self.compute(frames, mtx, rates, seq), n_mine), None
+            return self._as_shard(self.compute(frames, mtx, rates), n_mine), None
         except Exception as why:                              # never leave the other ranks alone in a collective
-            blank = ((np.zeros(n_mine, capi.BOARD_DTYPE), np.zeros((n_mine, LMAX, 2), np.float32)),
-                     np.zeros((n_mine, 10, 10), np.uint8), np.zeros((n_mine, 10, 10)), None, None)
-            return blank, why
+            return (shard_buffer(n_mine), None, None), why    # (host memory: the GPU may be what failed)
 
     def submit(self, my_frames, n_total):
         """start a batch (my_frames: frames rank, rank + world, ... of it) -> ticket for finish()"""
@@ -721,7 +903,7 @@ class FastFilePipeline:
         import time
         t0 = time.perf_counter()
         try:
-            self._fold_board(np.zeros(t.n_total, REC), t.frames)
+            self._fold_board(np.zeros(t.n_total, REC), t.frames, t.keep)
             return self.board.mtx, None
         except Exception as why:
             return None, why
@@ -748,8 +930,34 @@ class FastFilePipeline:
             finally:
                 self._xstream.synchronize()                   # nothing of this batch is left queued behind the thread
 
+    def _wire_rows(self, recs, rows, failed):
+        """the first `rows` rows of a shard's record buffer = this rank's contribution to the gather, its header row flagged
+        when this rank's GPU core failed"""
+        if failed:
+            if isinstance(recs, np.ndarray):
+                recs[0]["flags"] = FLAG_FAILED
+            else:
+                recs[0, FLAGS_AT] = FLAG_FAILED               # (little-endian int32, the flag fits its first byte)
+        return recs[:rows]
+
+    def _fold_gap(self, n):
+        """rank 0, a batch whose records never arrived: the board fold advances over its frames as frames without a contour
+        (no detection can come of them), so the running count stays the film's"""
+        blank = np.zeros(n, REC)
+        blank["status"] = capi.CK_BOARD_NO_CONTOUR
+        try:
+            self.board.run(blank)
+        except Exception as why:
+            self.errors.append(why)
+
     def _exchange_on_stream(self, t):
-        """-> (records of the whole batch, counts or None, transform after this batch, failure seen by any rank)"""
+        """-> (records of the whole batch in frame order -- rank 0 only, None elsewhere --, foreground counts (rank 0) or None,
+        transform after this batch, failure seen by any rank).
+
+        Collectives of a batch, the same on every rank in the same order: gather of the record buffers to rank 0 ->
+        broadcast of the wire (outcome, transform, fold state: 16 doubles) -> all-to-all of goban bands -> one-word
+        all-reduce (did a band of the background model fail?) -> gather of the counts to rank 0.  Ranks != 0 bring the
+        wire and the flag word to the host, nothing else."""
         import time
         hs = self.host_seconds
         lazy_x = None
@@ -757,144 +965,161 @@ class FastFilePipeline:
             # hold-off-aware board path across ranks: its rounds and the transform broadcast come FIRST -- they need nothing
             # of this batch's GPU core (the board contexts are idle in this mode), so they run under the stones path
             lazy_x = self._lazy_board_exchange(t)
-        (board, rl, rc, fg, gobans), failure = t.core.result()
+        (recs, fg, gobans), failure = t.core.result()
         lazy_fold = t.lazy_fold.result() if t.lazy_fold is not None else None
-        if lazy_x is not None and lazy_x[1]:                   # the board path failed somewhere: every rank leaves here,
-            if failure is not None:                            # before the records gather
-                self.errors.append(failure)
-            return np.zeros(t.n_total, REC), None, self.mtx, True
         if failure is not None:
             self.errors.append(failure)
-        n_total = t.n_total
-        t0 = time.perf_counter()
-        rec = pack_records(board, rl, rc, failed=failure is not None)
-        t1 = time.perf_counter()
-        hs["pack"] += t1 - t0
+        if lazy_x is not None and lazy_x[1]:                   # the board path failed somewhere: every rank leaves here,
+            return None, None, self.mtx, True                  # before the records gather
+        n_total, W = t.n_total, self.world
         if not self.exchange:
-            full, counts, failed = rec, fg, failure is not None
-        else:
-            # row 0 of every rank's contribution is a header: a rank whose shard is empty can still say that it failed
-            per = (n_total + self.world - 1) // self.world
-            mine = np.zeros(len(rec) + 1, REC)
-            mine[0]["flags"] = FLAG_FAILED if failure is not None else 0
-            mine[0]["n_lines"] = len(rec)
-            mine[1:] = rec
-            got = self.group.all_gather_rows(mine, per + 1)
-            full = np.zeros(n_total, REC)
-            for r in range(self.world):
-                k = len(shard_indices(n_total, r, self.world))
-                full[r::self.world] = got[r, 1:1 + k]
-            failed = bool((got[:, 0]["flags"] & FLAG_FAILED).any())
-            t2 = time.perf_counter()
-            hs["gather"] += t2 - t1
-            counts = None
-        if failed:                                             # every rank sees the same flags here, before the band
-            return full, None, self.board.mtx, True            # exchange whose sizes a failed rank could not honour
-        # ordered board fold (rank 0): it needs the records only, so the transform is known -- and on its way to the
-        # other ranks -- before the background model's exchange starts
-        t3 = time.perf_counter()
-        new, fold_error = None, None
-        if lazy_x is not None:
-            new = lazy_x[0]                                    # folded and broadcast already
-        elif lazy_fold is not None:
-            new, fold_error = lazy_fold
-            if fold_error is not None:
-                raise fold_error
-        elif self.rank == 0:
-            try:
+            if failure is not None:
+                if lazy_fold is None:
+                    self._fold_gap(n_total)
+                return None, None, self.board.mtx, True
+            full = records_view(recs)[1:1 + n_total]
+            t3 = time.perf_counter()
+            if lazy_fold is not None:
+                new, fold_error = lazy_fold
+                if fold_error is not None:
+                    raise fold_error
+            else:
                 self._fold_board(full, None)
                 new = self.board.mtx
-            except Exception as why:                           # e.g. the IndexError the reference raises on a 3-vertex hull
-                if not self.exchange:
-                    raise
-                fold_error = why                               # the other ranks are about to wait in the broadcast: tell them
-        t4 = time.perf_counter()
-        hs["fold_board"] += t4 - t3
-        if self.exchange:
-            if lazy_x is None:
-                wire = np.zeros(10)
-                if self.rank == 0 and fold_error is not None:
+            hs["fold_board"] += time.perf_counter() - t3
+            return full, fg, new, False
+        # ---- records to rank 0
+        t1 = time.perf_counter()
+        per = (n_total + W - 1) // W
+        got = self.group.gather_rows(self._wire_rows(recs, per + 1, failure is not None))
+        t2 = time.perf_counter()
+        hs["gather"] += t2 - t1
+        wire, full, fold_error = np.zeros(self.WIRE), None, None
+        if self.rank == 0:
+            bad = [int(r) for r in np.nonzero(got[:, 0, FLAGS_AT] & FLAG_FAILED)[0]]
+            if bad:
+                wire[0] = -2.0
+                if failure is None:
+                    self.errors.append(RuntimeError("the GPU core failed on rank(s) %s" % bad))
+                if lazy_x is None:
+                    self._fold_gap(n_total)
+            else:
+                # frame f of the batch is row 1 + f // W of rank f mod W: the folds read the records where the gather left them
+                f_all = np.arange(n_total, dtype=np.int32)
+                full = Gathered(got.view(REC).reshape(W * (per + 1)), (f_all % W) * (per + 1) + 1 + f_all // W)
+                t3 = time.perf_counter()
+                hs["unpack"] += t3 - t2
+                # ordered board fold: it needs the records only, so the transform is known -- and on its way to the other
+                # ranks -- before the background model's exchange starts
+                new = None
+                if lazy_x is not None:
+                    new = lazy_x[0]                            # folded (and broadcast) already
+                else:
+                    try:
+                        self._fold_board(full, None)
+                        new = self.board.mtx
+                    except Exception as why:                   # e.g. the IndexError the reference raises on a 3-vertex hull
+                        fold_error = why                       # the other ranks are about to wait in the broadcast: tell them
+                        self.errors.append(why)
+                hs["fold_board"] += time.perf_counter() - t3
+                if fold_error is not None:
                     wire[0] = -1.0
-                elif self.rank == 0 and new is not None:
-                    wire[0], wire[1:] = 1.0, np.asarray(new, np.float64).reshape(9)
-                wire = self.group.broadcast_array(wire, 0)
-                if wire[0] < 0:                                # every rank leaves the batch here, before the band exchange
-                    self.errors.append(fold_error if fold_error is not None else RuntimeError("the board fold failed on rank 0"))
-                    return full, None, self.mtx, True
-                new = wire[1:].reshape(3, 3).copy() if wire[0] else None
-                t5 = time.perf_counter()
-                hs["bcast"] += t5 - t4
-            if t.have_mtx:
-                # A rank whose band model fails (a library error, out of memory for the band tensor ...) must not leave
-                # the others waiting: it still joins the counts gather, with a header row that says so, and every rank
-                # leaves the batch together.
-                widest = max(b - a for a, b in band_rows(self.world))
-                slab = np.zeros((1, n_total + 1, widest, gsize), np.int32)               # row 0: header (-1 = failed)
-                band_error = None
-                try:
-                    mine_counts = self._band_counts(gobans, n_total, t.rates)            # (n_total, rows, 19)
-                    slab[0, 1:, :mine_counts.shape[1]] = mine_counts
-                except _BandExchangeBroken:
-                    raise                                     # could not even join the all-to-all: nothing left to keep in step
-                except Exception as why:
-                    band_error = why
-                    slab[0, 0] = -1
-                t6 = time.perf_counter()
-                allc = self.group.all_gather_rows(slab, 1)[:, 0]                         # (world, 1 + n_total, widest, 19)
-                hs["counts_gather"] += time.perf_counter() - t6
-                if (allc[:, 0] < 0).any():
-                    bad = [int(r) for r in np.nonzero((allc[:, 0] < 0).any(axis=(1, 2)))[0]]
-                    self.errors.append(band_error if band_error is not None
-                                       else RuntimeError("the background model's band failed on rank(s) %s" % bad))
-                    return full, None, self.mtx, True
-                counts = np.concatenate([allc[r, 1:, :b - a] for r, (a, b) in enumerate(band_rows(self.world))], 1)
+                elif new is not None:
+                    wire[0], wire[1:10] = 1.0, np.asarray(new, np.float64).reshape(9)
+            wire[10:14] = self.board.state()
+        t4 = time.perf_counter()
+        wire = self.group.broadcast_array(wire, 0)
+        hs["bcast"] += time.perf_counter() - t4
+        if wire[0] < 0:                                        # every rank leaves the batch here, before the band exchange
+            if self.rank != 0:                                 # whose sizes a failed rank could not honour
+                self.errors.append(RuntimeError("the GPU core of a rank failed" if wire[0] == -2.0 else "the board fold failed on rank 0"))
+            return full, None, self.mtx, True
+        new = wire[1:10].reshape(3, 3).copy() if wire[0] == 1.0 else None
+        counts = None
+        if t.have_mtx:
+            # A rank whose band model fails (a library error, out of memory for the band tensor ...) must not leave the
+            # others waiting: it has joined the all-to-all (with blank bands if need be), the flag word says so to
+            # everyone, and every rank leaves the batch together, before the counts gather.
+            band_error, mine_counts = None, None
+            try:
+                mine_counts = self._band_counts(gobans, n_total, t.rates)                # (n_total, rows, 19) int32
+            except _BandExchangeBroken:
+                raise                                         # could not even join the all-to-all: nothing left to keep in step
+            except Exception as why:
+                band_error = why
+            t5 = time.perf_counter()
+            bad = self.group.max_flag(self.rank + 1 if band_error is not None else 0)
+            t6 = time.perf_counter()
+            hs["flags"] += t6 - t5
+            if bad:
+                self.errors.append(band_error if band_error is not None
+                                   else RuntimeError("the background model's band failed on rank %d" % (bad - 1)))
+                return full, None, self.mtx, True
+            import torch
+            bands = band_rows(W)
+            widest = max(b - a for a, b in bands)
+            src = self.group.on_wire(mine_counts).reshape(-1)
+            slab = src
+            if src.numel() != n_total * widest * gsize:        # a narrower band: padded to the widest (equal contributions)
+                slab = torch.zeros(n_total * widest * gsize, dtype=torch.int32, device=src.device)
+                slab[:src.numel()] = src
+            got = self.group.gather_rows(slab.reshape(1, -1))
+            if self.rank == 0:
+                got = got.view(np.int32).reshape(W, -1)
+                counts = np.concatenate([got[r, :n_total * (b - a) * gsize].reshape(n_total, b - a, gsize)
+                                         for r, (a, b) in enumerate(bands)], 1)
+            hs["counts_gather"] += time.perf_counter() - t6
         return full, counts, new, False
 
     # ---- hold-off-aware board path with the frames dealt across ranks ------------------------------------------------
     WIRE = 16                                                 # doubles in front of a request's frame list: kind, 9 transform / count, 4 state
 
-    def _detect_frames(self, frames, idx):
+    def _detect_frames(self, frames, idx, rows, keep=None):
         """K1-K6 of frames[idx] on the lanes' board contexts, each driven from its own lane thread (a context is
-        single-threaded) -> (BOARD_DTYPE array, lines (len(idx), LMAX, 2)) in idx order"""
+        single-threaded) -> the board half of the record rows `rows` (len(idx) of them, host memory or HBM), in idx order"""
         import time
         lanes, pools = self.compute.lanes, self.compute.pools
 
-        def timed_detect(ctx, part):
+        def timed_detect(ctx, part, producer, out):
             t0 = time.perf_counter()
-            out = ctx.board_detect(part, -1, LMAX, True)
-            return out, time.perf_counter() - t0
+            if producer is not None and hasattr(ctx, "wait_stream"):
+                ctx.wait_stream(producer)                     # the gather of `part` was queued on another thread's stream
+            board_into(ctx, part, out)
+            return time.perf_counter() - t0
         t0 = time.perf_counter()
         idx = list(idx)
         k = len(lanes) if len(idx) >= 8 * len(lanes) else 1
         cuts = [round(i * len(idx) / k) for i in range(k + 1)]
-        futs = [pools[i][0].submit(timed_detect, lanes[i][0], _take(frames, idx[cuts[i]:cuts[i + 1]])) for i in range(k)]
+        futs = [pools[i][0].submit(timed_detect, lanes[i][0], *_take(frames, idx[cuts[i]:cuts[i + 1]], keep), rows[cuts[i]:cuts[i + 1]])
+                for i in range(k)]
         got = [f.result() for f in futs]
         hs = self.host_seconds                               # diagnostics: the requests' wall time and the library calls inside
         hs["lazy_fetch"] = hs.get("lazy_fetch", 0.0) + time.perf_counter() - t0
-        hs["lazy_detect"] = hs.get("lazy_detect", 0.0) + max(g[1] for g in got)
-        got = [g[0] for g in got]
-        return np.concatenate([g[0] for g in got]), np.concatenate([g[1] for g in got])
+        hs["lazy_detect"] = hs.get("lazy_detect", 0.0) + max(got)
+        return rows
 
     def _board_round(self, t, idx):
         """One round of the hold-off-aware board path across ranks: frame f of the batch lives on rank f mod world (at
-        index f // world of its shard); this rank computes K1-K6 of the requested frames it owns, ONE all-gather brings the
-        records together -> on rank 0 (rows in idx order, their lines), None elsewhere.  A rank whose board path raises
-        still joins the gather, with a header row that says so: rank 0 then raises, i.e. ends the fold and tells everyone."""
+        index f // world of its shard); this rank computes K1-K6 of the requested frames it owns straight into a record
+        buffer, ONE gather brings the buffers to rank 0 -> there (rows in idx order, their lines), None elsewhere.  A rank
+        whose board path raises still joins the gather, with a header row that says so: rank 0 then raises, i.e. ends the
+        fold and tells everyone."""
         W, r = self.world, self.rank
         per = max(sum(1 for f in idx if f % W == q) for q in range(W))
         mine = [f // W for f in idx if f % W == r]
-        rows = np.zeros(per + 1, REC)
+        buf, failed = record_buffer(per + 1, self.records_device), False
         try:
             if mine:
-                blank = np.zeros((len(mine), 10, 10))
-                rows[1:1 + len(mine)] = pack_records(self._detect_frames(t.frames, mine), blank.astype(np.uint8), blank)
+                self._detect_frames(t.frames, mine, buf[1:1 + len(mine)], t.keep)
         except Exception as why:                               # the peers are about to wait in the gather: join it
-            rows[0]["flags"] = FLAG_FAILED
+            failed = True
             self.errors.append(why)
-        got = self.group.all_gather_rows(rows, per + 1)
-        bad = [int(q) for q in np.nonzero(got[:, 0]["flags"] & FLAG_FAILED)[0]]
+            buf = record_buffer(per + 1)                       # (host memory: the GPU may be what failed)
+        got = self.group.gather_rows(self._wire_rows(buf, per + 1, failed))
         if r != 0:
             return None
+        got = got.view(REC).reshape(W, per + 1)
+        bad = [int(q) for q in np.nonzero(got[:, 0]["flags"] & FLAG_FAILED)[0]]
         if bad:
             raise RuntimeError("the board path (K1-K6) failed on rank(s) %s: %s" % (bad, self.errors[-1:] if 0 in bad else "see their logs"))
         out, at = np.zeros(len(idx), REC), [1] * W
@@ -932,6 +1157,7 @@ class FastFilePipeline:
                     self.group.broadcast_array(req, 0)
                 rounds[0] += 1
                 return self._board_round(t, idx)
+            count0 = self.board.finder.total_f_processed
             try:
                 if self.board.state() != self._board_state:
                     raise RuntimeError("the board fold's state %s is not the one this batch was planned from %s" % (self.board.state(), self._board_state))
@@ -939,6 +1165,19 @@ class FastFilePipeline:
                 new = self.board.mtx
             except Exception as why:
                 err = why
+                # the fold stopped at some frame k < n: it advances over the rest of the batch as frames without a contour, so
+                # that the state broadcast below -- what every rank plans the next batch from -- is that of a film with a
+                # gap, not of a film that is n - k frames short
+                rest = max(0, n - (self.board.finder.total_f_processed - count0))
+
+                def blank(idx):
+                    rows = np.zeros(len(idx), REC)
+                    rows["status"] = capi.CK_BOARD_NO_CONTOUR
+                    return rows, rows["lines"]
+                try:
+                    self.board.run_lazy(rest, blank, plan_ahead=True)
+                except Exception as again:
+                    self.errors.append(again)
             if first and rounds[0] == 0:                       # the fold ended before its first request: the other ranks are
                 try:                                           # in round 0's gather already
                     self._board_round(t, first)
@@ -951,7 +1190,7 @@ class FastFilePipeline:
                 wire[0] = 1.0 if new is not None else 0.0
                 if new is not None:
                     wire[1:10] = np.asarray(new, np.float64).reshape(9)
-            wire[10:14] = self.board.state()                   # also after a failure: the next batch is planned from where the fold stands
+            wire[10:14] = self.board.state()                   # also after a failure: the fold then stands at the end of the batch
             wire = self.group.broadcast_array(wire, 0)
         else:
             if first:
@@ -973,7 +1212,10 @@ class FastFilePipeline:
         """wait for the batch's exchange, publish the transform, stones fold (rank 0) -> the fold's per-frame request
         lists on rank 0, None elsewhere"""
         import time
-        full, counts, new, failed = ticket.exchange.result()
+        try:
+            full, counts, new, failed = ticket.exchange.result()
+        finally:
+            ticket.keep.clear()                                # everything queued for this batch has run
         if failed:
             raise RuntimeError("a rank failed in this batch (GPU core, the board fold on rank 0, or a band of the background "
                                "model): %s" % (self.errors[-1:] or "see its log"))
@@ -981,11 +1223,16 @@ class FastFilePipeline:
         t0 = time.perf_counter()
         emitted = None
         if self.rank == 0:
-            emitted = self.stones.run(full["region_label"], full["region_conf"], counts) if ticket.have_mtx else [()] * len(full)
+            if not ticket.have_mtx:
+                emitted = [()] * len(full)
+            elif isinstance(full, Gathered):
+                emitted = self.stones.run(None, None, counts, records=full.rows, order=full.order)
+            else:
+                emitted = self.stones.run(None, None, counts, records=full)
         hs = self.host_seconds
         hs["fold_stones"] += time.perf_counter() - t0
         hs["fold"] = hs["fold_board"] + hs["fold_stones"]
-        hs["collectives"] = hs["gather"] + hs["bcast"] + hs["band_exchange"] + hs["counts_gather"]
+        hs["collectives"] = hs["gather"] + hs["bcast"] + hs["band_exchange"] + hs["flags"] + hs["counts_gather"]
         self.frames_done += ticket.n_total
         return emitted
 
@@ -1009,14 +1256,15 @@ class FastFilePipeline:
         # leaving on an exception: do not wait for batches in flight (with a dead peer that is the collective timeout)
         self.close(wait=exc_type is None)
 
-    def _fold_board(self, full, frames=None):
+    def _fold_board(self, full, frames=None, keep=None):
         """ordered replay of the board finder on the gathered records of one batch (rank 0); with `frames` (hold-off-aware
         mode) the board records are computed on demand, the wanted frames split over the lanes' board contexts, each
         driven from its own lane thread (a context is single-threaded)"""
         if frames is None:
-            return self.board.run(full)
+            return self.board.run(full.rows, full.order) if isinstance(full, Gathered) else self.board.run(full)
         def fetch(idx):
-            return self._detect_frames(frames, idx)
+            rows = self._detect_frames(frames, idx, record_buffer(len(idx)), keep)
+            return rows, rows["lines"]
         return self.board.run_lazy(len(full), fetch, plan_ahead=os.environ.get("CK_LAZY_PLAN") != "0")      # (developer A/B knob)
 
     def fold(self, full, counts, have_mtx=True, frames=None):
@@ -1024,7 +1272,7 @@ class FastFilePipeline:
         self._fold_board(full, frames)
         if not have_mtx:
             return [()] * len(full)
-        return self.stones.run(full["region_label"], full["region_conf"], counts)
+        return self.stones.run(None, None, counts, records=full)
 
     def process_y4m(self, capture, batch=256, file_fps=None, torch_device=None):
         """Fast processing of a video file (README "Fast video file processing"; frame selection as the reference's

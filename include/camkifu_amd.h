@@ -184,6 +184,34 @@ int ck_stones_run(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_s
                   uint8_t* region_label, double* region_conf, int32_t* fgcount,
                   uint8_t* labels, double* conf, int out_space);
 
+/* ---- the fixed-size per-frame RESULT RECORD of the fast-file path (SURVEY 8e "Collective": labels + conf + n_lines +
+ * lines, Lmax = 64): what the stateless core of one frame leaves for the ordered fold -- the board half is what
+ * BoardFinderAuto._detect reads after the image chain (board/bf_auto.py:76-84, 125-135), the stones half what
+ * NNCache.predict_4_stones reads (stone/nn_cache.py:16-31).  The two entry points below write their half of n records IN
+ * PLACE, in host memory or in HBM (`rec_space`), and leave the other half untouched: with the records in HBM a multi-GPU
+ * host gathers them to the folding rank without a host copy on the other ranks (camkifu_amd/pipeline.py).
+ * lines beyond min(n_lines, CK_REC_LMAX) are zero; flags: CK_REC_LINES_CUT when n_lines > CK_REC_LMAX (the strongest
+ * CK_REC_LMAX lines are kept: OpenCV's order is most votes first). */
+#define CK_REC_LMAX 64
+enum { CK_REC_LINES_CUT = 1, CK_REC_FAILED = 2 };
+typedef struct ck_frame_record {
+    int32_t status;                   /* CK_BOARD_*                                      board half: 536 bytes */
+    int32_t n_contours;
+    int32_t n_lines;
+    int32_t flags;                    /* CK_REC_*                                                             */
+    double  biggest_area;
+    float   lines[CK_REC_LMAX][2];    /* (rho, theta)                                                         */
+    double  region_conf[100];         /* max(y) / sum(y), region (i, j) at i*10+j       stones half: 900 bytes */
+    uint8_t region_label[100];        /* argmax label 0..80                                                   */
+    uint8_t pad[4];
+} ck_frame_record;                    /* 1440 bytes, no implicit padding                                      */
+/* K1..K6 of n frames -> the board half of rec[0 .. n)                                board/bf_auto.py:72-84, 125-135 */
+int ck_board_detect_records(ck_ctx* ctx, const uint8_t* bgr, int n, int h, int w, int in_space,
+                            int hough_thresh, ck_frame_record* rec, int rec_space);
+/* K10..K12 of n goban images -> the stones half of rec[0 .. n)                         stone/nn_cache.py:16-31 */
+int ck_cnn_regions_records(ck_ctx* ctx, const uint8_t* goban, int n, int in_space,
+                           ck_frame_record* rec, int rec_space);
+
 /* ---- K9 sharded by PIXEL for multi-GPU batches: the model `handle` (ck_mog2_create(band_h, 380)) holds a horizontal band
  * of the goban image (a whole number of 20-pixel intersection rows; the last band is the one that ends at pixel row
  * 379).  band: n x band_h x 380 x 3, the band of n consecutive goban images in frame order; counts: n x (band_h/20
@@ -255,6 +283,26 @@ int  ck_boardfold_step(ck_boardfold* bf, int h, int w, int status, const float* 
                        long long frame_counter, const int32_t* cur_hull, int32_t* found, int32_t* update,
                        int32_t* centers, int32_t* n_centers, int32_t* stats);
 
+/* test hooks: Python's round(x, 10) as the fold computes it (integer arithmetic, exact) and by the long way (the decimal
+ * string and back) -- tests hold the two, and CPython's own round, equal */
+double ck_round10(double x);
+double ck_round10_reference(double x);
+/* The same fold over the board halves of n gathered records (ck_frame_record), frames *k_io .. n-1, with the hold-off
+ * after a hit as a FRAME COUNT (the reference's 10 s of wall clock, bf_auto.py:43-49, for a file read at file_fps):
+ * frames inside the hold-off are not looked at; every other frame goes through ck_boardfold_step with *counter_io as
+ * its frame_counter.  order (nullable): frame k's record is recs[order[k]] -- the gather leaves the records rank by
+ * rank, frame f at row (f mod world) * rows_per_rank + 1 + f / world, and the fold reads them where they lie.
+ * Returns with *k_io == n (batch done) or just after the first frame whose step says `update` (outputs as
+ * ck_boardfold_step's): the caller replaces its corners, derives the transform, sets *hold_io after a hit and calls
+ * again with the new hull.  A hit WITHOUT update leaves the corners -- hence the transform -- as they are: the fold then
+ * starts the hold-off itself (*hold_io = hold_after_same_hit) and goes on; hold_after_same_hit < 0 returns such hits too.
+ * seen_looked_io[2]: frames offered / looked at (running totals).  On an error *k_io is the frame that raised it (not
+ * counted), as an exception out of _detect leaves total_f_processed. */
+int  ck_boardfold_run(ck_boardfold* bf, int h, int w, const ck_frame_record* recs, const int32_t* order, int n, int32_t* k_io,
+                      long long* counter_io, int32_t* hold_io, long long* seen_looked_io, const int32_t* cur_hull,
+                      int hold_after_same_hit, int32_t* found, int32_t* update, int32_t* centers, int32_t* n_centers,
+                      int32_t* stats);
+
 /* ---- SfNeural._find after the classifier: predict_all / mark_targets / select_targets / predict_moves /
  *      get_color_ratio / lookback / HeatPoint                                  stone/sf_neural.py:37-244
  * Runs frames [*frame_io, n) of an ordered run.  Per frame: region_label (100 argmax labels 0..80, region (i, j)
@@ -271,6 +319,11 @@ void ck_policy_destroy(ck_policy* p);
 int  ck_policy_run(ck_policy* p, int n, long long first_counter, const uint8_t* region_label,
                    const double* region_conf, const int32_t* fgcount, const uint8_t* board,
                    int32_t* frame_io, int32_t* phase_io, int32_t* kind, int32_t* moves, int cap, int32_t* n_moves);
+/* ck_policy_run reading the classifier's answers from the stones halves of n gathered records where they lie (order as
+ * for ck_boardfold_run, nullable; fgcount stays in frame order): same protocol, same results */
+int  ck_policy_run_records(ck_policy* p, int n, long long first_counter, const ck_frame_record* recs, const int32_t* order,
+                           const int32_t* fgcount, const uint8_t* board,
+                           int32_t* frame_io, int32_t* phase_io, int32_t* kind, int32_t* moves, int cap, int32_t* n_moves);
 /* inspection / test hooks: any out pointer may be NULL.  targets 361 B, heat_color 361 B (0 = no watched prediction),
  * heat_energy 361 int32, heat_conf 361 doubles, flags[2] = {has_sampled, recolour events seen} */
 int  ck_policy_get_state(const ck_policy* p, uint8_t* targets, uint8_t* heat_color, int32_t* heat_energy,

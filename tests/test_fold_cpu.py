@@ -199,3 +199,110 @@ def test_colour_ratio_veto_and_single_suggest():
         c2.set_targets(t)
         c2.run(6, rl, np.full((1, 10, 10), conf), None, lambda: g2.b, g2.apply)
         assert len(g2.log) == expect
+
+
+# ------------------------------------------------------------------------------------------------ round 6: the folds over gathered records
+def test_round10_in_integers_equals_cpython_round():
+    """line_angle rounds its cosine with Python's round(x, 10) (core/imgutil.py:510).  The fold computes it in 128-bit
+    integers; held equal to the long way (decimal string and back) and to CPython's own round on random values, on the
+    half-way cases k + 0.5 (in units of 1e-10) and their neighbouring doubles, and at the ends of the fast path's range."""
+    L = capi.lib()
+    rng = np.random.default_rng(1)
+    vals = list(rng.uniform(-1.0000001, 1.0000001, 40000)) + list(rng.uniform(-1e-9, 1e-9, 4000)) + list(rng.uniform(-1e6, 1e6, 4000))
+    for k in rng.integers(0, 10 ** 10, 8000):
+        x = (int(k) + 0.5) / 1e10
+        for d in (-2, -1, 0, 1, 2):
+            y = x
+            for _ in range(abs(d)):
+                y = np.nextafter(y, np.inf if d > 0 else -np.inf)
+            vals += [float(y), -float(y)]
+    vals += [0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 0.99999999995, 0.5e-10, 1.5e-10, 2.5e-10, 5e-324, 1e-300, 524287.99999999995,
+             524288.0, 1048576.0, 1e15, 1e22, -1e22]
+    for x in vals:
+        x = float(x)
+        a, b, c = L.ck_round10(x), L.ck_round10_reference(x), round(x, 10)
+        assert a == b == c and np.signbit(a) == np.signbit(c), (x, a, b, c)
+    assert L.ck_round10(float("inf")) == float("inf") and np.isnan(L.ck_round10(float("nan")))
+
+
+def _board_records(seed, n, h, w, noise=1):
+    from camkifu_amd.pipeline import REC, LMAX, fill_board
+    rng = np.random.default_rng(seed)
+    sides = _sides(rng, h, w)
+    res, lines = np.zeros(n, capi.BOARD_DTYPE), np.zeros((n, LMAX, 2), np.float32)
+    for f in range(n):
+        if f == n // 2:
+            sides = _sides(rng, h, w)
+        ls = _hough_like(rng, sides, h, w, noise)[:LMAX]
+        res["status"][f] = int(rng.choice([0, 0, 0, 0, 1, 2]))
+        res["n_lines"][f] = len(ls)
+        lines[f, :len(ls)] = ls
+    return fill_board(np.zeros(n, REC), (res, lines))
+
+
+@pytest.mark.parametrize("seed,h,w,refresh", [(1, 1080, 1920, 50), (2, 480, 640, 3), (3, 1080, 1920, 0), (4, 2160, 3840, 17)])
+def test_boardfold_run_over_records_equals_the_frame_by_frame_fold(seed, h, w, refresh):
+    """ck_boardfold_run (the loop over a batch's records, the hold-off and the step in the library; Python entered only
+    where the corners change) against BoardFold.step frame by frame -- the per-frame finder's own _detect: same corners,
+    same transform, same counters after every batch, and the same IndexError where the reference raises one"""
+    from camkifu_amd.pipeline import BoardFold
+    a, b = BoardFold(h, w, refresh_frames=refresh), BoardFold(h, w, refresh_frames=refresh)
+    found = 0
+    for batch in range(6):
+        recs = _board_records(10 * seed + batch, 97 + 31 * batch, h, w)
+        out = []
+        for fold, data in ((a, recs), (b, [dict(status=int(r["status"]), n_lines=int(r["n_lines"]), lines=r["lines"]) for r in recs])):
+            try:
+                fold.run(data)
+                out.append("ok")
+            except IndexError as why:
+                out.append(str(why))
+        assert out[0] == out[1]
+        assert (a.mtx is None) == (b.mtx is None) and (a.mtx is None or np.array_equal(a.mtx, b.mtx))
+        assert a.finder.corners.hull == b.finder.corners.hull
+        assert (a.hold, a.seen, a.looked, a.finder.total_f_processed) == (b.hold, b.seen, b.looked, b.finder.total_f_processed)
+        if out[0] != "ok":                                   # after the reference's failure both folds stand at the same frame;
+            a, b = BoardFold(h, w, refresh_frames=refresh), BoardFold(h, w, refresh_frames=refresh)   # (start over)
+        found += a.mtx is not None
+    assert found >= 1
+
+
+def test_policy_over_records_equals_the_policy_over_arrays():
+    """ck_policy_run_records reads the classifier's answers from the stones halves of the gathered records where they lie;
+    same requests, same state as ck_policy_run on contiguous copies"""
+    from camkifu_amd.pipeline import REC
+    rng = np.random.default_rng(77)
+    n, bg = 300, 20
+    rl, rc, fg = _script(rng, n, bg)
+    recs = np.zeros(n, REC)
+    recs["region_label"], recs["region_conf"] = rl, rc
+    recs["lines"] = rng.random((n, 64, 2))                   # (the board half is somebody else's)
+    g1, g2 = _Goban(), _Goban()
+    c1, c2 = capi.PolicyCore(bg), capi.PolicyCore(bg)
+    c1.run(0, rl, rc, fg, lambda: g1.b, g1.apply)
+    c2.run(0, None, None, fg, lambda: g2.b, g2.apply, records=recs)
+    assert g1.log == g2.log and len(g1.log) >= 3
+    s1, s2 = c1.state(), c2.state()
+    assert all(np.array_equal(s1[k], s2[k]) for k in s1)
+
+
+def test_quiet_frames_leave_the_policy_early_with_the_same_state():
+    """round 6: a frame with no agitated zone, no live target and no watched prediction costs one pass over its 361
+    counts.  Counts just below / at the agitation thresholds of every cell size (400, 380, 361 pixels; 0.5 and 0.7 of the
+    area in the reference's float arithmetic) on every cell: the library's integer thresholds against the oracle's floats."""
+    bg = 0
+    n = 40
+    rl = np.zeros((n, 10, 10), np.uint8)
+    rc = np.full((n, 10, 10), 0.9)
+    fg = np.zeros((n, 19, 19), np.int32)
+    levels = [179, 180, 181, 189, 190, 191, 199, 200, 201, 252, 253, 265, 266, 267, 279, 280, 281]
+    for f in range(2, 2 + len(levels)):
+        fg[f] = levels[f - 2]
+    g1, g3 = _Goban(), _Goban()
+    core, pol = capi.PolicyCore(bg), ol.StonePolicy(bg)
+    for f in range(n):                                       # frame by frame: the targets are compared after every frame
+        core.run(f, rl[f:f + 1], rc[f:f + 1], fg[f:f + 1], lambda: g1.b, lambda kind, mv, fr, f=f: g1.apply(kind, mv, fr + f))
+        pol.frame(f, rl[f].tolist(), rc[f].tolist(), fg[f].tolist(), lambda: g3.b,
+                  lambda req, f=f: g3.apply({"suggest": 1, "bulk": 2}[req[0]], [req[1]] if req[0] == "suggest" else req[1], f))
+        assert np.array_equal(core.state()["targets"], np.array(pol.targets, np.uint8)), f
+    assert core.state()["targets"].max() == 0 and len(g1.log) == len(g3.log)
