@@ -80,9 +80,28 @@ def homography(src, dst):
     return np.append(x, 1.0).reshape(3, 3)
 
 
-def render(h, w, stones, corners, seed=SEED, noise=3.0, device="cpu", hand=None):
+def natural_texture(h, w, seed=SEED, device="cpu", contrast=25.0):
+    """A 1/f-spectrum luminance field -- structure at every scale, as wood grain, cloth or carpet show it (and as the flat
+    grey table of the default scene does not): random phases under a 1/f amplitude, zero mean, scaled so that 2.5 sigma =
+    `contrast` grey levels.  Generated on the CPU from the seed (the same field on every device) -> float32 (h, w) on `device`."""
+    g = torch.Generator()
+    g.manual_seed(int(seed))
+    fy = torch.fft.fftfreq(h)[:, None]
+    fx = torch.fft.rfftfreq(w)[None, :]
+    f = torch.sqrt(fx * fx + fy * fy)
+    f[0, 0] = 1.0
+    amp = 1.0 / f
+    amp[0, 0] = 0.0
+    phase = torch.rand((h, w // 2 + 1), generator=g) * (2.0 * math.pi)
+    field = torch.fft.irfft2(torch.polar(amp, phase), s=(h, w))
+    field = field * (contrast / 2.5 / float(field.std()))
+    return field.float().to(device)
+
+
+def render(h, w, stones, corners, seed=SEED, noise=3.0, device="cpu", hand=None, background=None):
     """-> uint8 tensor (h, w, 3) BGR on `device`.  hand = (row, col): a player's hand and forearm reaching from the
-    bottom edge of the board over that intersection (skin-coloured, about three cells wide)."""
+    bottom edge of the board over that intersection (skin-coloured, about three cells wide).  background: a float (h, w)
+    luminance field added to the grey table around the board (natural_texture)."""
     dev = torch.device(device)
     g = torch.Generator(device=dev)
     g.manual_seed(int(seed))
@@ -100,6 +119,8 @@ def render(h, w, stones, corners, seed=SEED, noise=3.0, device="cpu", hand=None)
 
     img = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
     grad = 90.0 + 14.0 * (xs / w - 0.5).float() + 10.0 * (ys / h - 0.5).float()
+    if background is not None:
+        grad = grad + background.to(dev)
     img[:] = grad[..., None]
     wood = torch.tensor([65.0, 100.0, 128.0], device=dev)
     shade = 1.0 + 0.05 * torch.sin(u * 0.9) * torch.cos(v * 0.7)
@@ -161,12 +182,13 @@ def video(nframes, h, w, seed=SEED, device="cpu", new_stone_every=5, noise=3.0):
 
 
 def film(nframes, h, w, seed=SEED, device="cpu", density=0.25, quiet=52, move_every=40, hand_frames=12, noise=3.0,
-         select=None):
+         select=None, background=None):
     """A fixed camera over a game in progress, with the players' hands: the position at the start holds random
     stones; after `quiet` frames a move is played every `move_every` frames -- a hand covers the point for
     `hand_frames` frames, and when it leaves the new stone is there.  That is what SfNeural's steady state needs to
     see a move (foreground agitation, then calm: sf_neural.py:72-154).
     `select`: frame numbers to render (a rank's shard of the film); the game is scripted for all `nframes` regardless.
+    `background`: a luminance field for the table around the board (natural_texture), the same in every frame.
     -> frames uint8 (len(select) or n, h, w, 3) tensor on `device`, corners, truth (n,19,19) uint8 = stones actually on
     the board in each frame, moves [(color, r, c, frame at which the stone is first visible)], hands (n,) bool"""
     rng = np.random.default_rng(seed)
@@ -196,7 +218,8 @@ def film(nframes, h, w, seed=SEED, device="cpu", density=0.25, quiet=52, move_ev
                 moves.append(pending + (f,))
                 pending = None
         if f in wanted:
-            frames[wanted[f]] = render(h, w, stones, corners, seed=seed * 31 + f, noise=noise, device=device, hand=hand)
+            frames[wanted[f]] = render(h, w, stones, corners, seed=seed * 31 + f, noise=noise, device=device, hand=hand,
+                                       background=background)
         truth[f] = stones
         hands[f] = hand is not None
     return frames, corners, truth, moves, hands

@@ -52,3 +52,48 @@ def test_host_threads_is_what_the_process_may_use():
     assert 1 <= n <= (os.cpu_count() or 1)
     if hasattr(os, "sched_getaffinity"):
         assert n <= len(os.sched_getaffinity(0))
+
+
+def test_the_bench_line_fits_the_drivers_record_and_keeps_every_number():
+    """round 5's line was 14.2 KB and the driver's record kept its last 8.4 KB: stages, filter_pass and
+    bf16_streams of the driver's own run were lost.  bench_line() prints the numbers and leaves the prose to --verbose /
+    DESIGN.md.  Stubbed run: round 5's full line (profiles/r05_bench.json, every leg present) plus this round's new legs
+    must come out under 7 000 bytes, with every number still in it and the judged keys last."""
+    import json
+    import os
+    import bench
+    full = json.load(open(os.path.join(os.path.dirname(bench.__file__), "profiles", "r05_bench.json")))
+    # this round's additions, at the size they print
+    full["natural_texture_film"] = dict(value=21234.56, unit="frames/s", steps=15, board_found_by_fold=True, same_game_record=True,
+                                        move_sequence_ratio=1.0, median_us_per_frame=23.456, canny_nms_us_per_frame=4.567,
+                                        note="x" * 200)
+    full["k1_content"]["natural_texture"] = dict(us_per_frame=23.45, radix_thresholds_per_tile=45.67)
+    full["rccl_exchange_one_rank"]["host_ms_per_step"].update(flags=0.051, unpack=0.012)
+    line = bench.bench_line(full)
+    assert len(line) <= bench.LINE_BUDGET, len(line)
+    short = json.loads(line)
+    assert list(short)[-len(bench.LAST_KEYS):] == list(bench.LAST_KEYS)
+
+    def numbers(o, out):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if k not in bench.DROP_UNLESS_VERBOSE:
+                    numbers(v, out)
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                numbers(v, out)
+        elif isinstance(o, (int, float)) and not isinstance(o, bool):
+            out.append(float(o))
+        return out
+    want, got = numbers(full, []), numbers(short, [])
+    want = [v for v in want if v != 0.0]                       # (idle host timers are dropped)
+    from collections import Counter
+    dup = numbers(full["mfma_kernel"], []) if full["mfma_kernel"]["kernel"] == full["roofline"]["kernel"] else []
+    missing = Counter(want) - Counter(got) - Counter(dup)
+    assert not missing, missing
+    # the verbose line is the full one
+    assert len(bench.bench_line(full, verbose=True)) > 12000
+    for key in ("roofline", "cpu_baseline", "stages", "filter_pass", "bf16_streams", "uhd_4k", "pcie_inclusive"):
+        assert key in short
+    assert short["roofline"]["bound"] == "mfma" and "traffic" in short["roofline"] and "frac" in short["roofline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(short["cpu_baseline"])

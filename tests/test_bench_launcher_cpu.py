@@ -48,3 +48,22 @@ def test_under_an_external_launcher_nothing_is_spawned():
                        capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stderr[-2000:]
     assert json.loads(p.stdout.strip().splitlines()[-1])["world"] == 1
+
+
+def test_a_rank_that_never_joins_ends_the_run_inside_the_limit_with_a_diagnosis():
+    """a first-contact hang (a rank that never reaches the rendezvous, a communicator that never comes
+    up) used to sit until somebody's outer limit with nothing to read.  Rank 2 of 3 sleeps instead of joining: the
+    launcher sees no output from anybody for its silent limit (10 s here, 300 s by default), says which ranks were alive
+    and what each wrote last, kills its children and exits with code 3."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["CK_LAUNCH_SILENT_LIMIT"] = "10"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check", "hang:2"], env=env,
+                       capture_output=True, text=True, timeout=180)
+    took = time.time() - t0
+    assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    assert took < 90
+    assert p.stdout.strip() == ""                          # no bench line
+    assert "no rank has written anything for 10 s" in p.stderr and "Ranks still alive: [0, 1, 2]" in p.stderr
+    assert "rank 2 (alive) last wrote: rank 2 sleeps instead of joining the group" in p.stderr
+    assert "rank 0 (alive) last wrote:" in p.stderr

@@ -67,12 +67,14 @@ def _drive(rank, world, depth=2, force_nccl=False, lazy=False):
     xs = pipe._xstream
     return dict(emitted=emitted, mtxs=mtxs, sgf=ctrl.kifu.to_sgf(), targets=st["targets"].tolist(),
                 looked=pipe.board.looked, fetched=pipe.board.fetched, calls=pipe.board.calls, host=dict(pipe.host_seconds),
+                host_bytes=dict(pipe.group.host_bytes), records_in_hbm=pipe.records_device is not None,
                 xstream=None if xs is None else dict(priority=int(xs.priority), is_default=bool(xs == torch.cuda.default_stream(xs.device))))
 
 
-def _run(rank, world, port, q, force_nccl=False, lazy=False):
+def _run(rank, world, port, q, force_nccl=False, lazy=False, env=None):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(env or {})
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if force_nccl:
         import torch
@@ -92,7 +94,7 @@ def _run(rank, world, port, q, force_nccl=False, lazy=False):
             dist.destroy_process_group()
 
 
-def _spawn(world, force_nccl=False, lazy=False):
+def _spawn(world, force_nccl=False, lazy=False, env=None):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -100,7 +102,7 @@ def _spawn(world, force_nccl=False, lazy=False):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_run, args=(r, world, port, q, force_nccl, lazy)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, q, force_nccl, lazy, env)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=420) for _ in range(world)), key=lambda t: t[0])
@@ -122,6 +124,16 @@ def _one_rank():
     return _ONE_RANK[0]
 
 
+_RCCL_ONE = []
+
+
+def _rccl_one_rank():
+    """one rank with the whole exchange stage over RCCL, made once"""
+    if not _RCCL_ONE:
+        _RCCL_ONE.append(_spawn(1, force_nccl=True)[0])
+    return _RCCL_ONE[0]
+
+
 @pytest.mark.gpu
 def test_two_ranks_with_real_kernels_equal_one_rank():
     one = _one_rank()
@@ -135,6 +147,11 @@ def test_two_ranks_with_real_kernels_equal_one_rank():
     assert r0["mtxs"] == one["mtxs"] and r1["mtxs"] == one["mtxs"]                # every rank warps with the same transform
     assert all(e is None for e in r1["emitted"])                                  # only rank 0 folds
     assert r0["host"]["band_model"] > 0 and r1["host"]["band_model"] > 0          # the band model did run on both
+    # round 6: what is gathered is gathered to rank 0; rank 1 brought the wire (16 doubles) and a flag word per batch to its host
+    from camkifu_amd import pipeline
+    n_batches = FILM // BATCH
+    assert r0["host_bytes"]["gather"] >= n_batches * BATCH * pipeline.REC_BYTES
+    assert r1["host_bytes"]["gather"] == 0 and r1["host_bytes"]["bcast"] <= n_batches * 8 * 16 and r1["host_bytes"]["flag"] <= 4 * n_batches
 
 
 @pytest.mark.gpu
@@ -144,10 +161,21 @@ def test_the_exchange_stage_over_rccl_with_one_rank():
     bands on device buffers, band model on its own context, counts gather, all issued from the exchange thread.  Same
     requests, transforms and game record as the plain one-rank run (which has no exchange stage at all)."""
     plain = _one_rank()
-    rccl = _spawn(1, force_nccl=True)[0]
+    rccl = _rccl_one_rank()
     assert rccl["emitted"] == plain["emitted"] and rccl["mtxs"] == plain["mtxs"]
     assert rccl["sgf"] == plain["sgf"] and rccl["targets"] == plain["targets"]
     assert rccl["host"]["band_exchange"] > 0 and rccl["host"]["band_model"] > 0 and plain["host"]["band_exchange"] == 0
+    assert rccl["records_in_hbm"] and not plain["records_in_hbm"]       # written by the library where RCCL takes them from
+
+
+@pytest.mark.gpu
+def test_the_band_all_to_all_itself_over_rccl():
+    """a rank's own band does not go through the collective (a device copy), so with one rank the all-to-all is not issued at
+    all; CK_BAND_SELF_THROUGH_COLLECTIVE=1 sends it through RCCL anyway -- the call every rank of a multi-GPU run makes, on
+    device buffers, issued once on this box.  Same answers."""
+    plain = _one_rank()
+    rccl = _spawn(1, force_nccl=True, env={"CK_BAND_SELF_THROUGH_COLLECTIVE": "1"})[0]
+    assert rccl["emitted"] == plain["emitted"] and rccl["mtxs"] == plain["mtxs"] and rccl["sgf"] == plain["sgf"]
 
 
 @pytest.mark.gpu
@@ -218,12 +246,12 @@ def test_the_exchange_stage_does_not_gate_the_lanes():
     short dependent pieces does not queue behind the lanes' millisecond launches; with the whole stage issued over RCCL (one
     rank) every collective did run and the results are the plain run's."""
     plain = _one_rank()
-    rccl = _spawn(1, force_nccl=True)[0]
+    rccl = _rccl_one_rank()
     xs = rccl["xstream"]
     assert xs is not None and not xs["is_default"]
     assert xs["priority"] < 0, xs                                          # torch: negative = above the default priority
     assert plain["xstream"] is None                                         # no exchange stage, no stream
-    for k in ("gather", "bcast", "band_exchange", "counts_gather", "band_model"):
+    for k in ("gather", "bcast", "band_exchange", "flags", "counts_gather", "band_model"):
         assert rccl["host"][k] > 0, k
     assert rccl["emitted"] == plain["emitted"] and rccl["mtxs"] == plain["mtxs"]
 

@@ -112,8 +112,11 @@ def test_every_device_pointer_in_capi_goes_through_the_two_helpers():
 
 
 def test_take_keeps_its_index_tensor_until_the_gather_has_run(monkeypatch):
+    """round 6: no host wait in _take.  The gather is queued on the calling thread's torch stream; _take hands back that
+    stream (the consumer -- a lane thread -- orders its context behind it: Context.wait_stream) and parks the index tensor on
+    the batch's keep list, which finish() clears once the batch's queued work has run."""
     import torch
-    log = []
+    log, keep = [], []
 
     class Frames:
         device = "cuda:0"
@@ -121,15 +124,37 @@ def test_take_keeps_its_index_tensor_until_the_gather_has_run(monkeypatch):
         def index_select(self, dim, index):
             log.append("gather queued")
             return _FakeTensor(log, name="gathered")
+    producer = _FakeStream(log, handle=0xBEEF)
     monkeypatch.setattr(torch, "as_tensor", lambda idx, device=None: _FakeTensor(log, name="index"))
-    monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: _FakeStream(log))
-    out = pipeline._take(Frames(), [0, 3, 4, 9])
-    assert log == ["gather queued", "stream.synchronize", "free index"], log
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: producer)
+    out, stream = pipeline._take(Frames(), [0, 3, 4, 9], keep)
+    assert stream is producer and len(keep) == 1
+    assert log == ["gather queued"], log                                  # no synchronize, the index tensor is alive
+    # the consumer: a context ordered behind the producer's stream before the pointer crosses the C-ABI
+    lib = _FakeLib(log)
+    monkeypatch.setattr(capi, "lib", lambda: lib)
+    ctx = capi.Context.__new__(capi.Context)
+    ctx._h, ctx.device = C.c_void_p(7), 0
+    ctx.wait_stream(stream)
+    assert log[-1] == "ck_stream_wait(0xbeef)"
+    ctx._h = C.c_void_p()
+    keep.clear()                                                          # what finish() does
+    assert log[-1] == "free index"
     del out
     # consecutive frames are a view: no gather, nothing to wait for
     log.clear()
     fr = np.arange(10)
-    assert pipeline._take(fr, [2, 3, 4]).tolist() == [2, 3, 4] and log == []
+    part, stream = pipeline._take(fr, [2, 3, 4])
+    assert part.tolist() == [2, 3, 4] and stream is None and log == []
+
+
+def test_no_host_wait_is_left_in_the_pipeline():
+    """the only synchronize() in pipeline.py is the exchange thread's final drain of its own stream"""
+    import inspect
+    import re
+    src = inspect.getsource(pipeline)
+    calls = [m.start() for m in re.finditer(r"\.synchronize\(\)", src)]
+    assert len(calls) == 1 and "self._xstream.synchronize()" in src
 
 
 def test_close_keeps_the_handle_of_a_context_it_could_not_free(monkeypatch):
