@@ -161,6 +161,27 @@ class _Group:
     def __init__(self, rank, world, device):
         self.rank, self.world, self.device = rank, world, device
         self.host_bytes = dict(gather=0, bcast=0, flag=0)
+        self._landing = {}                                    # free pinned host buffers the gathers land in, by (shape, dtype)
+
+    def _to_host(self, t, lease):
+        """a device tensor -> numpy, through PINNED memory (one DMA, no staging through a pageable bounce buffer).  The
+        buffer is taken from a free list (allocated when that is empty: a handful over a run) and noted on `lease`; whoever
+        holds the lease gives the buffers back (release) when nothing reads the arrays any more -- a batch's gathered records
+        are read by its folds while the next batches are being gathered."""
+        import torch
+        if not t.is_cuda:
+            return t.numpy()
+        key = (tuple(t.shape), t.dtype)
+        free = self._landing.setdefault(key, [])
+        buf = free.pop() if free else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        lease.append((key, buf))
+        buf.copy_(t)                                          # (blocking: complete when it returns)
+        return buf.numpy()
+
+    def release(self, lease):
+        while lease:
+            key, buf = lease.pop()
+            self._landing.setdefault(key, []).append(buf)
 
     def on_wire(self, a):
         """a numpy array or a torch tensor -> a tensor where the collectives' buffers live (no copy when it is there already)"""
@@ -171,9 +192,10 @@ class _Group:
         want = torch.device(self.device) if self.device is not None else torch.device("cpu")
         return t if t.device == want else t.to(want)
 
-    def gather_rows(self, mine):
+    def gather_rows(self, mine, lease):
         """every rank contributes the same number of rows (a tensor or an array, any dtype, first axis = rows) -> on rank 0 a
-        numpy uint8 array (world, rows, bytes per row), None elsewhere.  ONE device-to-host copy, on rank 0 only."""
+        numpy uint8 array (world, rows, bytes per row), None elsewhere.  ONE device-to-host copy, on rank 0 only, into a
+        pinned buffer noted on `lease` (see _to_host)."""
         import torch
         import torch.distributed as dist
         t = self.on_wire(mine)
@@ -188,23 +210,32 @@ class _Group:
         out = torch.empty((self.world,) + tuple(t.shape), dtype=torch.uint8, device=t.device)
         dist.gather(t, list(out.unbind(0)), dst=0)
         self.host_bytes["gather"] += out.numel()
-        return out.cpu().numpy() if out.is_cuda else out.numpy()
+        return self._to_host(out, lease)
 
     def broadcast_array(self, a, src=0):
+        """-> the source's array on every rank; the source itself reads nothing back (it holds the array)"""
         import torch.distributed as dist
         t = self.on_wire(a)
         dist.broadcast(t, src)
+        if self.rank == src:
+            return np.asarray(a)
         self.host_bytes["bcast"] += t.numel() * t.element_size()
         return t.cpu().numpy()
 
-    def max_flag(self, value):
-        """one int32 word all-reduced with MAX: every rank learns whether (and which) rank raised a flag"""
-        import torch
+    def max_flag_start(self, value):
+        """one int32 word all-reduced with MAX: every rank learns whether (and which) rank raised a flag.  Issued here, read
+        with max_flag_read -- after whatever else the caller queues behind it, so that ONE host wait covers both"""
         import torch.distributed as dist
         t = self.on_wire(np.array([int(value)], np.int32))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t
+
+    def max_flag_read(self, t):
         self.host_bytes["flag"] += 4
         return int(t.item())
+
+    def max_flag(self, value):
+        return self.max_flag_read(self.max_flag_start(value))
 
     def all_to_all_bands(self, send_parts, recv_sizes, self_through_collective=False):
         """send_parts[d]: torch uint8 tensor (any strides) for rank d; recv_sizes[s]: bytes rank s sends here (both sides
@@ -697,11 +728,12 @@ class Gathered:
 
 class _Ticket:
     """one batch on its way through the stages: GPU core -> exchange (records, transform, bands, counts) -> stones fold"""
-    __slots__ = ("core", "exchange", "mtx", "rates", "n_total", "frames", "have_mtx", "lazy_fold", "keep")
+    __slots__ = ("core", "exchange", "mtx", "rates", "n_total", "frames", "have_mtx", "lazy_fold", "keep", "landing")
 
     def __init__(self, core, mtx, rates, n_total, frames):
         self.core, self.exchange, self.lazy_fold = core, None, None
         self.keep = []                                        # tensors queued work still reads (index tensors of _take): until finish()
+        self.landing = []                                     # pinned host buffers the batch's gathers landed in: back to the pool at finish()
         self.mtx, self.rates, self.n_total, self.frames = mtx, rates, n_total, frames
         self.have_mtx = mtx is not None
 
@@ -991,7 +1023,7 @@ class FastFilePipeline:
         # ---- records to rank 0
         t1 = time.perf_counter()
         per = (n_total + W - 1) // W
-        got = self.group.gather_rows(self._wire_rows(recs, per + 1, failure is not None))
+        got = self.group.gather_rows(self._wire_rows(recs, per + 1, failure is not None), t.landing)
         t2 = time.perf_counter()
         hs["gather"] += t2 - t1
         wire, full, fold_error = np.zeros(self.WIRE), None, None
@@ -1047,28 +1079,35 @@ class FastFilePipeline:
                 raise                                         # could not even join the all-to-all: nothing left to keep in step
             except Exception as why:
                 band_error = why
+            # the flag word and the counts are queued one behind the other and read with ONE host wait (rank 0: the counts'
+            # copy to the host; the others: the flag); a rank whose band failed contributes zeros nobody will read
+            import torch
             t5 = time.perf_counter()
-            bad = self.group.max_flag(self.rank + 1 if band_error is not None else 0)
+            flag = self.group.max_flag_start(self.rank + 1 if band_error is not None else 0)
             t6 = time.perf_counter()
             hs["flags"] += t6 - t5
-            if bad:
-                self.errors.append(band_error if band_error is not None
-                                   else RuntimeError("the background model's band failed on rank %d" % (bad - 1)))
-                return full, None, self.mtx, True
-            import torch
             bands = band_rows(W)
             widest = max(b - a for a, b in bands)
+            if mine_counts is None:
+                mine_counts = np.zeros((n_total, bands[self.rank][1] - bands[self.rank][0], gsize), np.int32)
             src = self.group.on_wire(mine_counts).reshape(-1)
             slab = src
             if src.numel() != n_total * widest * gsize:        # a narrower band: padded to the widest (equal contributions)
                 slab = torch.zeros(n_total * widest * gsize, dtype=torch.int32, device=src.device)
                 slab[:src.numel()] = src
-            got = self.group.gather_rows(slab.reshape(1, -1))
+            got = self.group.gather_rows(slab.reshape(1, -1), t.landing)
+            t7 = time.perf_counter()
+            hs["counts_gather"] += t7 - t6
+            bad = self.group.max_flag_read(flag)
+            hs["flags"] += time.perf_counter() - t7
+            if bad:
+                self.errors.append(band_error if band_error is not None
+                                   else RuntimeError("the background model's band failed on rank %d" % (bad - 1)))
+                return full, None, self.mtx, True
             if self.rank == 0:
                 got = got.view(np.int32).reshape(W, -1)
                 counts = np.concatenate([got[r, :n_total * (b - a) * gsize].reshape(n_total, b - a, gsize)
                                          for r, (a, b) in enumerate(bands)], 1)
-            hs["counts_gather"] += time.perf_counter() - t6
         return full, counts, new, False
 
     # ---- hold-off-aware board path with the frames dealt across ranks ------------------------------------------------
@@ -1115,18 +1154,22 @@ class FastFilePipeline:
             failed = True
             self.errors.append(why)
             buf = record_buffer(per + 1)                       # (host memory: the GPU may be what failed)
-        got = self.group.gather_rows(self._wire_rows(buf, per + 1, failed))
+        lease = []
+        got = self.group.gather_rows(self._wire_rows(buf, per + 1, failed), lease)
         if r != 0:
             return None
-        got = got.view(REC).reshape(W, per + 1)
-        bad = [int(q) for q in np.nonzero(got[:, 0]["flags"] & FLAG_FAILED)[0]]
-        if bad:
-            raise RuntimeError("the board path (K1-K6) failed on rank(s) %s: %s" % (bad, self.errors[-1:] if 0 in bad else "see their logs"))
-        out, at = np.zeros(len(idx), REC), [1] * W
-        for j, f in enumerate(idx):
-            out[j] = got[f % W, at[f % W]]
-            at[f % W] += 1
-        return out, out["lines"]
+        try:
+            got = got.view(REC).reshape(W, per + 1)
+            bad = [int(q) for q in np.nonzero(got[:, 0]["flags"] & FLAG_FAILED)[0]]
+            if bad:
+                raise RuntimeError("the board path (K1-K6) failed on rank(s) %s: %s" % (bad, self.errors[-1:] if 0 in bad else "see their logs"))
+            out, at = np.zeros(len(idx), REC), [1] * W
+            for j, f in enumerate(idx):
+                out[j] = got[f % W, at[f % W]]
+                at[f % W] += 1
+            return out, out["lines"]
+        finally:
+            self.group.release(lease)                          # (copied out: the landing buffer is free again)
 
     def _lazy_board_exchange(self, t):
         """The board fold of one batch in hold-off-aware mode with an exchange stage (reference: no K1-K6 during the hold-off
@@ -1213,22 +1256,25 @@ class FastFilePipeline:
         lists on rank 0, None elsewhere"""
         import time
         try:
-            full, counts, new, failed = ticket.exchange.result()
+            try:
+                full, counts, new, failed = ticket.exchange.result()
+            finally:
+                ticket.keep.clear()                            # everything queued for this batch has run
+            if failed:
+                raise RuntimeError("a rank failed in this batch (GPU core, the board fold on rank 0, or a band of the background "
+                                   "model): %s" % (self.errors[-1:] or "see its log"))
+            self.mtx = new
+            t0 = time.perf_counter()
+            emitted = None
+            if self.rank == 0:
+                if not ticket.have_mtx:
+                    emitted = [()] * len(full)
+                elif isinstance(full, Gathered):
+                    emitted = self.stones.run(None, None, counts, records=full.rows, order=full.order)
+                else:
+                    emitted = self.stones.run(None, None, counts, records=full)
         finally:
-            ticket.keep.clear()                                # everything queued for this batch has run
-        if failed:
-            raise RuntimeError("a rank failed in this batch (GPU core, the board fold on rank 0, or a band of the background "
-                               "model): %s" % (self.errors[-1:] or "see its log"))
-        self.mtx = new
-        t0 = time.perf_counter()
-        emitted = None
-        if self.rank == 0:
-            if not ticket.have_mtx:
-                emitted = [()] * len(full)
-            elif isinstance(full, Gathered):
-                emitted = self.stones.run(None, None, counts, records=full.rows, order=full.order)
-            else:
-                emitted = self.stones.run(None, None, counts, records=full)
+            self.group.release(ticket.landing)                 # nothing reads the gathered records after the folds
         hs = self.host_seconds
         hs["fold_stones"] += time.perf_counter() - t0
         hs["fold"] = hs["fold_board"] + hs["fold_stones"]

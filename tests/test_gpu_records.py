@@ -67,10 +67,13 @@ def test_more_lines_than_a_record_holds_are_flagged_and_the_strongest_kept(setup
     from camkifu_amd import capi
     ctx, frames, torch = setup
     fr = frames[:2].cuda()
-    res, lines = ctx.board_detect(fr, 40, 1024, raw=True)
+    for thresh in (24, 12, 6):
+        res, lines = ctx.board_detect(fr, thresh, 4096, raw=True)
+        if res["n_lines"].max() > capi.REC_LMAX:
+            break
     assert res["n_lines"].max() > capi.REC_LMAX
     rec = _filled(2, "hbm", torch)
-    ctx.board_detect_records(fr, rec, hough_thresh=40)
+    ctx.board_detect_records(fr, rec, hough_thresh=thresh)
     got = _host(rec, torch)
     assert np.array_equal(got["n_lines"], res["n_lines"])
     cut = res["n_lines"] > capi.REC_LMAX
