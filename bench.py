@@ -715,7 +715,7 @@ def main():
                 lazy.mtx = M_true
             same = lazy.process_batch(frames, n_total) == requests
             k = max(4, args.steps // 2)
-            print("[bench] hold-off-aware leg: timed steps start", file=sys.stderr, flush=True)      # (tools/lazy_laps.py cuts here)
+            print("[bench] hold-off-aware leg: timed steps start", file=sys.stderr, flush=True)      # (tools/attic/lazy_laps.py cuts here)
             dlz = timed(lazy, k, 2, frames)
             print("[bench] hold-off-aware leg: timed steps end", file=sys.stderr, flush=True)
             lazy.close()

@@ -493,7 +493,8 @@ __global__ __launch_bounds__(256) void fc1_bf16_kernel(const uint16_t* __restric
 {
 #pragma clang fp contract(off)
     constexpr int KIN = 3456, NOUT = 160, KC = 128, NCH = KIN / KC, KS = KIN / 32, RSH = KC + 8;   // 272-byte LDS rows
-    constexpr int SPC = KC / 32;                     // k-steps per chunk (even: the 2-slot weight ring stays in phase)
+    constexpr int SPC = KC / 32;                     // k-steps per chunk = slots of the weight ring (wf[SPC][3], slot = k-step within the chunk:
+                                                     // wload(ks, s + SPC) refills a slot with the same k-step of the next chunk)
     constexpr int NLD = 64 * (KC / 8) / 256;         // 16-byte loads per thread and chunk
     __shared__ __attribute__((aligned(16))) uint16_t lds[64 * RSH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;

@@ -761,7 +761,8 @@ int k_cnn_q8_pack(ck_ctx* ctx, const float* k1, const float* k2, const float* k3
         for (int i = 0; i < 5; i++) {
             pr.push_back({Unit{i, 0, 0}, Unit{i, 1, 0}});
             pr.push_back({Unit{i, 2, 0}, Unit{i, 3, 0}});
-            pr.push_back({Unit{i, 4, 0}, Unit{-1, 0, 0}});       // (not used since the last column's taps are paired vertically:)
+            pr.push_back({Unit{i, 4, 0}, Unit{-1, 0, 0}});       // (not read by the kernel -- the last column's taps are paired vertically,
+                                                                 //  below -- but the kernel's fragment index is 3 i + pair: the slot stays)
         }
         pr.push_back({Unit{0, 4, 0}, Unit{1, 4, 0}});
         pr.push_back({Unit{2, 4, 0}, Unit{3, 4, 0}});
@@ -772,7 +773,7 @@ int k_cnn_q8_pack(ck_ctx* ctx, const float* k1, const float* k2, const float* k3
         std::vector<std::pair<Unit, Unit>> pr;
         for (int i = 0; i < 3; i++) {
             pr.push_back({Unit{i, 0, 0}, Unit{i, 1, 0}});
-            pr.push_back({Unit{i, 2, 0}, Unit{-1, 0, 0}});       // (not used: the vertical pairs below)
+            pr.push_back({Unit{i, 2, 0}, Unit{-1, 0, 0}});       // (not read: the vertical pairs below; kept for the fragment index 2 i + pair)
         }
         pr.push_back({Unit{0, 2, 0}, Unit{1, 2, 0}});
         pr.push_back({Unit{2, 2, 0}, Unit{-1, 0, 0}});

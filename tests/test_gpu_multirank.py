@@ -240,7 +240,7 @@ def test_bench_from_the_plain_command_with_two_ranks():
 @pytest.mark.gpu
 def test_the_exchange_stage_does_not_gate_the_lanes():
     """The mechanism, not a wall-clock ratio (the ratio's failure case sat within one sigma of its threshold; the
-    measured ratios stay in tools/exchange_runs.sh and in the bench line's `rccl_exchange_one_rank`).  The exchange thread's
+    measured ratios stay in tools/attic/exchange_runs.sh and in the bench line's `rccl_exchange_one_rank`).  The exchange thread's
     torch work and its waits for the collectives sit on that thread's OWN stream -- never torch's default stream, which every
     lane thread orders its calls behind (capi._in) -- and that stream is a HIGH-PRIORITY one, so that the stage's chain of
     short dependent pieces does not queue behind the lanes' millisecond launches; with the whole stage issued over RCCL (one

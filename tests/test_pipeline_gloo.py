@@ -348,7 +348,7 @@ def _failing_rank(rank, world, port, q, bad_rank, n_total, fold_fails=False, ban
                 outcome.append("ok")
             except RuntimeError as why:
                 outcome.append("raised: " + str(why)[:40])
-        q.put((rank, outcome, pipe.mtx is not None))
+        q.put((rank, outcome, pipe.mtx is not None, int(pipe.board.finder.total_f_processed)))
     finally:
         dist.destroy_process_group()
 
@@ -373,10 +373,11 @@ def test_a_failing_rank_makes_every_rank_raise_instead_of_hanging(bad_rank, n_to
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, outcome, has_mtx in res:
+    for rank, outcome, has_mtx, counted in res:
         assert outcome[0] == outcome[1] == outcome[3] == "ok", (rank, outcome)
         assert outcome[2].startswith("raised: a rank failed"), (rank, outcome)
         assert has_mtx
+    assert res[0][3] == 4 * n_total                            # the failed batch is a gap in the film, not a shorter film
 
 
 @pytest.mark.parametrize("where", ["in the model", "before the all-to-all"])
@@ -399,7 +400,7 @@ def test_a_band_model_failure_on_one_rank_reaches_every_rank(where):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, outcome, has_mtx in res:
+    for rank, outcome, has_mtx, counted in res:
         assert outcome[0] == outcome[1] == outcome[3] == "ok", (rank, outcome)
         assert outcome[2].startswith("raised: a rank failed"), (rank, outcome)
         assert has_mtx
@@ -423,7 +424,7 @@ def test_a_board_fold_exception_on_rank_0_reaches_every_rank():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, outcome, has_mtx in res:
+    for rank, outcome, has_mtx, counted in res:
         assert outcome[0] == outcome[1] == outcome[3] == "ok", (rank, outcome)
         assert outcome[2].startswith("raised: a rank failed"), (rank, outcome)
 
@@ -636,6 +637,9 @@ def test_a_board_path_failure_on_one_rank_reaches_every_rank():
         assert [i for i, x in enumerate(r["raised"]) if x is not None] == bad
         assert r["state"] == res[0]["state"] and r["mtxs"] == res[0]["mtxs"]
     assert any(m is not None for m in res[0]["mtxs"][bad[0] + 1:])
+    # the failed batch leaves a GAP, not a shorter film -- the fold advanced over the frames whose records never
+    # came as frames without a contour, so the running count every rank plans the next batches from is the film's
+    assert res[0]["state"][0] == sum(LAZY_SIZES) and res[0]["seen"] == sum(LAZY_SIZES)
 
 
 def test_hold_off_aware_pipeline_equals_the_eager_one_and_computes_a_fraction_of_the_records():

@@ -6,7 +6,7 @@
 set -e
 export TMPDIR=/tmp
 O=gpurun_out
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 bench.py --no-cpu-baseline --no-extras > $O/bench_prof.json 2> $O/prof_bench.err
 echo "bench stats done"
@@ -38,18 +38,24 @@ else
   echo "FETCH_SIZE CALIBRATION SKIPPED (build or run failed: $O/fetch_calib_build.err, $O/fetch_calib.log)"; rm -f $O/fetch_calib.txt
 fi
 rm -rf $O/pmc_calib
-# the bf16 classifier (BASELINE config 5): kernel stats of the classifier alone, 128 frames per call
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cnn_bf16 -- python3 tools/cnn_modes.py 128 bf16 > $O/cnn_bf16.log 2> $O/prof_cnn_bf16.err
-find $O/prof_cnn_bf16 -name "*kernel_trace.csv" -delete 2>/dev/null || true
-find $O/prof_cnn_bf16 -name "*.db" -delete 2>/dev/null || true
-echo "bf16 classifier stats done"
-# the opt-in F16Q8 classifier: the same
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cnn_q8 -- python3 tools/cnn_modes.py 128 f16q8 > $O/cnn_q8.log 2> $O/prof_cnn_q8.err
-find $O/prof_cnn_q8 -name "*kernel_trace.csv" -delete 2>/dev/null || true
-find $O/prof_cnn_q8 -name "*.db" -delete 2>/dev/null || true
-echo "f16q8 classifier stats done"
-du -sh $O | tail -1
+# the headline bench line FIRST among what is left: nothing below may keep it from being produced
 python bench.py > $O/bench_full.json 2> $O/bench_full.err
 echo "bench done"
 python tools/stonefind_timing.py > $O/stonefind_timing.json 2> $O/stonefind_timing.err
 echo "stonefind timing done"
+# the bf16 classifier (BASELINE config 5) and the opt-in F16Q8 one: kernel stats of the classifier alone, 128 frames per call.
+# Profiles of optional modes: a failure is said, not fatal
+for mode in bf16 f16q8; do
+  tag=cnn_${mode/f16q8/q8}
+  if rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- python3 tools/cnn_modes.py 128 $mode > $O/$tag.log 2> $O/prof_$tag.err; then
+    echo "$mode classifier stats done"
+  else
+    echo "CLASSIFIER STATS OF MODE $mode FAILED (see $O/prof_$tag.err): profiles/${R}_${tag}_* not refreshed"
+  fi
+  find $O/prof_$tag -name "*kernel_trace.csv" -delete 2>/dev/null || true
+  find $O/prof_$tag -name "*.db" -delete 2>/dev/null || true
+done
+# K1 across content classes (exactness against a sort-based median included) and the margin probe of the reduced-precision modes
+python tools/k1_content.py 5 > $O/k1_content.txt 2>&1 || echo "K1 CONTENT RUN FAILED (see $O/k1_content.txt)"
+python tools/margin_probe.py 16 1 > $O/margin_probe.txt 2>&1 || echo "MARGIN PROBE FAILED OR BEYOND ITS GATE (see $O/margin_probe.txt)"
+du -sh $O | tail -1
