@@ -34,5 +34,5 @@ open("profiles/%s_bench.json" % R, "w").write(line)
 d = json.loads(line)
 print(d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], d["filter_pass_fused"]["frac"],
       d.get("fp32_chain", {}).get("value"), d.get("pcie_inclusive", {}).get("value"), d["cpu_baseline"]["value"])
-print({k: round(v["us_per_frame"], 2) for k, v in d["stages"].items()})
+print({k: round(v[2] if isinstance(v, list) else v["us_per_frame"], 2) for k, v in d["stages"].items()})
 PY
