@@ -507,19 +507,31 @@ void phase_targets(ck_policy* p, long long f, const uint8_t* rl, const double* r
     const bool quiet = quiet_frame(p, fgc);
     if (quiet && p->live_targets == 0) return;          // nothing to mark, nothing to decay, no region can be hot
     // mark, then decay                                                                 sf_neural.py:72-83
+    // (one branch-free pass over the 361 cells as flat arrays: the compiler vectorises it)
     uint8_t hot[G][G], busy[G][G];
-    int live = 0;
-    for (int r = 0; r < G; r++) for (int c = 0; c < G; c++) {
-        uint8_t t = p->targets[r][c];
-        const int32_t v = quiet ? 0 : fgc[r * G + c];
-        if (!p->hp_color[r][c] && v >= p->thr7[r][c]) t = (uint8_t)(t + TARGET_INCR);
-        if (t) t--;
-        p->targets[r][c] = t;
-        live += t != 0;
-        hot[r][c] = t > TARGET_THRESH;
-        busy[r][c] = v >= p->thr5[r][c];
+    int live = 0, any_hot = 0;
+    {
+        uint8_t* __restrict__ tg = &p->targets[0][0];
+        const uint8_t* __restrict__ hp = &p->hp_color[0][0];
+        const int32_t* __restrict__ t7 = &p->thr7[0][0];
+        const int32_t* __restrict__ t5 = &p->thr5[0][0];
+        uint8_t* __restrict__ ht = &hot[0][0];
+        uint8_t* __restrict__ bs = &busy[0][0];
+        for (int i = 0; i < G * G; i++) {
+            const int32_t v = quiet ? 0 : fgc[i];
+            const uint8_t marked = (uint8_t)((hp[i] == 0) & (v >= t7[i]));
+            uint8_t t = (uint8_t)(tg[i] + (uint8_t)(marked * TARGET_INCR));
+            t = (uint8_t)(t - (uint8_t)(t != 0));
+            tg[i] = t;
+            live += t != 0;
+            const uint8_t h = (uint8_t)(t > TARGET_THRESH);
+            ht[i] = h;
+            any_hot |= h;
+            bs[i] = (uint8_t)(v >= t5[i]);
+        }
     }
     p->live_targets = live;
+    if (!any_hot) return;                               // no region can be selected
     // select + predict                                                                 sf_neural.py:101-154
     struct Mv { int color, r, c; double conf; };
     std::vector<Mv> mv;
