@@ -759,7 +759,8 @@ class FastFilePipeline:
     `gobans` (n x 380 x 380 x 3) is only handed back when world > 1, for the pixel-sharded background model."""
 
     def __init__(self, h, w, controller, ctx=None, rank=0, world=1, device=None, compute=None, ctx_board=None,
-                 bg_init_frames=50, band_model=None, lanes=None, ctx_bg=None, board_lazy=False, force_exchange=False):
+                 bg_init_frames=50, band_model=None, lanes=None, ctx_bg=None, board_lazy=False, force_exchange=False,
+                 records_in_hbm=None):
         self.h, self.w = h, w
         self.rank, self.world = rank, world
         self.group = _Group(rank, world, device)
@@ -772,8 +773,12 @@ class FastFilePipeline:
         self._owns_compute = compute is None
         # the records go through RCCL from HBM: the library writes them there (GpuCore) and nothing is staged on the host;
         # with one rank, or collectives on host buffers (gloo), they are written in host memory and used from there
+        # records_in_hbm: a torch device to force the HBM form whatever the collectives' buffers are (rehearsal on one GPU:
+        # two processes over gloo still have the library write their records in HBM; they cross to the host for the wire)
         self.records_device = None
-        if self.exchange and device is not None and str(device).startswith("cuda"):
+        if records_in_hbm is not None and records_in_hbm is not False:
+            self.records_device = records_in_hbm
+        elif self.exchange and device is not None and str(device).startswith("cuda"):
             self.records_device = device
         if compute is None:
             compute = GpuCore(lanes or [(ctx_board, ctx)], bg_ctx=ctx_bg, local_model=not self.exchange,

@@ -45,8 +45,11 @@ def _drive(rank, world, depth=2, force_nccl=False, lazy=False):
         pipe = pipeline.FastFilePipeline(H, W, ctrl, rank=0, world=1, device=torch.device("cuda", 0), lanes=lanes,
                                          ctx_bg=capi.Context(0, priority=1), bg_init_frames=BG, force_exchange=True, board_lazy=lazy)
     else:
+        # (two RCCL ranks cannot share a device, so with two processes the collectives run on host buffers over gloo -- but the
+        # records are still written by the library in HBM, as on a multi-GPU node: records_in_hbm)
         pipe = pipeline.FastFilePipeline(H, W, ctrl, rank=rank, world=world, device=torch.device("cpu") if world > 1 else None,
-                                         lanes=lanes, ctx_bg=capi.Context(0), bg_init_frames=BG, board_lazy=lazy)
+                                         lanes=lanes, ctx_bg=capi.Context(0), bg_init_frames=BG, board_lazy=lazy,
+                                         records_in_hbm=torch.device("cuda", 0) if world > 1 else None)
     pipe.board.refresh_frames = 5            # keep looking: the bump must be noticed within a batch or two
     mine, batches = [], []
     for b0 in range(0, FILM, BATCH):
@@ -152,6 +155,7 @@ def test_two_ranks_with_real_kernels_equal_one_rank():
     n_batches = FILM // BATCH
     assert r0["host_bytes"]["gather"] >= n_batches * BATCH * pipeline.REC_BYTES
     assert r1["host_bytes"]["gather"] == 0 and r1["host_bytes"]["bcast"] <= n_batches * 8 * 16 and r1["host_bytes"]["flag"] <= 4 * n_batches
+    assert r0["records_in_hbm"] and r1["records_in_hbm"]                            # written in place in HBM on both ranks
 
 
 @pytest.mark.gpu
