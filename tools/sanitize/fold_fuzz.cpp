@@ -95,6 +95,70 @@ int main()
         ck_policy_get_state(p, tg, hc, he, cf, flags);
         ck_policy_destroy(p);
     }
-    std::printf("ordered halves: %ld hull vertices, %ld positive board frames, %ld policy requests, clean\n", hull_pts, found_total, requests);
+    // ---- round 6: the folds over gathered records (ck_boardfold_run / ck_policy_run_records), records read through an order
+    // table as the gather leaves them (rank after rank, a header row first), and the exact round(x, 10)
+    long events = 0, rec_requests = 0;
+    {
+        const int W = 3, per = 40, n = W * per - 2;                     // the last two slots of the deal stay empty
+        std::vector<ck_frame_record> rows((size_t)W * (per + 1));
+        std::memset(rows.data(), 0, rows.size() * sizeof(ck_frame_record));
+        std::vector<int32_t> order((size_t)n);
+        const float sides[4][2] = { { 100.f, 0.05f }, { 540.f, 0.08f }, { 60.f, 1.55f }, { 420.f, 1.62f } };
+        for (int f = 0; f < n; f++) {
+            order[(size_t)f] = (f % W) * (per + 1) + 1 + f / W;
+            ck_frame_record& r = rows[(size_t)order[(size_t)f]];
+            r.status = uni(0, 9) < 8 ? CK_BOARD_LINES : uni(1, 2);
+            r.n_lines = f % 17 == 0 ? 90 : uni(0, 12);                    // more lines found than a record holds: flagged, 64 kept
+            r.flags = r.n_lines > CK_REC_LMAX ? CK_REC_LINES_CUT : 0;
+            for (int i = 0; i < (r.n_lines < CK_REC_LMAX ? r.n_lines : CK_REC_LMAX); i++) {
+                r.lines[i][0] = sides[i % 4][0] + (float)uni(-1, 1);
+                r.lines[i][1] = sides[i % 4][1];
+            }
+            for (int k = 0; k < 100; k++) { r.region_label[k] = (uint8_t)uni(0, 80); r.region_conf[k] = uni(0, 1000) / 1000.0; }
+        }
+        ck_boardfold* bf2 = nullptr;
+        if (ck_boardfold_create(&bf2) != CK_OK) return 1;
+        for (int pass = 0; pass < 2; pass++) {
+            int32_t k = 0, hold = 0, found = 0, update = 0, cen[8], ncen = 0, stats[2];
+            long long counter = 0, seen_looked[2] = { 0, 0 };
+            int32_t hull[8] = { 10, 10, 630, 12, 632, 470, 9, 468 };
+            bool have_hull = false;
+            for (int guard = 0; k < n && guard < 10000; guard++) {
+                const int rc = ck_boardfold_run(bf2, 480, 640, rows.data(), pass ? order.data() : nullptr, pass ? n : (int)rows.size(), &k, &counter,
+                                                &hold, seen_looked, have_hull ? hull : nullptr, pass ? 5 : -1, &found, &update, cen, &ncen, stats);
+                if (rc == CK_ERR_STATE) { k++; counter++; continue; }     // the reference's IndexError: skip the frame, go on
+                if (rc != CK_OK) { std::printf("boardfold_run: rc %d\n", rc); return 1; }
+                if (update && ncen == 4) { std::memcpy(hull, cen, sizeof hull); have_hull = true; }
+                if (found && (update || pass == 0)) hold = 5;
+                events += found || update;
+            }
+            if (seen_looked[0] < seen_looked[1]) { std::puts("boardfold_run: looked at more frames than it saw"); return 1; }
+        }
+        ck_boardfold_destroy(bf2);
+        ck_policy* p = nullptr;
+        if (ck_policy_create(5, &p) != CK_OK) return 1;
+        std::vector<int32_t> fg((size_t)n * 361), moves(3 * 722);
+        std::vector<uint8_t> board(361, 0);
+        for (auto& v : fg) v = uni(0, 9) < 7 ? 0 : uni(150, 400);
+        int32_t frame = 0, phase = 0, kind = 0, nm = 0;
+        for (int guard = 0; guard < 100000; guard++) {
+            if (ck_policy_run_records(p, n, 0, rows.data(), order.data(), fg.data(), board.data(), &frame, &phase, &kind, moves.data(), 722,
+                                      &nm) != CK_OK) { std::puts("policy_run_records: error"); return 1; }
+            if (!kind) break;
+            rec_requests++;
+            for (int i = 0; i < nm; i++) board[(size_t)moves[3 * i + 1] * 19 + moves[3 * i + 2]] = (uint8_t)moves[3 * i];
+        }
+        if (frame != n) { std::puts("policy_run_records: run did not finish"); return 1; }
+        ck_policy_destroy(p);
+        const double probes[] = { 0.0, -0.0, 0.5, 0.49999999995, 1.00000000005, -1.0, 5e-324, 1e-300, 524287.99999999994, 524288.0, 1e22, -1e22 };
+        for (double x : probes)
+            if (ck_round10(x) != ck_round10_reference(x)) { std::printf("round10(%.17g): %.17g != %.17g\n", x, ck_round10(x), ck_round10_reference(x)); return 1; }
+        for (int i = 0; i < 200000; i++) {
+            const double x = (uni(-1000000, 1000000) + 0.5) / 1e10 * (i % 3 ? 1.0 : 1000.0);
+            if (ck_round10(x) != ck_round10_reference(x)) { std::printf("round10(%.17g) differs\n", x); return 1; }
+        }
+    }
+    std::printf("ordered halves: %ld hull vertices, %ld positive board frames, %ld policy requests, %ld fold events and %ld requests over gathered "
+                "records, clean\n", hull_pts, found_total, requests, events, rec_requests);
     return 0;
 }
