@@ -112,8 +112,9 @@ def shard_buffer(n, device=None):
 
 def records_view(buf):
     """a host record buffer (numpy REC array, or uint8 bytes of it) as a REC array"""
-    a = buf if isinstance(buf, np.ndarray) else buf.numpy()
-    return a if a.dtype == REC else a.view(REC).reshape(a.shape[:-1])
+    if not isinstance(buf, np.ndarray):
+        buf = (buf.cpu() if buf.is_cuda else buf).numpy()     # (records forced into HBM on a rank that folds them itself)
+    return buf if buf.dtype == REC else buf.view(REC).reshape(buf.shape[:-1])
 
 
 def board_into(ctx, frames, rows):
