@@ -793,7 +793,7 @@ def main():
                 if xp.mtx is None:
                     xp.mtx = M_true
                 same_x = xp.process_batch(frames, n_total) == requests
-                k = max(4, args.steps // 2)
+                k = max(4, args.steps)                         # (the ratio of two short timings is noisy: as many steps as the headline)
                 dx = timed(xp, k, 2, frames)
                 dp = timed(pipe, k, 2, frames)                 # the plain pipeline again, right after: same box state
                 xp.close()

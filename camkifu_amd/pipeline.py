@@ -213,21 +213,44 @@ class _Group:
         self.host_bytes["gather"] += out.numel()
         return self._to_host(out, lease)
 
+    def _small(self, key, shape, dtype):
+        """a persistent small tensor where the collectives' buffers live (and, for device buffers, its pinned host twin): the
+        wire and the flag word are a few bytes per batch -- no allocation, no pageable staging copy"""
+        import torch
+        slot = self._landing.get(("small", key, shape))
+        if slot is None:
+            dev = torch.device(self.device) if self.device is not None else torch.device("cpu")
+            t = torch.zeros(shape, dtype=dtype, device=dev)
+            slot = (t, torch.zeros(shape, dtype=dtype, pin_memory=True) if t.is_cuda else None)
+            self._landing[("small", key, shape)] = slot
+        return slot
+
     def broadcast_array(self, a, src=0):
-        """-> the source's array on every rank; the source itself reads nothing back (it holds the array)"""
+        """-> the source's array (float64) on every rank; the source itself reads nothing back (it holds the array) and
+        uploads through pinned memory without waiting"""
+        import torch
         import torch.distributed as dist
-        t = self.on_wire(a)
+        a = np.ascontiguousarray(a, np.float64)
+        t, pinned = self._small("wire", tuple(a.shape), torch.float64)
+        if self.rank == src:
+            if pinned is not None:
+                pinned.numpy()[...] = a
+                t.copy_(pinned, non_blocking=True)
+            else:
+                t.copy_(torch.from_numpy(a))
         dist.broadcast(t, src)
         if self.rank == src:
-            return np.asarray(a)
+            return a
         self.host_bytes["bcast"] += t.numel() * t.element_size()
         return t.cpu().numpy()
 
     def max_flag_start(self, value):
         """one int32 word all-reduced with MAX: every rank learns whether (and which) rank raised a flag.  Issued here, read
         with max_flag_read -- after whatever else the caller queues behind it, so that ONE host wait covers both"""
+        import torch
         import torch.distributed as dist
-        t = self.on_wire(np.array([int(value)], np.int32))
+        t, _ = self._small("flag", (1,), torch.int32)
+        t.fill_(int(value))                                   # (a fill on the device: nothing to upload)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t
 
