@@ -622,6 +622,7 @@ class BoardFoldCore:
         if lib().ck_boardfold_create(C.byref(self._h)) != 0:
             raise CkError("ck_boardfold_create failed")
         self._out = np.zeros(16, np.int32)          # found, update, n_centers, pad, centers[8], stats[2]
+        self._io32, self._io64 = np.zeros(2, np.int32), np.zeros(3, np.int64)      # ck_boardfold_run: (k, hold), (counter, seen, looked)
 
     def __del__(self):
         try:
@@ -662,8 +663,6 @@ class BoardFoldCore:
             assert order.dtype == np.int32 and order.flags.c_contiguous
             n = len(order)
         hull = None if cur_hull is None else np.ascontiguousarray(cur_hull, np.int32).reshape(8)
-        if not hasattr(self, "_io32"):
-            self._io32, self._io64 = np.zeros(2, np.int32), np.zeros(3, np.int64)
         io32, io64 = self._io32, self._io64
         io32[:] = (k, hold)
         io64[:] = (counter, seen, looked)

@@ -51,8 +51,7 @@ for name, batch in (("bench_scene", frames), ("natural_texture", nat), ("smooth_
     wrong = 0
     for (y0, x0) in ((0, 0), (H - 240, W - 320), (400, 800)):
         # the reference median of a 240 x 320 window is computed on the window grown by the filter's reach (7 px, clipped at
-        # the frame): inside the window its replicate border is then the frame's own, except along window edges that are
-        # not frame edges and could not be grown -- there are none: the window is grown wherever the frame allows
+        # the frame): inside the window the replicate border the reference pads with is then the frame's own
         ya, xa = max(0, y0 - 7), max(0, x0 - 7)
         grown = reference_median(batch[0, ya:min(H, y0 + 247), xa:min(W, x0 + 327)])
         want = grown[y0 - ya:y0 - ya + 240, x0 - xa:x0 - xa + 320]
