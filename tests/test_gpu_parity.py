@@ -826,6 +826,39 @@ def test_board_detect_random_textures(ck, ora, seed):
             assert out[k]["biggest_area"] == ref["biggest_area"], (seed, k)
 
 
+@pytest.mark.parametrize("contrast", [25.0, 60.0])
+def test_board_and_stones_paths_on_a_textured_table(ck, ora, synth, contrast):
+    """round 6: the bench's new content class.  A filmed game on a table with a 1/f-spectrum texture (synth.natural_texture:
+    +-25 grey levels as in the bench, and +-60 -- strong enough to leave edges of its own after the 15 x 15 median): every
+    stage of the board path against the oracle chain bit for bit (median, Canny, contours, lines), and the 19 x 19 labels of
+    the stones path.  The radix side of K1 and the unskipped tiles of K2 are what this content exercises (the plain scene is
+    56 % flat tiles that take the linear scan and are skipped by the NMS)."""
+    from camkifu_amd import capi
+    from camkifu_amd.stone.nn_manager import NNManager
+    h, w = 480, 640
+    table = synth.natural_texture(h, w, seed=11, contrast=contrast)
+    frames, corners, truth, moves, hands = synth.film(12, h, w, seed=5, quiet=2, move_every=4, hand_frames=2, background=table)
+    frames = frames.numpy()[[0, 5, 11]]
+    med = np.asarray(ck.median15(frames))
+    out = ck.board_detect(frames)
+    W8 = NNManager.init_net()
+    ck.cnn_set_weights(W8)
+    M = capi.get_perspective_transform(corners, np.array([(0, 0), (380, 0), (380, 380), (0, 380)], np.float32))
+    labels, conf = ck.stones_detect(frames, M)
+    for k in range(len(frames)):
+        want_med = ora.median(frames[k], 15)
+        assert np.array_equal(med[k], want_med), k
+        ref = ora.board_lines(ora.canny(want_med, 25, 75))
+        assert out[k]["n_contours"] == ref["n_contours"], k
+        kk = max(ref["status"], 0)
+        assert out[k]["n_lines"] == kk and np.array_equal(out[k]["lines"][:kk], ref["lines"][:kk]), k
+        if ref["n_contours"]:
+            assert out[k]["biggest_area"] == ref["biggest_area"], k
+        lab, cf = ora.decode_all(ora.cnn_predict_regions(W8, ora.warp_perspective(frames[k], M)))
+        assert np.array_equal(np.asarray(labels)[k], lab), k
+    assert any(o["n_lines"] > 0 for o in out)                  # the board is still seen on the textured table
+
+
 def test_split_precision_falls_back_when_fp16_overflows(ck, synth):
     """activations beyond the fp16 range (weights blown up on purpose) turn into inf in the split-precision
     kernels; the decode kernel notices and the batch is recomputed by the f32 kernels: same bits as CK_CNN_FP32"""
