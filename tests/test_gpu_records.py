@@ -111,7 +111,6 @@ def test_both_halves_from_two_contexts_at_once_fill_one_buffer(setup):
     the same records in HBM at the same time; slices of one buffer per lane"""
     import threading
     from camkifu_amd import capi
-    from camkifu_amd.stone.nn_manager import NNManager
     ctx, frames, torch = setup
     other = capi.Context(0)
     try:
