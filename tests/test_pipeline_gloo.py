@@ -94,8 +94,9 @@ def _drive(rank, world):
     return out, ctrl.kifu.to_sgf(), mtx, pipe.stones.policy.state()["targets"].tolist()
 
 
-def _run(rank, world, port, q):
+def _run(rank, world, port, q, env=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(env or {})
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         q.put((rank,) + _drive(rank, world))
@@ -139,8 +140,12 @@ def test_grid_of_regions_matches_the_oracle(ora):
     assert np.array_equal(grid[0], want_l) and np.array_equal(cgrid[0], want_c)
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("world", [2, 3, 8, -3])
 def test_multi_rank_fold_equals_single_process(world):
+    """(world -3: three ranks with every rank's own goban band sent through the all-to-all as well, the form a one-GPU box
+    uses to exercise the RCCL call -- CK_BAND_SELF_THROUGH_COLLECTIVE; by default the own band is a local copy)"""
+    env = {"CK_BAND_SELF_THROUGH_COLLECTIVE": "1"} if world < 0 else None
+    world = abs(world)
     ref = _drive(0, 1)
     assert ref[2] is not None                                  # the fold did find the board
     assert any(req for batch in ref[0] for req in batch)       # and the policy emitted something afterwards
@@ -152,7 +157,7 @@ def test_multi_rank_fold_equals_single_process(world):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_run, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, q, env)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in range(world))
